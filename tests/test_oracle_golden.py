@@ -1,0 +1,164 @@
+"""CPU: the oracle restatement against the golden vectors generated from the real
+reference (oracle/tools/gen_goldens.py) and against the reference tests' known answers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import envs as E
+from oracle import learner as L
+
+ENVS = ["CartPole", "QuadPole2D", "QuadPole"]
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_single_step_matches_reference(name):
+    g = load_golden(f"env_step_{name.lower()}.npz")
+    nxt, rew, trunc, steps, tb = E.ENV_SPECS[name]["step"](
+        g["state"], g["action"], g["steps"], g["time_balanced"], max_steps=int(g["max_steps"]))
+    np.testing.assert_allclose(nxt, g["next_state"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(rew, g["reward"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(trunc, g["truncated"])                      # bit-exact flags
+    if name != "QuadPole":
+        np.testing.assert_allclose(tb, g["time_balanced_after"], rtol=0, atol=1e-15)
+    assert trunc.sum() > 8 and (~trunc).sum() > 100
+
+
+def test_cartpole_upright_known_answer():
+    # reference tests/test_cartpole.py:91-104: upright, zero action -> 0 < r < 5 (closed form 2.8)
+    nxt, rew, trunc, _, tb = E.cartpole_step(np.array([[0, 0, 0, 1, 0.0]]), np.zeros((1, 1), np.float32), [0], [0.0])
+    assert 0 < rew[0] < 5
+    assert rew[0] == pytest.approx(2.8, abs=1e-12)
+    assert not trunc[0] and tb[0] == pytest.approx(0.02)
+
+
+def test_cartpole_time_clause_is_inert_under_worker_cap():
+    for ms in (10, 64, 100, 128, 256, 500):
+        assert E.cartpole_time_trunc_step(ms) >= ms
+
+
+def test_quadrotor_dynamics():
+    g = load_golden("quadrotor_dynamics.npz")
+    np.testing.assert_allclose(E.quadrotor_dynamics(g["state"], g["control"]), g["next_state"], rtol=1e-12, atol=1e-13)
+
+
+def _policy_from_golden(g, prefix, S, A, hidden, cov, critic):
+    pol = L.OraclePolicy(S, A, hidden, cov=[float(c) for c in cov], critic=critic)
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+    if critic:
+        pol.actor.load_state_dict({k[len("actor."):]: v for k, v in sd.items() if k.startswith("actor.")})
+        pol.critic.load_state_dict({k[len("critic."):]: v for k, v in sd.items() if k.startswith("critic.")})
+    else:
+        pol.actor.load_state_dict(sd)
+    return pol
+
+
+@pytest.mark.parametrize("name,S,A,hidden,critic,T", [
+    ("CartPole", 5, 1, (128, 128), False, 128),
+    ("QuadPole2D", 10, 2, (32, 32), True, 128),
+    ("QuadPole", 20, 4, (64, 64), True, 256)])
+@pytest.mark.parametrize("tag", ["reset", "restart"])
+def test_teacher_forced_rollout_matches_reference(name, S, A, hidden, critic, T, tag):
+    g = load_golden(f"rollout_{name.lower()}.npz")
+    obs, act, rew, ln, mask = (g[f"{tag}_{k}"] for k in ("obs", "act", "rew", "len", "mask"))
+    G, Eps = ln.shape
+    assert obs.shape == (G, Eps, T, S) and act.shape == (G, Eps, T, A)    # reference tests/test_rollout_manager.py:40-53
+    assert rew.shape == (G, Eps, T) and mask.shape == (G, Eps, T)
+    init = obs[:, :, 0, :].astype(np.float64)
+    o2, a2, r2, l2, m2 = L.rollout(lambda: L.OracleEnv(name, max_steps=T), None, G, Eps,
+                                   restart=(tag == "restart"), initial_states=init, forced_actions=act)
+    assert np.array_equal(l2.numpy(), ln)            # bit-exact lengths
+    assert np.array_equal(m2.numpy(), mask)          # bit-exact masks
+    assert l2.dtype == torch.float32
+    # initial obs went through a float32 round trip in the fixture -> trajectories agree to fp32 noise
+    np.testing.assert_allclose(o2.numpy(), obs, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(r2.numpy(), rew, rtol=2e-4, atol=2e-4)
+    assert np.array_equal(a2.numpy(), act)
+    # zero padding beyond each episode
+    assert np.all(obs[mask == 0] == 0) and np.all(o2.numpy()[m2.numpy() == 0] == 0)
+    if tag == "restart":
+        assert np.array_equal(obs[:, 1:, 0, :], np.broadcast_to(obs[:, :1, 0, :], obs[:, 1:, 0, :].shape))
+
+
+@pytest.mark.parametrize("kind", ["actor", "actorcritic"])
+def test_policy_closed_forms(kind):
+    g = load_golden(f"policy_{kind}.npz")
+    pol = _policy_from_golden(g, "policy.", 20, 4, (64, 64), g["cov"], kind == "actorcritic")
+    obs = torch.from_numpy(g["obs"])
+    mean = pol.actor(obs).detach()
+    np.testing.assert_allclose(mean.numpy(), g["mean"], rtol=0, atol=1e-6)
+    action = mean + torch.sqrt(pol.var) * torch.from_numpy(g["eps"])
+    np.testing.assert_allclose(action.numpy(), g["action"], rtol=0, atol=1e-6)
+    lp, ent = pol.log_prob(obs, torch.from_numpy(g["action"]))
+    np.testing.assert_allclose(lp.detach().numpy(), g["logp_eval"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(lp.detach().numpy(), g["logp"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ent.numpy(), g["entropy"], rtol=0, atol=1e-6)
+    if kind == "actorcritic":
+        np.testing.assert_allclose(pol.value(obs).detach().numpy(), g["value_squeezed"], rtol=0, atol=1e-6)
+    # sampling identity: MultivariateNormal.sample() == mean + sqrt(var) * randn, same stream
+    torch.manual_seed(9)
+    a1, _, _ = pol(g["obs"][0])
+    np.testing.assert_allclose(a1, g["action_row0"], rtol=0, atol=1e-6)
+
+
+def test_rtg_known_answer_from_reference_test():
+    # reference tests/test_rollout_buffer.py:76-92 (gamma 0.99, no masks)
+    rew = np.array([[[1, 2, 3], [0, 1, 2]], [[3, 2, 1], [1, 0, 1]]], dtype=np.float32)
+    exp = np.zeros_like(rew)
+    for j in range(2, -1, -1):
+        exp[:, :, j] = rew[:, :, j] + (0.99 * exp[:, :, j + 1] if j < 2 else 0)
+    got = L.rtg_scan(torch.from_numpy(rew), torch.ones(2, 2, 3), 0.99).numpy()
+    np.testing.assert_allclose(got, exp, atol=1e-5)
+
+
+@pytest.mark.parametrize("gamma", [0.5, 0.99, 0.999])
+def test_returns_and_advantages(gamma):
+    g = load_golden("rtg_adv.npz")
+    rew, mask = torch.from_numpy(g["rew"]), torch.from_numpy(g["mask"])
+    tag = f"g{gamma}"
+    rtg = L.rtg_scan(rew, mask, gamma)
+    np.testing.assert_allclose(rtg.numpy(), g[f"{tag}_rtg"], rtol=0, atol=1e-5)
+    for i, adv in enumerate(L.grpo_group_advantages(rtg, mask)):
+        np.testing.assert_allclose(adv.numpy(), g[f"{tag}_grpo_adv_{i}"], rtol=1e-5, atol=1e-5)
+    values = torch.from_numpy(g[f"{tag}_values"])
+    for kind, mc in (("mc", True), ("gae", False)):
+        adv, ret = L.ppo_advantages(rew, mask, values, gamma, 0.95, mc)
+        np.testing.assert_allclose(adv.numpy(), g[f"{tag}_ppo_{kind}_adv"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ret.numpy(), g[f"{tag}_ppo_{kind}_ret"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_upd", [1, 2])
+def test_grpo_step(n_upd):
+    g = load_golden(f"grpo_step_u{n_upd}.npz")
+    pol = _policy_from_golden(g, "init.", 5, 1, (32, 32), [float(g["cov"])], False)
+    old = _policy_from_golden(g, "old_init.", 5, 1, (32, 32), [float(g["cov"])], False)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    t = lambda k: torch.from_numpy(g[k])
+    Js = L.grpo_learn(pol, old, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=float(g["epsilon"]),
+                      gamma=float(g["gamma"]), updates_per_iter=n_upd)
+    np.testing.assert_allclose(Js, g["J"], rtol=1e-4, atol=2e-6)
+    for k, p in pol.actor.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), g[f"final.{k}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(p.grad.numpy(), g[f"lastgrad.{k}"], rtol=1e-3, atol=1e-5)
+    # sign convention F6: the reference DEscends on J.  With lr>0 and old==policy on the first
+    # pass (ratio == 1) the first-order change of J is -lr * |g|_adam <= 0.
+    assert float(g["J"][0]) == pytest.approx(Js[0], abs=2e-6)
+
+
+@pytest.mark.parametrize("n_upd", [1, 2])
+def test_ppo_step(n_upd):
+    g = load_golden(f"ppo_step_u{n_upd}.npz")
+    pol = _policy_from_golden(g, "init.", 10, 2, (32, 32), [float(g["cov"])] * 2, True)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    t = lambda k: torch.from_numpy(g[k])
+    logs = L.ppo_learn(pol, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=float(g["epsilon"]),
+                       gamma=float(g["gamma"]), c1=float(g["c1"]), kl_coeff=float(g["kl_coeff"]),
+                       entropy_coeff=float(g["entropy_coeff"]), updates_per_iter=n_upd)
+    np.testing.assert_allclose([l["total"] for l in logs], g["total_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([l["actor"] for l in logs], g["actor_loss"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose([l["critic"] for l in logs], g["critic_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([l["kl"] for l in logs], g["kl_div"], rtol=1e-4, atol=1e-7)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
+            np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(p.grad.numpy(), g[f"lastgrad.{net}.{k}"], rtol=1e-3, atol=1e-6)
