@@ -1,0 +1,201 @@
+/*
+ * trajopt_grpo_hip.h -- C ABI of the MI355X (gfx950) rollout / returns / loss kernels.
+ *
+ * The reference (Dyllon-Preston/trajopt-grpo @ 2025-06-13) is pure Python and has no
+ * FFI of its own; its drop-in seam is the duck-typed Python surface of SURVEY.md 8(b).
+ * This library is what that surface's GPU implementation binds (ctypes, see
+ * INTEGRATION.md): each entry point names the reference code whose arithmetic it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (hipMalloc / torch CUDA storage);
+ *   - `stream` is a hipStream_t passed as void*; all calls only ENQUEUE work on it
+ *     (no allocation, no synchronisation: they are hipGraph-capturable);
+ *   - return value: 0 = ok, negative = error (TG_ERR_*); tg_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI;
+ *   - struct-of-arrays layouts, env index fastest:
+ *       state      [S][ld]            component-major, ld >= n
+ *       trajectory obs [S][T+1][n], act [A][T][n], rew [T][n], mask [T][n] (u8),
+ *       len [n] (i32).  Slot t of obs is the observation BEFORE action t
+ *       (rollout/rollout_worker.py:53); slot t+1 is written only while the
+ *       episode is still running, so padding stays zero (rollout_worker.py:37-41).
+ *   - flat env index n = g*E + e  (buffers/rollout_buffer.py:85-89).
+ */
+#ifndef TRAJOPT_GRPO_HIP_H
+#define TRAJOPT_GRPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
+
+/* environments (environments/cartpole_env.py, environments/quadrotor_env.py) */
+enum { TG_ENV_CARTPOLE = 0, TG_ENV_QUADPOLE2D = 1, TG_ENV_QUADPOLE = 2, TG_ENV_QUADROTOR12 = 3 };
+/* arithmetic type of the environment state / trajectory */
+enum { TG_F32 = 0, TG_F64 = 1 };
+
+/* Physical parameters.  p[] meaning per env (defaults = the reference constructors):
+ *  CARTPOLE   (cartpole_env.py:7-16):  p0 masscart, p1 masspole, p2 length, p3 gravity
+ *  QUADPOLE2D (quadrotor_env.py:875-895): p0 mq, p1 mp, p2 I, p3 Lq, p4 Lp, p5 gravity,
+ *                                         p6 bound (|x|,|z| <= p6), p7 balance_radius
+ *  QUADPOLE   (quadrotor_env.py:362-382): p0 mass, p1 load_mass, p2 gravity, p3 tether,
+ *                                         p4 Ixx, p5 Iyy, p6 Izz, p7 torque_constant, p8 arm,
+ *                                         p9 bound
+ *  QUADROTOR12(quadrotor_env.py:9-16):   p0 mass, p1 arm_length, p2 Ixx, p3 Iyy, p4 Izz,
+ *                                         p5 torque_constant, p6 gravity
+ * time_trunc_step: CartPole only -- first step count at which the reference's
+ *  float-accumulated `_time > max_time` fires (cartpole_env.py:168); filled by
+ *  tg_env_default_params / tg_env_finalize_params. */
+typedef struct tg_env_params {
+    int32_t env_id;
+    int32_t max_steps;
+    int32_t time_trunc_step;
+    int32_t reserved;
+    double  timestep;
+    double  p[12];
+} tg_env_params;
+
+/* GPU-resident trajectory of one rollout (this rank's shard). */
+typedef struct tg_traj {
+    void*     d_obs;      /* real [S][T+1][n] */
+    float*    d_act;      /* f32  [A][T][n]   (policies emit float32: actor_critic.py:138) */
+    void*     d_rew;      /* real [T][n] */
+    uint8_t*  d_mask;     /* u8   [T][n] */
+    int32_t*  d_len;      /* i32  [n]; 0 while the episode is running */
+    uint64_t* d_counters; /* u64  [4]: [0] env-steps executed (= sum of mask), [1] episodes ended */
+    int64_t   n;
+    int32_t   horizon;    /* T = env.max_steps */
+    int32_t   dtype;      /* TG_F32 | TG_F64 */
+} tg_traj;
+
+const char* tg_last_error(void);
+int  tg_abi_version(void);
+
+int  tg_env_dims(int env_id, int* obs_dim, int* act_dim);
+int  tg_env_default_params(int env_id, int max_steps, tg_env_params* out);
+/* recompute derived fields (time_trunc_step) after the caller edited max_steps/timestep */
+int  tg_env_finalize_params(tg_env_params* p);
+
+/* reset(): draw initial states with the reference's distributions
+ * (cartpole_env.py:102-119, quadrotor_env.py:530-576, :930-961) from a counter-based
+ * Philox4x32-10 stream keyed by (seed, stream_id, (key_offset + i) / key_div): with
+ * key_div = E all E episodes of a group share one draw (the `restart=True` semantics of
+ * rollout_worker.py:70-71); key_offset = this shard's first global env index, so results
+ * do not depend on how envs are sharded over GPUs.  Writes d_state[S][ld], columns 0..n-1. */
+int  tg_env_reset(const tg_env_params* p, int dtype, void* d_state, int64_t ld, int64_t n,
+                  uint64_t seed, uint64_t stream_id, int64_t key_offset, int64_t key_div,
+                  void* stream);
+
+/* step(): one Env.step for n independent envs on SoA state (may be in place:
+ * d_next == d_state).  cartpole_env.py:138-182, quadrotor_env.py:625-713, :1132-1223.
+ * d_action f32 [A][ld_a]; d_steps i32 [n] in/out (count before -> after);
+ * d_time_balanced real [n] in/out or NULL; d_reward real [n]; d_truncated u8 [n]. */
+int  tg_env_step(const tg_env_params* p, int dtype, const void* d_state, int64_t ld,
+                 const float* d_action, int64_t ld_a, void* d_next, int64_t ld_next,
+                 int32_t* d_steps, void* d_time_balanced, void* d_reward,
+                 uint8_t* d_truncated, int64_t n, void* stream);
+
+/* Quadrotor._dynamics (quadrotor_env.py:113-169): pure explicit-Euler map, raw control
+ * real [4][ld_c]; state real [12][ld]. */
+int  tg_quadrotor12_dynamics(const tg_env_params* p, int dtype, const void* d_state, int64_t ld,
+                             const void* d_control, int64_t ld_c, void* d_next, int64_t ld_next,
+                             int64_t n, void* stream);
+
+/* ---- GPU-resident rollout (replaces RolloutManager.rollout / RolloutWorker.run_episodes,
+ *      rollout/rollout_manager.py:85-125, rollout/rollout_worker.py:19-84) ---- */
+
+/* zero the trajectory + counters (padding must be zero: rollout_worker.py:37-41) */
+int  tg_rollout_begin(const tg_traj* tr, int obs_dim, int act_dim, void* stream);
+
+/* fused time step t for all n envs:
+ *   action source: d_mean != NULL  -> a = mean[i][:] + sigma * eps, eps ~ N(0,I) from
+ *                                     Philox keyed (seed, stream_id, env_offset + i, t)
+ *                                     (MultivariateNormal(mean, diag(sigma^2)).sample(),
+ *                                     actor_critic.py:131-133); action recorded in act[:,t,i];
+ *                  d_mean == NULL  -> teacher forcing: act[:,t,i] is read (parity runs);
+ *   then Env.step, reward/mask/len recording and episode termination.  A wavefront whose 64
+ *   envs have all ended (ballot == 0) exits before touching memory; env-steps are counted
+ *   with one atomic per wavefront (popcount of the ballot).
+ * d_rng: device u64[2] = {seed, stream_id} (read by the kernel so a captured graph can be
+ * replayed with a fresh stream id).  sigma: host float[A] = sqrt(diag(cov)). */
+int  tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const float* d_mean,
+                     int64_t mean_row_stride, const float* sigma, const uint64_t* d_rng,
+                     int64_t env_offset, void* stream);
+
+/* counters[0] = sum of episode lengths (= env-steps executed = sum of mask),
+ * counters[1] = episodes ended.  rollout/rollout_worker.py:67-68 */
+int  tg_rollout_finish(const tg_traj* tr, void* stream);
+
+/* d_rng[1] += 1 (enqueued; one thread) */
+int  tg_rng_advance(uint64_t* d_rng, void* stream);
+
+/* ---- returns / advantages (algorithms/grpo.py:66-74,110-115; algorithms/ppo.py:93-139) ---- */
+
+/* reward-to-go reverse scan, fp32, bit-for-bit the reference recurrence:
+ *   R[T-1] = r[T-1] m[T-1];  R[t] = r[t] m[t] + (gamma R[t+1]) m[t+1]      [T][n] layout */
+int  tg_rtg_scan(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg,
+                 int64_t n, int32_t T, void* stream);
+
+/* GAE branch (ppo.py:112-124): adv and ret = values + adv */
+int  tg_gae_scan(const float* d_rew, const float* d_values, const uint8_t* d_mask, float gamma,
+                 float lam, float* d_adv, float* d_ret, int64_t n, int32_t T, void* stream);
+
+/* masked moments per group of `group_size` consecutive envs (all T steps):
+ * d_moments f64 [n/group_size][3] = {count, sum, sum of squares}; deterministic
+ * (no float atomics).  d_work: f64 [3*n] scratch. */
+int  tg_masked_moments(const float* d_x, const uint8_t* d_mask, int64_t n, int32_t T,
+                       int64_t group_size, double* d_moments, double* d_work, void* stream);
+
+/* mode 0 (GRPO, grpo.py:115): out = (x - mean_g) / std_g          (unbiased std, eps inside std)
+ * mode 1 (PPO,  ppo.py:138-139): out = (x - mean_g) / (std_g + 1e-8)
+ * masked-out entries are written as 0. */
+int  tg_group_normalize(const float* d_x, const uint8_t* d_mask, const double* d_moments,
+                        int mode, float* d_out, int64_t n, int32_t T, int64_t group_size,
+                        void* stream);
+
+/* ---- policy log-prob + fused clipped-surrogate loss (forward + backward) ----
+ * Gaussian policy with fixed diagonal covariance (actor_critic.py:100-103,159-160):
+ *   logp = -1/2 sum_k (a_k - mu_k)^2 / var_k - k/2 ln 2pi - 1/2 sum_k ln var_k
+ * rows are samples; mean is row-major [M][A] (row stride given); act element (i,k) is at
+ * d_act[i*act_row_stride + k*act_col_stride]. */
+int  tg_gaussian_logp(const float* d_mean, int64_t mean_row_stride, const float* d_act,
+                      int64_t act_row_stride, int64_t act_col_stride, const float* var,
+                      int act_dim, float* d_logp, int64_t M, void* stream);
+
+typedef struct tg_loss_args {
+    const float*   d_mean;  int64_t mean_row_stride;            /* [M][A] policy means */
+    const float*   d_act;   int64_t act_row_stride, act_col_stride;
+    const float*   d_logp_old;                                  /* [M] */
+    const float*   d_adv;                                       /* [M] */
+    const float*   d_value;                                     /* [M] or NULL (GRPO) */
+    const float*   d_ret;                                       /* [M] or NULL (GRPO) */
+    const uint8_t* d_mask;                                      /* [M] or NULL = all rows valid */
+    const float*   d_norm;   /* NULL, or device f32[4] {adv_mean, adv_inv_std, ret_mean, ret_inv_std}
+                                applied on the fly: x <- (x - mean) * inv_std   (ppo.py:138-139) */
+    float   var[8];          /* diag(cov) */
+    int32_t act_dim;
+    float   epsilon;         /* clip range */
+    float   surr_coef;       /* d(total)/d(sum_i min(rho A, clip(rho) A)):
+                                GRPO +1/G (descent on J as written, grpo.py:137-145);
+                                PPO  -1/n_valid (ppo.py:165) */
+    float   critic_coef;     /* PPO: c1/n_valid  (ppo.py:169,179); 0 for GRPO */
+    float   kl_coef;         /* PPO: kl_coeff/n_valid  (ppo.py:175-176); 0 for GRPO */
+    float*  d_grad_mean;     /* [M][A] row-major (row stride A): d total / d mean */
+    float*  d_grad_value;    /* [M] or NULL */
+    double* d_sums;          /* f64[4]: sum surrogate, sum (V-R)^2, sum exp(lp_old)(lp_old-lp), #valid */
+    double* d_work;          /* f64[4*tg_loss_work_blocks()] scratch */
+    int64_t M;
+} tg_loss_args;
+
+int  tg_loss_work_blocks(void);
+int  tg_surrogate_loss(const tg_loss_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJOPT_GRPO_HIP_H */

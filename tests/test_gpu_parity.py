@@ -1,0 +1,526 @@
+"""GPU parity tests (run on an MI355X with `-m gpu`): the HIP path, called through the C ABI,
+against the CPU oracle on seeded inputs and against the golden fixtures generated from the
+real reference.  Tolerances: bit-exact for indices / lengths / masks / flags; fp64 kernels
+<= 1e-11 on states and rewards; fp32 kernels within a few fp32 ulp per step (stated inline);
+fp32 returns within 1e-5 (the north-star bar)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import envs as E
+from oracle import learner as L
+
+pytestmark = pytest.mark.gpu
+
+ENVS = ["CartPole", "QuadPole2D", "QuadPole"]
+DIMS = {"CartPole": (5, 1), "QuadPole2D": (10, 2), "QuadPole": (20, 4)}
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import trajopt_grpo_amd as tg
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return tg
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def native_step(tg, name, state, action, steps, tb, max_steps, dtype, dev):
+    """tg_env_step through the C ABI on SoA device arrays."""
+    Nn = tg._native
+    env = tg.environments.ENV_CLASSES[name](max_steps=max_steps)
+    p = env.native_params()
+    n = state.shape[0]
+    st = torch.as_tensor(np.ascontiguousarray(state.T), dtype=dtype, device=dev)
+    ac = torch.as_tensor(np.ascontiguousarray(action.T), dtype=torch.float32, device=dev)
+    nx = torch.empty_like(st)
+    sp = torch.as_tensor(np.asarray(steps), dtype=torch.int32, device=dev)
+    tbt = torch.as_tensor(np.asarray(tb), dtype=dtype, device=dev)
+    rw = torch.empty(n, dtype=dtype, device=dev)
+    tr = torch.empty(n, dtype=torch.uint8, device=dev)
+    Nn.check(Nn.load().tg_env_step(C.byref(p), Nn.dtype_code(dtype), st.data_ptr(), n, ac.data_ptr(), n, nx.data_ptr(), n,
+                                   sp.data_ptr(), tbt.data_ptr(), rw.data_ptr(), tr.data_ptr(), n, Nn.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    return (nx.cpu().numpy().T.astype(np.float64), rw.cpu().numpy().astype(np.float64), tr.cpu().numpy().astype(bool),
+            sp.cpu().numpy(), tbt.cpu().numpy().astype(np.float64))
+
+
+# --------------------------------------------------------------------------------------------
+# single-step maps
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ENVS)
+def test_step_fp64_matches_reference_golden(tg, dev, name):
+    g = load_golden(f"env_step_{name.lower()}.npz")
+    nx, rw, tr, sp, tb = native_step(tg, name, g["state"], g["action"], g["steps"], g["time_balanced"],
+                                     int(g["max_steps"]), torch.float64, dev)
+    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(rw, g["reward"], rtol=1e-11, atol=1e-11)
+    assert np.array_equal(tr, g["truncated"])
+    assert np.array_equal(sp, g["steps"] + 1)
+    if name != "QuadPole":
+        np.testing.assert_allclose(tb, g["time_balanced_after"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_step_fp32_matches_reference_golden(tg, dev, name):
+    g = load_golden(f"env_step_{name.lower()}.npz")
+    nx, rw, tr, sp, tb = native_step(tg, name, g["state"], g["action"], g["steps"], g["time_balanced"],
+                                     int(g["max_steps"]), torch.float32, dev)
+    # one step in fp32: inputs are rounded to fp32 (6e-8 relative) and |state| <= ~20
+    np.testing.assert_allclose(nx, g["next_state"], rtol=2e-6, atol=5e-6)
+    scale = np.maximum(1.0, np.abs(g["reward"]))
+    assert np.all(np.abs(rw - g["reward"]) <= 2e-5 * scale)
+    # flags may only differ where the fp64 position sits within fp32 rounding of a threshold
+    diff = tr != g["truncated"]
+    if diff.any():
+        pos = np.abs(g["next_state"][diff][:, :3 if name == "QuadPole" else 2 if name == "QuadPole2D" else 1])
+        bound = {"CartPole": 1.0, "QuadPole2D": 2.0, "QuadPole": 1.5}[name]
+        assert np.all(np.min(np.abs(pos - bound), axis=1) < 1e-5)
+
+
+@pytest.mark.parametrize("name", ENVS)
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+def test_step_matches_oracle_on_seeded_batch(tg, dev, name, dtype, tol):
+    rng = np.random.default_rng(123)
+    S, A = DIMS[name]
+    n = 5000                                       # ragged vs the 64-lane wavefront on purpose
+    st = rng.normal(size=(n, S)) * 0.5
+    if name == "QuadPole":
+        for sl in (slice(6, 10), slice(13, 17)):
+            st[:, sl] /= np.linalg.norm(st[:, sl], axis=1, keepdims=True)
+    else:
+        for i0 in ((2,) if name == "CartPole" else (4, 7)):
+            ang = rng.uniform(-np.pi, np.pi, n)
+            st[:, i0], st[:, i0 + 1] = np.sin(ang), np.cos(ang)
+    if dtype == torch.float32:
+        st = st.astype(np.float32).astype(np.float64)
+    act = (rng.normal(size=(n, A)) * 0.8).astype(np.float32)
+    steps = rng.integers(0, 99, n)
+    tb0 = rng.choice([0.0, 0.02], n)
+    ref = E.ENV_SPECS[name]["step"](st, act, steps, tb0, max_steps=100)
+    nx, rw, tr, sp, tb = native_step(tg, name, st, act, steps, tb0, 100, dtype, dev)
+    np.testing.assert_allclose(nx, ref[0], rtol=tol, atol=tol)
+    np.testing.assert_allclose(rw, ref[1], rtol=tol, atol=tol * 50)
+    if dtype == torch.float64:
+        assert np.array_equal(tr, ref[2])
+    else:
+        assert (tr != ref[2]).mean() < 1e-3
+
+
+def test_quadrotor12_dynamics(tg, dev):
+    g = load_golden("quadrotor_dynamics.npz")
+    q = tg.Quadrotor(device=dev)
+    np.testing.assert_allclose(q._dynamics(g["state"], g["control"]), g["next_state"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(q._dynamics(g["state"][0], g["control"][0]), g["next_state"][0], rtol=1e-11, atol=1e-12)
+
+
+def test_scalar_env_dropin_api(tg, dev):
+    """reset / restart / step of one env instance: the reference's return conventions."""
+    env = tg.CartPole(max_steps=10, device=dev)
+    obs, info = env.reset()
+    assert obs.shape == (5,) and obs.dtype == np.float64 and info == {"time_balanced": 0}
+    assert obs[0] == 0 and obs[1] == 0 and obs[4] == 0 and abs(obs[2] ** 2 + obs[3] ** 2 - 1) < 1e-12
+    env.set_state([0, 0, 0, 1, 0.0])
+    o, r, term, trunc, info = env.step(np.zeros(1, np.float32))      # reference tests/test_cartpole.py:91-104
+    assert 0 < r < 5 and r == pytest.approx(2.8, abs=1e-12) and term is False and trunc is False
+    assert env._time_balanced == pytest.approx(0.02) and info["time_balanced"] == 0   # info is pre-update
+    o0, _ = env.restart()
+    np.testing.assert_array_equal(o0, [0, 0, 0, 1, 0])
+    for k in range(10):
+        o, r, term, trunc, _ = env.step(np.zeros(1, np.float32))
+    assert env._steps == 10
+    np.testing.assert_array_equal(env.state_dict["cartpole"], o)
+
+
+# --------------------------------------------------------------------------------------------
+# teacher-forced rollouts against the reference's in-process rollout
+# --------------------------------------------------------------------------------------------
+ROLL = [("CartPole", 128), ("QuadPole2D", 128), ("QuadPole", 256)]
+
+
+@pytest.mark.parametrize("name,T", ROLL)
+@pytest.mark.parametrize("tag", ["reset", "restart"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_teacher_forced_rollout_matches_reference(tg, dev, name, T, tag, dtype):
+    g = load_golden(f"rollout_{name.lower()}.npz")
+    obs, act, rew, ln, mask = (g[f"{tag}_{k}"] for k in ("obs", "act", "rew", "len", "mask"))
+    G, Eps = ln.shape
+    S, A = DIMS[name]
+    pol = tg.GaussianActor_NeuralNetwork(S, A, (8,), cov=0.5, device=dev)      # unused: actions are forced
+    mgr = tg.RolloutManager(lambda: tg.environments.ENV_CLASSES[name](max_steps=T), pol, restart=(tag == "restart"),
+                            num_workers=G, num_episodes_per_worker=Eps, dtype=dtype)
+    init = obs[:, :, 0, :].reshape(G * Eps, S)
+    o2, a2, r2, l2, m2 = mgr.rollout(initial_states=init, forced_actions=act)
+    assert o2.shape == obs.shape and a2.shape == act.shape and r2.shape == rew.shape       # shape contract
+    assert o2.dtype == torch.float32 and l2.dtype == torch.float32 and m2.dtype == torch.float32
+    assert np.array_equal(l2.numpy(), ln), "episode lengths must be bit-exact"
+    assert np.array_equal(m2.numpy(), mask), "masks must be bit-exact"
+    assert np.array_equal(a2.numpy(), act)
+    assert np.all(o2.numpy()[mask == 0] == 0) and np.all(r2.numpy()[mask == 0] == 0)       # zero padding
+    if dtype == torch.float64:
+        # the fixture's initial state went through float32; the fp64 kernel then tracks the fp64 reference
+        np.testing.assert_allclose(o2.numpy(), obs, rtol=0, atol=5e-4)
+        np.testing.assert_allclose(r2.numpy(), rew, rtol=2e-4, atol=2e-4)
+    else:
+        # fp32 state over up to 256 chaotic steps: compare where the episode is young, bound the rest
+        early = np.zeros_like(mask, dtype=bool)
+        early[:, :, :16] = True
+        np.testing.assert_allclose(o2.numpy()[early], obs[early], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(r2.numpy()[early[..., ]], rew[early], rtol=1e-3, atol=1e-3)
+    assert mgr.engine.traj.env_steps() == int(mask.sum())
+    assert list(mgr.episodes_completed) == [Eps] * G
+
+
+def test_rollout_worker_dropin(tg, dev):
+    g = load_golden("rollout_cartpole.npz")
+    obs, act, ln, mask = g["reset_obs"], g["reset_act"], g["reset_len"], g["reset_mask"]
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (8,), cov=0.5, device=dev)
+    done = [0, 0]
+    w = tg.RolloutWorker(1, tg.CartPole(max_steps=128), pol, done, dtype=torch.float64)
+    o, a, r, l, m = w.run_episodes(2, initial_states=obs[1, :, 0, :], forced_actions=act[1])
+    assert o.shape == (2, 128, 5) and l.dtype == torch.int32 and done == [0, 2]
+    assert np.array_equal(l.numpy(), ln[1].astype(np.int32)) and np.array_equal(m.numpy(), mask[1])
+
+
+# --------------------------------------------------------------------------------------------
+# sampled rollouts: invariants, determinism, independence of sharding
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ENVS)
+def test_sampled_rollout_invariants_and_oracle_replay(tg, dev, name):
+    S, A = DIMS[name]
+    T, G, Eps = 64, 3, 70                 # n = 210: not a multiple of the wavefront
+    torch.manual_seed(1)
+    pol = tg.GaussianActor_NeuralNetwork(S, A, (32, 32), cov=0.4, device=dev)
+    mk = lambda: tg.environments.ENV_CLASSES[name](max_steps=T)
+    mgr = tg.RolloutManager(mk, pol, num_workers=G, num_episodes_per_worker=Eps, dtype=torch.float64, seed=5)
+    obs, act, rew, ln, mask = mgr.rollout()
+    m = mask.numpy()
+    assert np.array_equal(m, (np.arange(T)[None, None, :] < ln.numpy()[..., None]).astype(np.float32))
+    assert np.all(obs.numpy()[m == 0] == 0) and np.all(act.numpy()[m == 0] == 0) and np.all(rew.numpy()[m == 0] == 0)
+    assert mgr.engine.traj.env_steps() == int(m.sum())
+    # the oracle replays the same initial states and actions
+    init = mgr.engine.traj.obs[:, 0, :].t().reshape(G, Eps, S).cpu().numpy()
+    o2, a2, r2, l2, m2 = L.rollout(lambda: L.OracleEnv(name, max_steps=T), None, G, Eps, initial_states=init,
+                                   forced_actions=act.numpy())
+    assert torch.equal(l2, ln) and torch.equal(m2, mask)
+    np.testing.assert_allclose(obs.numpy(), o2.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rew.numpy(), r2.numpy(), rtol=1e-5, atol=1e-5)
+    # initial-state distributions of the reference resets
+    i0 = init.reshape(-1, S)
+    if name == "CartPole":
+        assert np.all(i0[:, [0, 1, 4]] == 0) and np.allclose(i0[:, 2] ** 2 + i0[:, 3] ** 2, 1)
+    elif name == "QuadPole2D":
+        assert np.all(i0[:, [0, 1, 2, 3, 4, 6, 9]] == 0) and np.all(i0[:, 5] == 1)
+        assert np.allclose(i0[:, 7] ** 2 + i0[:, 8] ** 2, 1)
+    else:
+        assert np.all(i0[:, :6] == 0) and np.all(i0[:, 6] == 1) and np.all(i0[:, 7:13] == 0) and np.all(i0[:, 17:] == 0)
+        assert np.allclose((i0[:, 13:17] ** 2).sum(1), 1) and np.all(np.abs(i0[:, 16]) <= np.sin(0.5) ** 2 + 1e-12)
+    # sampled actions are mean + sigma*eps: eps has unit variance
+    mean0 = pol.actor(torch.as_tensor(init.reshape(-1, S), dtype=torch.float32, device=dev)).detach().cpu().numpy()
+    eps = (act.numpy()[:, :, 0, :].reshape(-1, A) - mean0) / np.sqrt(0.4)
+    assert abs(eps.mean()) < 0.2 and 0.7 < eps.std() < 1.3
+
+
+def test_rollout_is_deterministic_and_sharding_independent(tg, dev):
+    T, G, Eps = 32, 4, 64
+    torch.manual_seed(2)
+    pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, (32, 32), cov=0.3, device=dev)
+    mk = lambda: tg.QuadPole(max_steps=T)
+    for restart in (False, True):
+        full = tg.DeviceRollout(mk(), pol, G, Eps, restart, seed=9).run()
+        ref = [t.clone() for t in (full.obs, full.act, full.rew, full.mask, full.len)]
+        again = tg.DeviceRollout(mk(), pol, G, Eps, restart, seed=9).run()
+        for a, b in zip(ref, (again.obs, again.act, again.rew, again.mask, again.len)):
+            assert torch.equal(a, b)
+        # two "ranks", each owning half the groups, reproduce the single-GPU rollout exactly
+        n_half = G // 2 * Eps
+        for r in range(2):
+            part = tg.DeviceRollout(mk(), pol, G // 2, Eps, restart, seed=9, group_offset=r * G // 2).run()
+            sl = slice(r * n_half, (r + 1) * n_half)
+            assert torch.equal(part.obs[:, 0, :], ref[0][:, 0, sl])
+            assert torch.equal(part.act, ref[1][:, :, sl]) and torch.equal(part.len, ref[4][sl])
+            assert torch.equal(part.rew, ref[2][:, sl])
+        if restart:     # the E episodes of a group share the group's initial state
+            init = ref[0][:, 0, :].reshape(20, G, Eps)
+            assert torch.equal(init, init[:, :, :1].expand_as(init))
+            assert not torch.equal(init[:, 0, 0], init[:, 1, 0])
+    second = tg.DeviceRollout(mk(), pol, G, Eps, False, seed=10).run()
+    assert not torch.equal(second.act, ref[1])
+
+
+def test_graph_replay_matches_eager(tg, dev):
+    T, G, Eps = 16, 2, 128
+    torch.manual_seed(3)
+    pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, (64, 64), cov=0.3, device=dev)
+    eager = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps, seed=4)
+    graph = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps, seed=4, use_graph=True)
+    for it in range(3):             # replay 3 times: the RNG stream id lives in device memory
+        a, b = eager.run(), graph.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.len, b.len) and torch.equal(a.mask, b.mask)
+        assert torch.allclose(a.act, b.act, atol=1e-5) and torch.allclose(a.rew, b.rew, atol=1e-4)
+    assert a.env_steps() == b.env_steps() > 0
+
+
+# --------------------------------------------------------------------------------------------
+# returns / advantages
+# --------------------------------------------------------------------------------------------
+def _to_dev_tn(x, dev, dtype=torch.float32):
+    """(G,E,T) reference layout -> [T][n] device layout."""
+    G, Eps, T = x.shape
+    return torch.as_tensor(np.ascontiguousarray(x.reshape(G * Eps, T).T), dtype=dtype, device=dev)
+
+
+def _from_dev_tn(x, G, Eps):
+    return x.t().reshape(G, Eps, -1).cpu().numpy()
+
+
+@pytest.mark.parametrize("gamma", [0.5, 0.99, 0.999])
+def test_rtg_and_advantages_match_reference_golden(tg, dev, gamma):
+    K = tg.hip_ops
+    g = load_golden("rtg_adv.npz")
+    G, Eps, T = g["rew"].shape
+    rew, mask = _to_dev_tn(g["rew"], dev), _to_dev_tn(g["mask"], dev, torch.uint8)
+    tag = f"g{gamma}"
+    rtg = K.rtg_scan(rew, mask, gamma)
+    np.testing.assert_allclose(_from_dev_tn(rtg, G, Eps), g[f"{tag}_rtg"], rtol=0, atol=1e-5)   # north star: 1e-5
+    # GRPO group-relative advantage
+    adv = K.group_normalize(rtg, mask, K.masked_moments(rtg, mask, Eps), 0, Eps)
+    adv_ref = _from_dev_tn(adv, G, Eps)
+    m = g["mask"].astype(bool)
+    for i in range(G):
+        np.testing.assert_allclose(adv_ref[i][m[i]], g[f"{tag}_grpo_adv_{i}"], rtol=1e-5, atol=1e-5)
+    assert np.all(adv_ref[~m] == 0)
+    # PPO: A = R - V (MC) or GAE, then global normalisation of A and R
+    V = _to_dev_tn(g[f"{tag}_values"], dev)
+    for kind in ("mc", "gae"):
+        if kind == "mc":
+            a_full, r_full = rtg - V, rtg
+        else:
+            a_full, r_full = K.gae_scan(rew, V, mask, gamma, 0.95)
+        n = G * Eps
+        a_n = K.group_normalize(a_full, mask, K.masked_moments(a_full, mask, n), 1, n)
+        r_n = K.group_normalize(r_full, mask, K.masked_moments(r_full, mask, n), 1, n)
+        np.testing.assert_allclose(_from_dev_tn(a_n, G, Eps)[m], g[f"{tag}_ppo_{kind}_adv"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_from_dev_tn(r_n, G, Eps)[m], g[f"{tag}_ppo_{kind}_ret"], rtol=1e-5, atol=1e-5)
+
+
+def test_rtg_scan_is_bit_exact_vs_oracle_and_known_answer(tg, dev):
+    K = tg.hip_ops
+    rng = np.random.default_rng(7)
+    G, Eps, T = 5, 67, 300                        # n = 335 (ragged), T not a multiple of the 32-step chunk
+    lens = rng.integers(1, T + 1, size=(G, Eps))
+    mask = (np.arange(T)[None, None] < lens[..., None]).astype(np.float32)
+    rew = (rng.normal(size=(G, Eps, T)) * 3).astype(np.float32) * mask
+    for gamma in (0.5, 0.999, 1.0):
+        got = _from_dev_tn(K.rtg_scan(_to_dev_tn(rew, dev), _to_dev_tn(mask, dev, torch.uint8), gamma), G, Eps)
+        want = L.rtg_scan(torch.from_numpy(rew), torch.from_numpy(mask), gamma).numpy()
+        assert np.array_equal(got, want), f"reward-to-go not bit-exact at gamma={gamma}"
+    # reference tests/test_rollout_buffer.py:76-92 (gamma 0.99, no masks)
+    r = np.array([[[1, 2, 3], [0, 1, 2]], [[3, 2, 1], [1, 0, 1]]], dtype=np.float32)
+    got = _from_dev_tn(K.rtg_scan(_to_dev_tn(r, dev), _to_dev_tn(np.ones_like(r), dev, torch.uint8), 0.99), 2, 2)
+    exp = np.zeros_like(r)
+    for j in range(2, -1, -1):
+        exp[:, :, j] = r[:, :, j] + (0.99 * exp[:, :, j + 1] if j < 2 else 0)
+    np.testing.assert_allclose(got, exp, atol=1e-5)
+
+
+def test_returns_properties_at_scale(tg, dev):
+    """Size-independent properties at the bench size (65,536 envs x 256 steps)."""
+    K = tg.hip_ops
+    n, T, Eg = 65536, 256, 256
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lens = torch.randint(1, T + 1, (n,), device=dev, generator=gen)
+    mask = (torch.arange(T, device=dev)[:, None] < lens[None, :]).to(torch.uint8)
+    rew = torch.randn(T, n, device=dev, generator=gen) * mask
+    r1 = K.rtg_scan(rew, mask, 1.0)
+    # gamma = 1: R[0] is the episode return (sum of masked rewards)
+    assert torch.allclose(r1[0], rew.sum(0), rtol=1e-4, atol=1e-3)
+    # linearity in the rewards
+    r2 = K.rtg_scan(2 * rew, mask, 0.9)
+    assert torch.equal(r2, 2 * K.rtg_scan(rew, mask, 0.9))
+    # zero beyond the episode; group-normalised advantages have zero mean / unit (unbiased) std per group
+    assert torch.all(r1[mask == 0] == 0)
+    mom = K.masked_moments(r1, mask, Eg)
+    assert torch.equal(mom[:, 0].long().sum(), lens.sum())
+    adv = K.group_normalize(r1, mask, mom, 0, Eg)
+    a = adv.t().reshape(n // Eg, Eg * T)
+    mk = mask.t().reshape(n // Eg, Eg * T).bool()
+    for gi in (0, 17, 255):
+        v = a[gi][mk[gi]]
+        assert abs(float(v.mean())) < 1e-4 and abs(float(v.std()) - 1) < 1e-4
+
+
+# --------------------------------------------------------------------------------------------
+# policy log-prob and the fused loss head
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["actor", "actorcritic"])
+def test_gaussian_logp_matches_reference_golden(tg, dev, kind):
+    g = load_golden(f"policy_{kind}.npz")
+    mean = torch.as_tensor(g["mean"], device=dev)
+    act = torch.as_tensor(g["action"], device=dev)
+    lp = tg.hip_ops.gaussian_logp(mean, act, g["cov"])
+    np.testing.assert_allclose(lp.cpu().numpy(), g["logp_eval"], rtol=0, atol=5e-6)
+    lp_t = tg.hip_ops.gaussian_logp(mean, act.t().contiguous().t(), g["cov"])          # strided actions
+    assert torch.equal(lp, lp_t)
+    # the policy object: load the reference checkpoint layout and evaluate
+    cls = tg.GaussianActorCritic_NeuralNetwork if kind == "actorcritic" else tg.GaussianActor_NeuralNetwork
+    pol = cls(20, 4, (64, 64), cov=[float(c) for c in g["cov"]], device=dev)
+    sd = {k[len("policy."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("policy.")}
+    if kind == "actorcritic":
+        pol.load_state_dict({"actor": {k[6:]: v for k, v in sd.items() if k.startswith("actor.")},
+                             "critic": {k[7:]: v for k, v in sd.items() if k.startswith("critic.")}})
+    else:
+        pol.load_state_dict(sd)
+    lp2, ent = pol.log_prob(g["obs"], g["action"])
+    np.testing.assert_allclose(lp2.detach().cpu().numpy(), g["logp_eval"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), g["entropy"], rtol=0, atol=1e-6)
+    if kind == "actorcritic":
+        np.testing.assert_allclose(pol.value(g["obs"]).detach().cpu().numpy(), g["value_squeezed"], rtol=0, atol=2e-5)
+    a, lp3, v = pol(g["obs"][0])
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.shape == (4,)
+
+
+@pytest.mark.parametrize("A,ppo", [(1, False), (4, False), (2, True), (4, True)])
+def test_fused_loss_matches_torch_autograd(tg, dev, A, ppo):
+    """The fused HIP loss head against plain torch fp32 autograd of the same formulae
+    (oracle.learner.grpo_objective / ppo_loss restate algorithms/grpo.py:115-140, ppo.py:159-179)."""
+    K = tg.hip_ops
+    gen = torch.Generator(device=dev).manual_seed(11)
+    M = 10007
+    var = [0.3, 0.2, 0.5, 0.1][:A]
+    mean = torch.randn(M, A, device=dev, generator=gen, requires_grad=True)
+    act = (mean.detach() + 0.6 * torch.randn(M, A, device=dev, generator=gen))
+    vt = torch.tensor(var, device=dev)
+    c = -0.5 * A * np.log(2 * np.pi) - 0.5 * float(torch.log(vt).sum())
+    logp_old = (-0.5 * (((act - mean.detach()) ** 2) / vt).sum(1) + c) + 0.25 * torch.randn(M, device=dev, generator=gen)
+    adv = torch.randn(M, device=dev, generator=gen)
+    mask = (torch.rand(M, device=dev, generator=gen) < 0.8).to(torch.uint8)
+    eps = 0.2
+    value = torch.randn(M, device=dev, generator=gen, requires_grad=True) if ppo else None
+    ret = torch.randn(M, device=dev, generator=gen) if ppo else None
+    norm = torch.tensor([0.1, 1.7, -0.2, 0.6], device=dev) if ppo else None
+    nv = float(mask.sum())
+    coefs = (-1.0 / nv, 0.5 / nv, 0.5 / nv) if ppo else (1.0 / 3, 0.0, 0.0)
+    total, sums = K.SurrogateLoss.apply(mean, value, act, logp_old, adv, ret, mask, norm, var, eps, *coefs)
+    total.backward()
+    g_mean, g_val = mean.grad.clone(), (value.grad.clone() if ppo else None)
+    mean.grad = None
+    # torch reference
+    mb = mask.bool()
+    lp = -0.5 * (((act - mean) ** 2) / vt).sum(1) + c
+    a_n = (adv - norm[0]) * norm[1] if ppo else adv
+    ratio = torch.exp(lp - logp_old)
+    surr = torch.min(ratio * a_n, torch.clamp(ratio, 1 - eps, 1 + eps) * a_n)[mb].sum()
+    ref_total = coefs[0] * surr
+    if ppo:
+        value.grad = None
+        r_n = (ret - norm[2]) * norm[3]
+        sq = ((value - r_n) ** 2)[mb].sum()
+        kl = (torch.exp(logp_old) * (logp_old - lp))[mb].sum()
+        ref_total = ref_total + coefs[1] * sq + coefs[2] * kl
+        np.testing.assert_allclose(float(sums[1]), float(sq), rtol=1e-5)
+        np.testing.assert_allclose(float(sums[2]), float(kl), rtol=1e-4, atol=1e-4)
+    ref_total.backward()
+    np.testing.assert_allclose(float(sums[0]), float(surr), rtol=1e-5, atol=1e-3)
+    assert float(sums[3]) == nv
+    np.testing.assert_allclose(float(total), float(ref_total), rtol=1e-4, atol=1e-6)
+    scale = float(mean.grad.abs().max())
+    assert float((g_mean - mean.grad).abs().max()) <= 1e-5 * scale + 1e-9
+    assert torch.all(g_mean[~mb] == 0)
+    if ppo:
+        assert float((g_val - value.grad).abs().max()) <= 1e-5 * float(value.grad.abs().max()) + 1e-9
+
+
+# --------------------------------------------------------------------------------------------
+# learn(): optimizer steps against the reference
+# --------------------------------------------------------------------------------------------
+class _Buf:
+    device_traj = None
+
+
+def _buffer_from_golden(g):
+    b = _Buf()
+    b.group_observations, b.group_actions = torch.from_numpy(g["obs"]), torch.from_numpy(g["act"])
+    b.group_rewards, b.group_masks = torch.from_numpy(g["rew"]), torch.from_numpy(g["mask"])
+    return b
+
+
+@pytest.mark.parametrize("n_upd", [1, 2])
+def test_grpo_learn_matches_reference(tg, dev, n_upd):
+    g = load_golden(f"grpo_step_u{n_upd}.npz")
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (32, 32), cov=float(g["cov"]), device=dev)
+    pol.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")})
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    algo = tg.GRPO(epsilon=float(g["epsilon"]), beta=0.5, gamma=float(g["gamma"]), policy=pol, optimizer=opt,
+                   updates_per_iter=n_upd)
+    algo.old_policy.load_state_dict({k[9:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("old_init.")})
+    algo.learn(_buffer_from_golden(g))
+    np.testing.assert_allclose(algo.last_stats["J"], g["J"], rtol=2e-4, atol=5e-6)
+    for k, p in pol.actor.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"lastgrad.{k}"], rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final.{k}"], rtol=0, atol=2e-5)
+    # old_policy <- policy after learn (grpo.py:148)
+    for a, b in zip(algo.old_policy.parameters(), pol.parameters()):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_upd", [1, 2])
+def test_ppo_learn_matches_reference(tg, dev, n_upd):
+    g = load_golden(f"ppo_step_u{n_upd}.npz")
+    pol = tg.GaussianActorCritic_NeuralNetwork(10, 2, (32, 32), cov=float(g["cov"]), device=dev)
+    sd = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    pol.load_state_dict({"actor": {k[6:]: v for k, v in sd.items() if k.startswith("actor.")},
+                         "critic": {k[7:]: v for k, v in sd.items() if k.startswith("critic.")}})
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    algo = tg.PPO(epsilon=float(g["epsilon"]), policy=pol, optimizer=opt, ref_model=None, updates_per_iter=n_upd,
+                  c1=float(g["c1"]), kl_coeff=float(g["kl_coeff"]), gamma=float(g["gamma"]), lam=0.95,
+                  entropy=float(g["entropy_coeff"]), batch_size=None)
+    algo.learn(_buffer_from_golden(g))
+    st = algo.last_stats
+    np.testing.assert_allclose(st["total_loss"], g["total_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(st["actor_loss"], g["actor_loss"], rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(st["critic_loss"], g["critic_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(st["kl_div"], g["kl_div"], rtol=1e-3, atol=1e-7)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"lastgrad.{net}.{k}"], rtol=2e-3, atol=2e-6)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-5)
+
+
+def test_pipeline_trains_and_checkpoints(tg, dev, tmp_path, monkeypatch):
+    """C1 plumbing: CartPole GRPO, 4 envs (2x2), 128-step horizon through the Pipeline API; resume from the checkpoint."""
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+    mk = lambda: tg.CartPole(max_steps=128)
+    mgr = tg.RolloutManager(mk, pol, num_workers=2, num_episodes_per_worker=2, restart=True)
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4),
+                   updates_per_iter=1)
+    pipe = tg.create_cartpole_pipeline_grpo("t", "001", env_fn=mk, policy=pol, algorithm=algo, rollout_manager=mgr)
+    pipe.train(3)
+    assert len(pipe.buffer.avg_reward) == 3 and np.isfinite(pipe.buffer.avg_reward).all()
+    ck = tmp_path / "archive" / "CartPole" / "t" / "001"
+    for f in ("policy.pt", "optimizer.pth", "reward.csv", "metadata.json"):
+        assert (ck / f).exists()
+    obs = pipe.buffer.group_observations
+    assert obs.shape == (2, 2, 128, 5) and pipe.buffer.group_lengths.shape == (2, 2)
+    pipe.save_trajectory()
+    assert (ck / "trajectory.csv").exists()
+    pipe.save(pipe.archive_path)
+    pol2 = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+    mgr2 = tg.RolloutManager(mk, pol2, num_workers=2, num_episodes_per_worker=2)
+    algo2 = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol2, optimizer=torch.optim.Adam(pol2.parameters(), lr=3e-4),
+                    updates_per_iter=1)
+    pipe2 = tg.create_cartpole_pipeline_grpo("t", "002", env_fn=mk, policy=pol2, algorithm=algo2, rollout_manager=mgr2,
+                                             load_path=str(ck))
+    for a, b in zip(pol.parameters(), pol2.parameters()):
+        assert torch.equal(a, b)
+    assert len(pipe2.buffer.avg_reward) >= 1
+    pipe2.shutdown()

@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads and exports every symbol include/trajopt_grpo_hip.h declares;
+argument validation and host-side parameter logic work without a GPU (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import trajopt_grpo_amd as tg
+from oracle import envs as E
+
+N = tg._native
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.load()
+    header = open(os.path.join(REPO, "include", "trajopt_grpo_hip.h")).read()
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    assert lib.tg_abi_version() == 1
+
+
+def test_single_hip_runtime_is_shared_with_torch():
+    N.load()
+    libs = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    assert len(libs) == 1, libs           # one HIP runtime: torch's and the kernels' device pointers are the same world
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(N.EnvParams) == 4 * 4 + 8 + 12 * 8
+    assert C.sizeof(N.Traj) == 6 * 8 + 8 + 4 + 4
+    assert C.sizeof(N.LossArgs) == 8 * 11 + 8 * 4 + 4 * 5 + 4 + 8 * 5   # incl. 4 bytes of padding before d_grad_mean
+
+
+def test_env_dims_and_default_params_follow_the_reference():
+    assert N.env_dims(N.TG_ENV_CARTPOLE) == (5, 1)
+    assert N.env_dims(N.TG_ENV_QUADPOLE2D) == (10, 2)
+    assert N.env_dims(N.TG_ENV_QUADPOLE) == (20, 4)
+    p = N.default_params(N.TG_ENV_QUADPOLE, 256)
+    assert list(p.p)[:10] == [1.5, 0.5, 9.80665, 0.5, 0.4, 0.4, 0.25, 0.1, 0.5, 1.5] and p.timestep == 0.02
+    p = N.default_params(N.TG_ENV_QUADPOLE2D, 0)
+    assert p.max_steps == 500 and list(p.p)[:8] == [1.5, 0.5, 0.4, 0.5, 0.75, 9.80665, 2.0, 0.25]
+    for ms in (10, 64, 100, 128, 256, 500):
+        p = N.default_params(N.TG_ENV_CARTPOLE, ms)
+        assert p.time_trunc_step == E.cartpole_time_trunc_step(ms) >= ms     # float-accumulated time clause
+
+
+def test_errors_are_status_codes_with_messages():
+    lib = N.load()
+    assert lib.tg_env_dims(9, None, None) == -1 and b"bad env_id" in lib.tg_last_error()
+    p = N.default_params(N.TG_ENV_CARTPOLE, 10)
+    # null device pointer is refused on the host, before any launch
+    rc = lib.tg_env_step(C.byref(p), 0, None, 1, None, 1, None, 1, None, None, None, None, 1, None)
+    assert rc == -1 and b"null pointer" in lib.tg_last_error()
+    rc = lib.tg_rtg_scan(None, None, 0.5, None, 4, 4, None)
+    assert rc == -1
+    with pytest.raises(RuntimeError, match="failed"):
+        N.check(rc, "tg_rtg_scan")
+
+
+def test_env_objects_carry_the_reference_surface_without_a_gpu():
+    c = tg.CartPole()
+    assert (c.env_name, c.max_steps, c.timestep, c._is_3d) == ("CartPole", 500, 0.02, False)
+    assert c.observation_space.shape == (5,) and c.action_space.shape == (1,)
+    q = tg.QuadPole(max_steps=256)
+    assert q.observation_space.shape == (20,) and q.action_space.shape == (4,) and q._is_3d is True
+    assert q.hover_force == pytest.approx((1.5 + 0.5) * 9.80665 / 4)
+    q2 = tg.QuadPole2D()
+    assert q2.observation_space.shape == (10,) and q2.action_space.shape == (2,)
+    q.mass = 2.0                                   # attributes are live parameters, like the reference's
+    assert q.native_params().p[0] == 2.0
+    assert issubclass(tg.QuadrotorSwarm, tg.Quadrotor)
+    assert c.action_space.contains(c.action_space.sample())
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (8,), cov=0.5, device="cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+            tg.DeviceRollout(tg.CartPole(max_steps=8), pol, 1, 2, device="cpu")
+        with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+            tg.hip_ops.rtg_scan(torch.zeros(4, 4), torch.zeros(4, 4, dtype=torch.uint8), 0.9)
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(N.NativeLibraryError, match="is missing"):
+        N.load()
+
+
+def test_policy_surface_and_checkpoint_formats(tmp_path):
+    torch.manual_seed(0)
+    a = tg.GaussianActor_NeuralNetwork(5, 1, (16, 16), cov=0.5, device="cpu")
+    ac = tg.GaussianActorCritic_NeuralNetwork(20, 4, (16,), cov=[0.3, 0.2, 0.5, 0.1], device="cpu")
+    assert a.metadata()["num_parameters"] == 5 * 16 + 16 + 16 * 16 + 16 + 16 + 1
+    assert list(a.state_dict().keys())[0] == "network.0.weight"           # reference checkpoint key names
+    assert set(ac.state_dict().keys()) == {"actor", "critic"}
+    assert ac.cov.shape == (4, 4) and torch.equal(torch.diagonal(ac.cov), torch.tensor([0.3, 0.2, 0.5, 0.1]))
+    act, lp, v = ac(np.zeros(20))
+    assert act.dtype == np.float32 and act.shape == (4,) and lp.shape == () and v.shape == (1,)
+    act, lp, v = a(np.zeros((7, 5)))
+    assert act.shape == (7, 1) and lp.shape == (7,) and v is None
+    lp2, ent = ac.log_prob(np.zeros((3, 20)), np.zeros((3, 4), np.float32))
+    dist = torch.distributions.MultivariateNormal(ac.actor(torch.zeros(3, 20)), ac.cov)   # the reference's construction
+    assert torch.allclose(lp2, dist.log_prob(torch.zeros(3, 4)), atol=1e-5) and torch.allclose(ent, dist.entropy(), atol=1e-6)
+    a.save(str(tmp_path)); b = tg.GaussianActor_NeuralNetwork(5, 1, (16, 16), cov=0.5, device="cpu"); b.load(str(tmp_path))
+    assert all(torch.equal(x, y) for x, y in zip(a.parameters(), b.parameters()))
+    assert isinstance(torch.load(tmp_path / "policy.pt", weights_only=True), dict)
+    ac.save(str(tmp_path)); sd = torch.load(tmp_path / "policy.pt", weights_only=True)
+    assert set(sd) == {"actor", "critic"}
+    import copy
+    c = copy.deepcopy(ac)                                                 # grpo.py:48 / ppo.py:62 deep-copy the policy
+    assert all(torch.equal(x, y) for x, y in zip(c.parameters(), ac.parameters()))

@@ -1,0 +1,140 @@
+"""ctypes binding of libtrajopt_grpo_hip.so (the C ABI in include/trajopt_grpo_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, or an entry point is called
+without a GPU tensor, this module raises.  `import torch` happens first on purpose so the
+library resolves `libamdhip64.so.7` to the HIP runtime torch already loaded (one runtime
+per process: device pointers and streams are shared with PyTorch-ROCm).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
+
+TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12 = 0, 1, 2, 3
+TG_F32, TG_F64 = 0, 1
+ENV_IDS = {"CartPole": TG_ENV_CARTPOLE, "QuadPole2D": TG_ENV_QUADPOLE2D, "QuadPole": TG_ENV_QUADPOLE,
+           "Quadrotor": TG_ENV_QUADROTOR12}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class EnvParams(C.Structure):
+    _fields_ = [("env_id", C.c_int32), ("max_steps", C.c_int32), ("time_trunc_step", C.c_int32),
+                ("reserved", C.c_int32), ("timestep", C.c_double), ("p", C.c_double * 12)]
+
+
+class Traj(C.Structure):
+    _fields_ = [("d_obs", C.c_void_p), ("d_act", C.c_void_p), ("d_rew", C.c_void_p), ("d_mask", C.c_void_p),
+                ("d_len", C.c_void_p), ("d_counters", C.c_void_p), ("n", C.c_int64), ("horizon", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [("d_mean", C.c_void_p), ("mean_row_stride", C.c_int64),
+                ("d_act", C.c_void_p), ("act_row_stride", C.c_int64), ("act_col_stride", C.c_int64),
+                ("d_logp_old", C.c_void_p), ("d_adv", C.c_void_p), ("d_value", C.c_void_p), ("d_ret", C.c_void_p),
+                ("d_mask", C.c_void_p), ("d_norm", C.c_void_p),
+                ("var", C.c_float * 8), ("act_dim", C.c_int32), ("epsilon", C.c_float), ("surr_coef", C.c_float),
+                ("critic_coef", C.c_float), ("kl_coef", C.c_float),
+                ("d_grad_mean", C.c_void_p), ("d_grad_value", C.c_void_p), ("d_sums", C.c_void_p),
+                ("d_work", C.c_void_p), ("M", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/trajopt_grpo_hip.h declares
+_P, _I32, _I64, _U64, _F, _VP = C.POINTER, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+SIGNATURES = {
+    "tg_last_error": (C.c_char_p, []),
+    "tg_abi_version": (C.c_int, []),
+    "tg_env_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "tg_env_default_params": (C.c_int, [C.c_int, C.c_int, _P(EnvParams)]),
+    "tg_env_finalize_params": (C.c_int, [_P(EnvParams)]),
+    "tg_env_reset": (C.c_int, [_P(EnvParams), C.c_int, _VP, _I64, _I64, _U64, _U64, _I64, _I64, _VP]),
+    "tg_env_step": (C.c_int, [_P(EnvParams), C.c_int, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "tg_quadrotor12_dynamics": (C.c_int, [_P(EnvParams), C.c_int, _VP, _I64, _VP, _I64, _VP, _I64, _I64, _VP]),
+    "tg_rollout_begin": (C.c_int, [_P(Traj), C.c_int, C.c_int, _VP]),
+    "tg_rollout_step": (C.c_int, [_P(EnvParams), _P(Traj), _I32, _VP, _I64, _P(_F), _VP, _I64, _VP]),
+    "tg_rollout_finish": (C.c_int, [_P(Traj), _VP]),
+    "tg_rng_advance": (C.c_int, [_VP, _VP]),
+    "tg_rtg_scan": (C.c_int, [_VP, _VP, _F, _VP, _I64, _I32, _VP]),
+    "tg_gae_scan": (C.c_int, [_VP, _VP, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP]),
+    "tg_masked_moments": (C.c_int, [_VP, _VP, _I64, _I32, _I64, _VP, _VP, _VP]),
+    "tg_group_normalize": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _I64, _I32, _I64, _VP]),
+    "tg_gaussian_logp": (C.c_int, [_VP, _I64, _VP, _I64, _I64, _P(_F), C.c_int, _VP, _I64, _VP]),
+    "tg_loss_work_blocks": (C.c_int, []),
+    "tg_surrogate_loss": (C.c_int, [_P(LossArgs), _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises NativeLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the GPU rollout path.")
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.tg_abi_version() != 1:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.tg_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'trajopt_grpo_hip'} failed ({rc}): {msg}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeLibraryError("the HIP rollout path needs tensors on an MI355X (cuda) device; got a CPU tensor. "
+                                     "There is no CPU fallback.")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return TG_F32
+    if dt == torch.float64:
+        return TG_F64
+    raise ValueError(f"state dtype must be float32 or float64, got {dt}")
+
+
+def default_params(env_id, max_steps):
+    p = EnvParams()
+    check(load().tg_env_default_params(env_id, int(max_steps), C.byref(p)), "tg_env_default_params")
+    return p
+
+
+def env_dims(env_id):
+    s, a = C.c_int(), C.c_int()
+    check(load().tg_env_dims(env_id, C.byref(s), C.byref(a)), "tg_env_dims")
+    return s.value, a.value

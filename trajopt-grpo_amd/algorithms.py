@@ -1,0 +1,287 @@
+"""GRPO and PPO with the reference's constructor / `learn(buffer)` surface, running on the GPU.
+
+Mirrors algorithms/algorithm.py:3-35, algorithms/grpo.py:12-169 and algorithms/ppo.py:8-225.
+`learn` reproduces the reference arithmetic as written, including:
+  * reward-to-go with the next-step mask inside the recurrence (grpo.py:69-72);
+  * GRPO group statistics over ALL valid steps of a group's E episodes, unbiased std, the
+    epsilon inside std() (i.e. none) (grpo.py:115);
+  * GRPO performs gradient DESCENT on J (grpo.py:137-145) -- `maximize=True`
+    is the explicit, non-default divergence;
+  * PPO `old_log_probs` come from the CURRENT policy (ppo.py:142-143); the critic regresses on
+    batch-normalised returns while A = R_raw - V (ppo.py:111,139,169); the entropy of the
+    fixed-covariance Gaussian is a constant (zero gradient).
+What changes is where it runs: RTG / moments / normalisation / log-prob / the loss head are HIP
+kernels over the device trajectory; the MLP forward/backward are PyTorch-ROCm GEMMs; gradients
+of all ranks are summed with ONE flat all-reduce per optimizer step.
+"""
+from __future__ import annotations
+
+import copy
+import math
+import os
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import distributed as D
+from . import hip_ops as K
+from .rollout import DeviceTrajectory
+
+
+class Algorithm(ABC):
+    """algorithms/algorithm.py:3-35."""
+
+    def __init__(self):
+        pass
+
+    @abstractmethod
+    def learn(self, buffer):
+        pass
+
+    @abstractmethod
+    def metadata(self):
+        return {}
+
+    @abstractmethod
+    def save(self, path: str):
+        pass
+
+    @abstractmethod
+    def load(self, path: str):
+        pass
+
+
+def device_trajectory(buffer, device) -> DeviceTrajectory:
+    """The buffer's device trajectory; reference-layout CPU tensors (a legacy manager) are uploaded."""
+    traj = getattr(buffer, "device_traj", None)
+    if traj is not None:
+        return traj
+    obs, act = buffer.group_observations, buffer.group_actions
+    rew, mask = buffer.group_rewards, buffer.group_masks
+    G, E, T, S = obs.shape
+    A = act.shape[-1]
+    n = G * E
+    tr = DeviceTrajectory(S, A, T, n, G, E, torch.float32, device)
+    tr.obs[:, :T, :].copy_(obs.reshape(n, T, S).permute(2, 1, 0))
+    tr.act.copy_(act.reshape(n, T, A).permute(2, 1, 0))
+    tr.rew.copy_(rew.reshape(n, T).t())
+    tr.mask.copy_(mask.reshape(n, T).t().to(torch.uint8))
+    tr.len.copy_(mask.reshape(n, T).sum(1).to(torch.int32))
+    return tr
+
+
+class _GpuLearner(Algorithm):
+    chunk_rows = 1 << 20
+
+    def _setup(self, policy, optimizer, chunk_rows, autocast_dtype, process_group):
+        self.policy, self.optimizer = policy, optimizer
+        if chunk_rows is not None:
+            self.chunk_rows = int(chunk_rows)
+        self.autocast_dtype = autocast_dtype
+        self.process_group = process_group
+        self._bucket = None
+        self.last_stats = {}
+
+    @property
+    def bucket(self) -> D.GradBucket:
+        if self._bucket is None:
+            self._bucket = D.GradBucket(list(self.policy.parameters()))
+        return self._bucket
+
+    def _forward(self, net, x):
+        if self.autocast_dtype is not None:
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                y = net(x)
+            return y.float()
+        return net(x)
+
+    def _gather_valid(self, traj):
+        """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
+        idx = traj.mask.reshape(-1).nonzero().squeeze(1)
+        X = traj.obs_rows().index_select(0, idx)
+        if X.dtype != torch.float32:
+            X = X.float()
+        act = traj.act_rows().index_select(0, idx)
+        return idx, X.contiguous(), act.contiguous()
+
+    def _logp_nograd(self, actor, X, act, var):
+        out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+        with torch.no_grad():
+            for lo in range(0, X.shape[0], self.chunk_rows):
+                hi = min(lo + self.chunk_rows, X.shape[0])
+                mean = self._forward(actor, X[lo:hi]).contiguous()
+                out[lo:hi] = K.gaussian_logp(mean, act[lo:hi], var)
+        return out
+
+
+class GRPO(_GpuLearner):
+    """Group Relative Policy Optimization.  algorithms/grpo.py:12-169."""
+
+    def __init__(self, epsilon: float, beta: float, gamma: float, policy, optimizer, ref_model=None,
+                 updates_per_iter: int = 10, *, maximize: bool = False, chunk_rows=None, autocast_dtype=None,
+                 process_group=None):
+        self.epsilon, self.beta, self.gamma = epsilon, beta, gamma
+        self.ref_model = ref_model
+        self.updates_per_iter = updates_per_iter
+        self.maximize = maximize
+        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group)
+        self.old_policy = copy.deepcopy(self.policy)                        # grpo.py:48
+
+    def learn(self, buffer) -> None:
+        if self.ref_model is not None:
+            raise NotImplementedError("the reference's ref_model branch mis-unpacks a 3-tuple (grpo.py:129-132) "
+                                      "and never runs in shipped code; it is not reproduced")
+        traj = device_trajectory(buffer, self.policy.device)
+        var = self.policy.var
+        rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
+        rtg = K.rtg_scan(rew, traj.mask, self.gamma)                        # grpo.py:66-74
+        moments = K.masked_moments(rtg, traj.mask, traj.E)                  # per group, grpo.py:110-115
+        adv_full = K.group_normalize(rtg, traj.mask, moments, 0, traj.E)
+        idx, X, act = self._gather_valid(traj)
+        adv = adv_full.reshape(-1).index_select(0, idx)
+        _, world = D.rank_world(self.process_group)
+        G_global = traj.G * world
+        coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
+        old_logp = self._logp_nograd(self.old_policy.actor, X, act, var)    # grpo.py:118-119
+        Js = []
+        for _ in range(self.updates_per_iter):
+            self.bucket.zero_()
+            sums = torch.zeros(4, dtype=torch.float64, device=X.device)
+            for lo in range(0, X.shape[0], self.chunk_rows):
+                hi = min(lo + self.chunk_rows, X.shape[0])
+                mean = self._forward(self.policy.actor, X[lo:hi]).contiguous()
+                total, s = K.SurrogateLoss.apply(mean, None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None, None, None,
+                                                 var, self.epsilon, coef, 0.0, 0.0)
+                total.backward()
+                sums += s
+            self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
+            self.optimizer.step()
+            Js.append(sums)
+        self.old_policy.load_state_dict(self.policy.state_dict())           # grpo.py:148
+        if Js:
+            allJ = torch.stack(Js)
+            D.allreduce_sum_(allJ, self.process_group)
+            self.last_stats = {"J": (allJ[:, 0] / G_global).tolist(), "n_valid": allJ[0, 3].item()}
+
+    def save(self, path: str) -> None:
+        torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pth"))   # grpo.py:154
+
+    def load(self, path: str) -> None:
+        self.optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.pth"), weights_only=True))
+
+    def metadata(self):
+        return {"algorithm": "GRPO", "epsilon": self.epsilon, "beta": self.beta,
+                "updates_per_iter": self.updates_per_iter}
+
+
+class PPO(_GpuLearner):
+    """Proximal Policy Optimization.  algorithms/ppo.py:8-225."""
+
+    def __init__(self, epsilon: float, policy, optimizer, ref_model, updates_per_iter: int, c1: float = 0.5,
+                 kl_coeff: float = 0.5, gamma: float = 0.99, lam: float = 0.95, entropy: float = 0.01,
+                 batch_size: int = 64, monte_carlo: bool = True, *, chunk_rows=None, autocast_dtype=None,
+                 process_group=None, seed: int = 0):
+        self.epsilon, self.c1, self.ref_model = epsilon, c1, ref_model
+        self.updates_per_iter = updates_per_iter
+        self.gamma, self.lam, self.entropy = gamma, lam, entropy
+        self.batch_size, self.kl_coeff, self.monte_carlo = batch_size, kl_coeff, monte_carlo
+        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group)
+        self.old_policy = copy.deepcopy(self.policy)                        # ppo.py:62 (never read in learn)
+        self._seed = seed
+        self._gen = None
+
+    def _values_nograd(self, X):
+        out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+        with torch.no_grad():
+            for lo in range(0, X.shape[0], self.chunk_rows):
+                hi = min(lo + self.chunk_rows, X.shape[0])
+                out[lo:hi] = self._forward(self.policy.critic, X[lo:hi]).reshape(-1)
+        return out
+
+    def _step(self, X, act, adv, ret, old_logp, norm, var, n_global, sums_out):
+        """One optimizer step on the given rows (all local rows, or one minibatch)."""
+        self.bucket.zero_()
+        sums = torch.zeros(4, dtype=torch.float64, device=X.device)
+        for lo in range(0, X.shape[0], self.chunk_rows):
+            hi = min(lo + self.chunk_rows, X.shape[0])
+            mean = self._forward(self.policy.actor, X[lo:hi]).contiguous()
+            value = self._forward(self.policy.critic, X[lo:hi]).reshape(-1).contiguous()
+            total, s = K.SurrogateLoss.apply(mean, value, act[lo:hi], old_logp[lo:hi], adv[lo:hi], ret[lo:hi], None, norm,
+                                             var, self.epsilon, -1.0 / n_global, self.c1 / n_global,
+                                             self.kl_coeff / n_global)
+            total.backward()
+            sums += s
+        self.bucket.allreduce(self.process_group)                            # one RCCL all-reduce / step
+        self.optimizer.step()
+        sums_out.append(sums)
+
+    def learn(self, buffer) -> None:
+        traj = device_trajectory(buffer, self.policy.device)
+        var = self.policy.var
+        T, n = traj.T, traj.n
+        idx, X, act = self._gather_valid(traj)
+        rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
+        # V on valid rows only; padded rows never reach a result (they are masked in both scans)
+        v_valid = self._values_nograd(X)                                    # ppo.py:93
+        V = torch.zeros(T * n, dtype=torch.float32, device=X.device)
+        V.index_copy_(0, idx, v_valid)
+        V = V.view(T, n)
+        if self.monte_carlo:
+            rtg = K.rtg_scan(rew, traj.mask, self.gamma)                    # ppo.py:100-109
+            adv_full = rtg - V                                              # ppo.py:111
+        else:
+            adv_full, rtg = K.gae_scan(rew, V, traj.mask, self.gamma, self.lam)   # ppo.py:112-124
+        # global (all ranks) moments of the valid advantages and returns -> fused normalisation
+        m = torch.cat([K.masked_moments(adv_full, traj.mask, n), K.masked_moments(rtg, traj.mask, n)])   # [2][3]
+        D.allreduce_sum_(m, self.process_group)
+        cnt, s1, s2 = m[:, 0], m[:, 1], m[:, 2]
+        mean = s1 / cnt
+        std = torch.sqrt(torch.clamp((s2 - s1 * mean) / (cnt - 1.0), min=0.0)).float()     # unbiased, ppo.py:138-139
+        inv = 1.0 / (std + 1e-8)
+        norm = torch.stack([mean[0].float(), inv[0], mean[1].float(), inv[1]]).contiguous()
+        n_global = float(cnt[0].item())
+        adv = adv_full.reshape(-1).index_select(0, idx)
+        ret = rtg.reshape(-1).index_select(0, idx)
+        old_logp = self._logp_nograd(self.policy.actor, X, act, var)        # ppo.py:142-143 (current policy)
+        M = X.shape[0]
+        _, world = D.rank_world(self.process_group)
+        all_sums = []
+        for _ in range(self.updates_per_iter):
+            if self.batch_size is None:
+                # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
+                self._step(X, act, adv, ret, old_logp, norm, var, n_global, all_sums)
+            else:
+                if self._gen is None:
+                    self._gen = torch.Generator(device=X.device)
+                    self._gen.manual_seed(self._seed)
+                perm = torch.randperm(M, device=X.device, generator=self._gen)
+                local_bs = max(1, math.ceil(self.batch_size / world))
+                for lo in range(0, M, local_bs):
+                    b = perm[lo:lo + local_bs]
+                    nb = torch.tensor([float(b.numel())], dtype=torch.float64, device=X.device)
+                    D.allreduce_sum_(nb, self.process_group)
+                    self._step(X.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
+                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(nb.item()), all_sums)
+        self.old_policy.load_state_dict(self.policy.state_dict())           # ppo.py:186
+        if all_sums:
+            S = torch.stack(all_sums)
+            D.allreduce_sum_(S, self.process_group)
+            nn = S[:, 3]
+            ent = 0.5 * act.shape[1] * (1.0 + math.log(2 * math.pi)) + 0.5 * float(torch.log(var).sum())
+            actor = (-S[:, 0] / nn)
+            critic = (S[:, 1] / nn)
+            kl = (S[:, 2] / nn)
+            total = actor + self.c1 * critic - self.entropy * ent + self.kl_coeff * kl
+            self.last_stats = {"actor_loss": actor.tolist(), "critic_loss": critic.tolist(), "kl_div": kl.tolist(),
+                               "total_loss": total.tolist(), "entropy": ent, "n_valid": n_global}
+
+    def metadata(self) -> dict:
+        return {"algorithm": "PPO", "epsilon": self.epsilon, "c1": self.c1, "kl_coeff": self.kl_coeff,
+                "gamma": self.gamma, "lam": self.lam, "entropy": self.entropy, "batch_size": self.batch_size,
+                "updates_per_iter": self.updates_per_iter}
+
+    def save(self, path: str) -> None:
+        torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pt"))    # ppo.py:214
+
+    def load(self, path: str) -> None:
+        self.optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.pt"), weights_only=True))

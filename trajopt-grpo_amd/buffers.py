@@ -1,0 +1,110 @@
+"""Rollout_Buffer with the reference's surface, holding the trajectory on the device.
+
+Mirrors buffers/buffer.py and buffers/rollout_buffer.py:10-126.  `sample()` keeps the
+`DeviceTrajectory` the rollout produced; `group_observations / group_actions / group_rewards /
+group_lengths / group_masks` are the reference's CPU float32 `(G,E,T,.)` tensors, materialised
+lazily the first time a legacy consumer (Dashboard, Publisher, a reference learner) reads them.
+`avg_reward` is the same metric: mean over (G,E) of the undiscounted episode return (:70),
+reduced over ranks from (sum, count) under torch.distributed.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import distributed as D
+
+
+class Buffer:
+    """buffers/buffer.py."""
+
+    def __init__(self):
+        pass
+
+
+class Rollout_Buffer(Buffer):
+    _REF_FIELDS = ("group_observations", "group_actions", "group_rewards", "group_lengths", "group_masks")
+
+    def __init__(self, rollout_manager, rtg: bool = True):
+        self.rollout_manager = rollout_manager
+        self.env = rollout_manager.env_fn()
+        self.rtg = rtg                       # stored, never used -- as in the reference (:14,19)
+        self.device_traj = None              # DeviceTrajectory of the last sample()
+        self._ref = None                     # cached reference-layout CPU tensors
+        self.avg_reward = []
+        self.fig = None
+        self.axs = None
+
+    # ---- lazy reference-layout attributes ------------------------------------------
+    def _materialise(self):
+        if self._ref is None:
+            if self.device_traj is None:
+                return None
+            self._ref = dict(zip(self._REF_FIELDS, self.device_traj.to_reference()))
+        return self._ref
+
+    def __getattr__(self, name):
+        if name in Rollout_Buffer._REF_FIELDS:
+            ref = self._materialise()
+            return None if ref is None else ref[name]
+        raise AttributeError(name)
+
+    # ---- reference surface ---------------------------------------------------------------
+    def load(self, path: str):
+        self.avg_reward = np.atleast_1d(np.loadtxt(os.path.join(path, "reward.csv"), delimiter=",")).tolist()
+        return len(self.avg_reward)
+
+    def sample(self):
+        mgr = self.rollout_manager
+        if hasattr(mgr, "rollout_device"):
+            traj = mgr.rollout_device()
+            self.device_traj, self._ref = traj, None
+            total = traj.rew.sum(dtype=torch.float64).reshape(1)
+            stats = torch.cat([total, torch.tensor([float(traj.n)], dtype=torch.float64, device=total.device)])
+            D.allreduce_sum_(stats, getattr(mgr, "process_group", None))
+            s, c = stats.tolist()
+            self.avg_reward.append(np.asarray(s / c, dtype=np.float32))
+        else:
+            self.store(*mgr.rollout())
+
+    def store(self, group_observations, group_actions, group_rewards, group_lengths, group_masks):
+        """rollout_buffer.py:55-70 (CPU tensors from a legacy manager)."""
+        self.device_traj = None
+        self._ref = dict(zip(self._REF_FIELDS, (group_observations, group_actions, group_rewards, group_lengths,
+                                                group_masks)))
+        self.avg_reward.append(group_rewards.sum(2).mean().detach().numpy())
+
+    def retrieve(self):
+        """The reference reads attributes that are never set (:107-108); return the five stored tensors."""
+        r = self._materialise()
+        return tuple(r[k] for k in self._REF_FIELDS)
+
+    def save_trajectory(self, path: str):
+        """trajectory.csv: episode_id, observation_i..., action_j...  (rollout_buffer.py:72-102)."""
+        import pandas as pd
+        obs = self.group_observations.numpy()
+        act = self.group_actions.numpy()
+        lens = self.group_lengths.numpy().astype(int)
+        rows_o, rows_a, eid = [], [], []
+        for i in range(lens.shape[0]):
+            for j in range(lens.shape[1]):
+                L = lens[i, j]
+                rows_o.append(obs[i, j, :L])
+                rows_a.append(act[i, j, :L])
+                eid.extend([j + i * lens.shape[1]] * L)
+        header = ["episode_id"] + [f"observation_{i}" for i in range(obs.shape[3])] + \
+                 [f"action_{i}" for i in range(act.shape[3])]
+        data = np.hstack([np.array(eid).reshape(-1, 1), np.vstack(rows_o), np.vstack(rows_a)])
+        df = pd.DataFrame(data, columns=header)
+        df["episode_id"] = df["episode_id"].astype(int)
+        df.to_csv(os.path.join(path, "trajectory.csv"), index=False)
+
+    def metadata(self):
+        return {"avg_reward": float(self.avg_reward[-1]) if len(self.avg_reward) > 0 else None}
+
+    def save(self, path: str):
+        with open(os.path.join(path, "reward.csv"), "w") as f:
+            for reward in self.avg_reward:
+                f.write(f"{reward}\n")

@@ -1,0 +1,416 @@
+// Environment kernels for gfx950: reset, standalone step, and the fused GPU-resident
+// rollout step (sample action -> Env.step -> record -> terminate).  One lane per
+// environment, struct-of-arrays state so every load/store is a coalesced 256-B (f32)
+// or 512-B (f64) wavefront access.
+#include "env_dynamics.hpp"
+
+#include <math.h>
+#include <string.h>
+
+namespace tg {
+
+// ---------------------------------------------------------------------------
+// reset
+// ---------------------------------------------------------------------------
+template <typename Env, typename R>
+__global__ __launch_bounds__(256) void reset_kernel(R* __restrict__ state, int64_t ld, int64_t n, uint64_t seed,
+                                                    uint32_t stream_id, int64_t key_offset, int64_t key_div) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rnd[4];
+    Philox::draw(seed, (uint64_t)((key_offset + i) / key_div), 0xFFFFFFFFu /* sub = reset */, stream_id, rnd);
+    R o[Env::S];
+    Env::reset(rnd, o);
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k) state[k * ld + i] = o[k];
+}
+
+// ---------------------------------------------------------------------------
+// standalone Env.step on SoA state
+// ---------------------------------------------------------------------------
+template <typename Env, typename R>
+__global__ __launch_bounds__(256) void step_kernel(typename Env::C c, const R* __restrict__ state, int64_t ld,
+                                                   const float* __restrict__ action, int64_t ld_a,
+                                                   R* __restrict__ next, int64_t ld_next, int32_t* __restrict__ steps,
+                                                   R* __restrict__ time_balanced, R* __restrict__ reward,
+                                                   uint8_t* __restrict__ truncated, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    R s[Env::S], o[Env::S];
+    float a[Env::A];
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k) s[k] = state[k * ld + i];
+#pragma unroll
+    for (int k = 0; k < Env::A; ++k) a[k] = action[k * ld_a + i];
+    const int steps_after = steps[i] + 1;
+    R r;
+    const StepOut out = Env::step(s, a, c, steps_after, o, r);
+#pragma unroll
+    for (int k = 0; k < Env::S; ++k) next[k * ld_next + i] = o[k];
+    steps[i] = steps_after;
+    reward[i] = r;
+    truncated[i] = out.truncated ? 1 : 0;
+    if (time_balanced != nullptr) time_balanced[i] = out.balanced ? time_balanced[i] + c.dt : (R)0;
+}
+
+// ---------------------------------------------------------------------------
+// fused rollout step
+// ---------------------------------------------------------------------------
+struct Sigma { float v[8]; };
+
+template <typename Env, typename R, bool kSample>
+__global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R* __restrict__ obs,
+                                                           float* __restrict__ act, R* __restrict__ rew,
+                                                           uint8_t* __restrict__ mask, int32_t* __restrict__ len,
+                                                           int64_t n, int32_t T, int32_t t,
+                                                           const float* __restrict__ mean, int64_t mean_rs, Sigma sigma,
+                                                           const uint64_t* __restrict__ rng, int64_t env_offset) {
+    constexpr int S = Env::S, A = Env::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = (i < n) && (len[i] == 0);
+    // wavefront-wide termination: if all 64 envs of this wave have ended, leave before
+    // touching the trajectory (wave-uniform branch, no divergence)
+    if (__ballot(alive) == 0ull) return;
+    if (!alive) return;
+
+    const int64_t T1 = (int64_t)T + 1;
+    R s[S], o[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = obs[(k * T1 + t) * n + i];
+    float a[A];
+    if constexpr (kSample) {
+        // a = mean + sigma * eps, eps ~ N(0, I): Box-Muller on Philox words keyed by the
+        // GLOBAL env index and t (independent of sharding / launch geometry)
+        uint32_t rnd[4];
+        Philox::draw(rng[0], (uint64_t)(env_offset + i), (uint32_t)t, (uint32_t)rng[1], rnd);
+        float eps[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (2 * h < A) {
+                const float rad = sqrtf(-2.0f * logf(Philox::u01(rnd[2 * h])));
+                float sn, cs;
+                sincospif(2.0f * Philox::u01(rnd[2 * h + 1]), &sn, &cs);
+                eps[2 * h] = rad * cs;
+                eps[2 * h + 1] = rad * sn;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            a[k] = __fadd_rn(mean[i * mean_rs + k], __fmul_rn(sigma.v[k], eps[k]));
+            act[((int64_t)k * T + t) * n + i] = a[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < A; ++k) a[k] = act[((int64_t)k * T + t) * n + i];
+    }
+
+    R r;
+    const StepOut out = Env::step(s, a, c, t + 1, o, r);
+    rew[(int64_t)t * n + i] = r;
+    mask[(int64_t)t * n + i] = 1;
+    // the worker also stops at t == max_steps (rollout_worker.py:51)
+    if (out.truncated || (t + 1 >= T)) {
+        len[i] = t + 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = o[k];
+    }
+}
+
+// sum of episode lengths (= env-steps executed = sum of mask) and #episodes ended
+__global__ __launch_bounds__(256) void rollout_finish_kernel(const int32_t* __restrict__ len, int64_t n,
+                                                             uint64_t* __restrict__ counters) {
+    __shared__ unsigned long long s_sum[4], s_done[4];
+    unsigned long long sum = 0, done = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t l = len[i];
+        sum += (unsigned long long)l;
+        done += (l > 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off, 64);
+        done += __shfl_down(done, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_done[w] = done; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[0] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        counters[1] = s_done[0] + s_done[1] + s_done[2] + s_done[3];
+    }
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
+
+// Quadrotor._dynamics (12-state, explicit Euler).  quadrotor_env.py:128-169
+template <typename R>
+__global__ __launch_bounds__(256) void quadrotor12_kernel(const R* __restrict__ st, int64_t ld,
+                                                          const R* __restrict__ ctl, int64_t ld_c, R* __restrict__ nx,
+                                                          int64_t ld_n, int64_t n, R mass, R arm, R Ixx, R Iyy, R Izz,
+                                                          R tc, R g, R dt) {
+    using M = Math<R>;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    R s[12], u[4];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = st[k * ld + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = ctl[k * ld_c + i];
+    const R phi = s[6], th = s[7], p = s[9], q = s[10], r = s[11];
+    R sphi, cphi, sth, cth;
+    M::sincos_(phi, &sphi, &cphi);
+    M::sincos_(th, &sth, &cth);
+    const R tth = M::tan_(th);
+    const R ut = ((u[0] + u[1]) + u[2]) + u[3];
+    const R im = (R)1 / mass;
+    R rate[12];
+    rate[0] = s[3]; rate[1] = s[4]; rate[2] = s[5];
+    rate[3] = im * ((-sth) * ut);                       // third column of R (the [2][1] typo at :144 is unused)
+    rate[4] = im * ((sphi * cth) * ut);
+    rate[5] = im * ((cphi * cth) * ut + (-mass * g));
+    rate[6] = (p + sphi * tth * q) + cphi * tth * r;
+    rate[7] = cphi * q + (-sphi) * r;
+    rate[8] = sphi / cth * q + cphi / cth * r;
+    const R s22 = (R)(1.4142135623730951 / 2.0);
+    rate[9] = (s22 * (u[0] + u[2] - u[1] - u[3]) * arm - (Izz - Iyy) * q * r) / Ixx;
+    rate[10] = (s22 * (u[2] + u[3] - u[0] - u[1]) * arm - (Izz - Ixx) * p * r) / Iyy;
+    rate[11] = (tc * (u[0] + u[3] - u[1] - u[2])) / Izz;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) nx[k * ld_n + i] = s[k] + rate[k] * dt;
+}
+
+// ---------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------
+static inline dim3 env_grid(int64_t n, int& block) {
+    // small launches are latency-bound: one wave per workgroup spreads them over all CUs
+    block = (n <= (int64_t)1 << 18) ? 64 : 256;
+    return dim3((unsigned)ceil_div(n, block));
+}
+
+template <template <typename> class EnvT, typename R>
+static int reset_dispatch(const tg_env_params* p, void* state, int64_t ld, int64_t n, uint64_t seed, uint64_t stream_id,
+                          int64_t key_offset, int64_t key_div, hipStream_t st) {
+    int block;
+    dim3 grid = env_grid(n, block);
+    hipLaunchKernelGGL((reset_kernel<EnvT<R>, R>), grid, dim3(block), 0, st, (R*)state, ld, n, seed, (uint32_t)stream_id,
+                       key_offset, key_div);
+    TG_LAUNCH_CHECK("tg_env_reset");
+    return TG_OK;
+}
+
+template <template <typename> class EnvT, typename R>
+static int step_dispatch(const tg_env_params* p, const void* state, int64_t ld, const float* action, int64_t ld_a,
+                         void* next, int64_t ld_next, int32_t* steps, void* tb, void* reward, uint8_t* trunc, int64_t n,
+                         hipStream_t st) {
+    int block;
+    dim3 grid = env_grid(n, block);
+    auto c = EnvT<R>::C::make(*p);
+    hipLaunchKernelGGL((step_kernel<EnvT<R>, R>), grid, dim3(block), 0, st, c, (const R*)state, ld, action, ld_a, (R*)next,
+                       ld_next, steps, (R*)tb, (R*)reward, trunc, n);
+    TG_LAUNCH_CHECK("tg_env_step");
+    return TG_OK;
+}
+
+template <template <typename> class EnvT, typename R>
+static int rollout_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t, const float* mean, int64_t mean_rs,
+                            const float* sigma, const uint64_t* rng, int64_t env_offset, hipStream_t st) {
+    int block;
+    dim3 grid = env_grid(tr->n, block);
+    auto c = EnvT<R>::C::make(*p);
+    Sigma sg;
+    memset(&sg, 0, sizeof(sg));
+    if (mean != nullptr) {
+        for (int k = 0; k < EnvT<R>::A; ++k) sg.v[k] = sigma[k];
+        hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, true>), grid, dim3(block), 0, st, c, (R*)tr->d_obs, tr->d_act,
+                           (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, env_offset);
+    } else {
+        hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, false>), grid, dim3(block), 0, st, c, (R*)tr->d_obs, tr->d_act,
+                           (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, env_offset);
+    }
+    TG_LAUNCH_CHECK("tg_rollout_step");
+    return TG_OK;
+}
+
+#define TG_ENV_SWITCH(env_id, dtype, CALL)                                                     \
+    switch ((env_id) * 2 + (dtype)) {                                                          \
+        case TG_ENV_CARTPOLE * 2 + TG_F32: return CALL(CartPoleEnv, float);                    \
+        case TG_ENV_CARTPOLE * 2 + TG_F64: return CALL(CartPoleEnv, double);                   \
+        case TG_ENV_QUADPOLE2D * 2 + TG_F32: return CALL(QuadPole2DEnv, float);                \
+        case TG_ENV_QUADPOLE2D * 2 + TG_F64: return CALL(QuadPole2DEnv, double);               \
+        case TG_ENV_QUADPOLE * 2 + TG_F32: return CALL(QuadPoleEnv, float);                    \
+        case TG_ENV_QUADPOLE * 2 + TG_F64: return CALL(QuadPoleEnv, double);                   \
+        default: return set_error(TG_ERR_UNSUPPORTED, "unsupported env_id %d / dtype %d", (int)(env_id), (int)(dtype)); \
+    }
+
+static int cartpole_time_trunc_step(int max_steps, double timestep) {
+    // cartpole_env.py:27,151,168: `_time += timestep` accumulated in fp64 vs max_steps*timestep
+    const double max_time = max_steps * timestep;
+    double t = 0;
+    int k = 0;
+    for (;;) {
+        ++k;
+        t += timestep;
+        if (t > max_time) return k;
+        if (k > max_steps + 8) return k;  // unreachable for sane inputs; bounds the loop
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_env_dims(int env_id, int* obs_dim, int* act_dim) {
+    static const int dims[4][2] = {{5, 1}, {10, 2}, {20, 4}, {12, 4}};
+    TG_REQUIRE(env_id >= 0 && env_id < 4, "tg_env_dims: bad env_id %d", env_id);
+    if (obs_dim) *obs_dim = dims[env_id][0];
+    if (act_dim) *act_dim = dims[env_id][1];
+    return TG_OK;
+}
+
+int tg_env_finalize_params(tg_env_params* p) {
+    TG_REQUIRE(p != nullptr, "tg_env_finalize_params: null params");
+    TG_REQUIRE(p->max_steps > 0 && p->timestep > 0, "tg_env_finalize_params: max_steps/timestep must be positive");
+    p->time_trunc_step = (p->env_id == TG_ENV_CARTPOLE) ? cartpole_time_trunc_step(p->max_steps, p->timestep) : p->max_steps;
+    return TG_OK;
+}
+
+int tg_env_default_params(int env_id, int max_steps, tg_env_params* out) {
+    TG_REQUIRE(out != nullptr, "tg_env_default_params: null out");
+    memset(out, 0, sizeof(*out));
+    out->env_id = env_id;
+    out->max_steps = max_steps > 0 ? max_steps : 500;
+    out->timestep = 0.02;
+    switch (env_id) {
+        case TG_ENV_CARTPOLE: {  // cartpole_env.py:7-16
+            const double d[] = {1.0, 1.0, 0.5, 9.80665};
+            memcpy(out->p, d, sizeof(d));
+            break;
+        }
+        case TG_ENV_QUADPOLE2D: {  // quadrotor_env.py:875-895
+            const double d[] = {1.5, 0.5, 4e-1, 0.5, 0.75, 9.80665, 2.0, 0.25};
+            memcpy(out->p, d, sizeof(d));
+            break;
+        }
+        case TG_ENV_QUADPOLE: {  // quadrotor_env.py:362-382
+            const double d[] = {1.5, 0.5, 9.80665, 0.5, 4e-1, 4e-1, 2.5e-1, 0.1, 0.5, 1.5};
+            memcpy(out->p, d, sizeof(d));
+            break;
+        }
+        case TG_ENV_QUADROTOR12: {  // quadrotor_env.py:9-16
+            const double d[] = {1.0, 0.2, 0.005, 0.005, 0.006, 0.017, 9.80665};
+            memcpy(out->p, d, sizeof(d));
+            out->timestep = 0.05;
+            out->max_steps = max_steps > 0 ? max_steps : 200;
+            break;
+        }
+        default:
+            return set_error(TG_ERR_ARG, "tg_env_default_params: bad env_id %d", env_id);
+    }
+    return tg_env_finalize_params(out);
+}
+
+int tg_env_reset(const tg_env_params* p, int dtype, void* d_state, int64_t ld, int64_t n, uint64_t seed,
+                 uint64_t stream_id, int64_t key_offset, int64_t key_div, void* stream) {
+    TG_REQUIRE(p && d_state, "tg_env_reset: null pointer");
+    TG_REQUIRE(n >= 0 && ld >= n && key_div >= 1 && key_offset >= 0, "tg_env_reset: bad sizes n=%lld ld=%lld key_div=%lld",
+               (long long)n, (long long)ld, (long long)key_div);
+    if (n == 0) return TG_OK;
+#define CALL(E, R) reset_dispatch<E, R>(p, d_state, ld, n, seed, stream_id, key_offset, key_div, (hipStream_t)stream)
+    TG_ENV_SWITCH(p->env_id, dtype, CALL)
+#undef CALL
+}
+
+int tg_env_step(const tg_env_params* p, int dtype, const void* d_state, int64_t ld, const float* d_action, int64_t ld_a,
+                void* d_next, int64_t ld_next, int32_t* d_steps, void* d_time_balanced, void* d_reward,
+                uint8_t* d_truncated, int64_t n, void* stream) {
+    TG_REQUIRE(p && d_state && d_action && d_next && d_steps && d_reward && d_truncated, "tg_env_step: null pointer");
+    TG_REQUIRE(n >= 0 && ld >= n && ld_a >= n && ld_next >= n, "tg_env_step: leading dimensions smaller than n=%lld",
+               (long long)n);
+    if (n == 0) return TG_OK;
+#define CALL(E, R) \
+    step_dispatch<E, R>(p, d_state, ld, d_action, ld_a, d_next, ld_next, d_steps, d_time_balanced, d_reward, d_truncated, n, (hipStream_t)stream)
+    TG_ENV_SWITCH(p->env_id, dtype, CALL)
+#undef CALL
+}
+
+int tg_quadrotor12_dynamics(const tg_env_params* p, int dtype, const void* d_state, int64_t ld, const void* d_control,
+                            int64_t ld_c, void* d_next, int64_t ld_next, int64_t n, void* stream) {
+    TG_REQUIRE(p && d_state && d_control && d_next, "tg_quadrotor12_dynamics: null pointer");
+    TG_REQUIRE(p->env_id == TG_ENV_QUADROTOR12, "tg_quadrotor12_dynamics: params are for env %d", p->env_id);
+    TG_REQUIRE(n >= 0 && ld >= n && ld_c >= n && ld_next >= n, "tg_quadrotor12_dynamics: bad leading dimensions");
+    if (n == 0) return TG_OK;
+    const dim3 grid((unsigned)ceil_div(n, 256));
+    const double* q = p->p;
+    if (dtype == TG_F32) {
+        hipLaunchKernelGGL(quadrotor12_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_state, ld,
+                           (const float*)d_control, ld_c, (float*)d_next, ld_next, n, (float)q[0], (float)q[1], (float)q[2],
+                           (float)q[3], (float)q[4], (float)q[5], (float)q[6], (float)p->timestep);
+    } else if (dtype == TG_F64) {
+        hipLaunchKernelGGL(quadrotor12_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)d_state, ld,
+                           (const double*)d_control, ld_c, (double*)d_next, ld_next, n, q[0], q[1], q[2], q[3], q[4], q[5],
+                           q[6], p->timestep);
+    } else {
+        return set_error(TG_ERR_UNSUPPORTED, "tg_quadrotor12_dynamics: dtype %d", dtype);
+    }
+    TG_LAUNCH_CHECK("tg_quadrotor12_dynamics");
+    return TG_OK;
+}
+
+int tg_rollout_begin(const tg_traj* tr, int obs_dim, int act_dim, void* stream) {
+    TG_REQUIRE(tr && tr->d_obs && tr->d_act && tr->d_rew && tr->d_mask && tr->d_len && tr->d_counters,
+               "tg_rollout_begin: null trajectory pointer");
+    TG_REQUIRE(tr->n > 0 && tr->horizon > 0 && obs_dim > 0 && act_dim > 0, "tg_rollout_begin: bad sizes");
+    TG_REQUIRE(tr->dtype == TG_F32 || tr->dtype == TG_F64, "tg_rollout_begin: bad dtype %d", tr->dtype);
+    const size_t rs = tr->dtype == TG_F64 ? 8 : 4;
+    const size_t n = (size_t)tr->n, T = (size_t)tr->horizon;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    // slot 0 of obs holds the initial states (written by tg_env_reset before or after this call):
+    // clear slots 1..T of every component with one strided 2-D memset
+    e = hipMemset2DAsync((char*)tr->d_obs + n * rs, (T + 1) * n * rs, 0, T * n * rs, (size_t)obs_dim, st);
+    if (e == hipSuccess) e = hipMemsetAsync(tr->d_act, 0, (size_t)act_dim * T * n * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(tr->d_rew, 0, T * n * rs, st);
+    if (e == hipSuccess) e = hipMemsetAsync(tr->d_mask, 0, T * n, st);
+    if (e == hipSuccess) e = hipMemsetAsync(tr->d_len, 0, n * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(tr->d_counters, 0, 4 * sizeof(uint64_t), st);
+    if (e != hipSuccess) return set_error(TG_ERR_HIP, "tg_rollout_begin: %s", hipGetErrorString(e));
+    return TG_OK;
+}
+
+int tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const float* d_mean, int64_t mean_row_stride,
+                    const float* sigma, const uint64_t* d_rng, int64_t env_offset, void* stream) {
+    TG_REQUIRE(p && tr && tr->d_obs && tr->d_act && tr->d_rew && tr->d_mask && tr->d_len, "tg_rollout_step: null pointer");
+    TG_REQUIRE(tr->n > 0 && tr->horizon > 0 && t >= 0 && t < tr->horizon, "tg_rollout_step: t=%d outside horizon %d", t,
+               tr->horizon);
+    TG_REQUIRE(tr->horizon == p->max_steps, "tg_rollout_step: trajectory horizon %d != env.max_steps %d", tr->horizon,
+               p->max_steps);
+    if (d_mean != nullptr) {
+        int S, A;
+        tg_env_dims(p->env_id, &S, &A);
+        TG_REQUIRE(sigma != nullptr && d_rng != nullptr, "tg_rollout_step: sampling needs sigma and d_rng");
+        TG_REQUIRE(mean_row_stride >= A, "tg_rollout_step: mean_row_stride %lld < act_dim %d", (long long)mean_row_stride, A);
+    }
+#define CALL(E, R) rollout_dispatch<E, R>(p, tr, t, d_mean, mean_row_stride, sigma, d_rng, env_offset, (hipStream_t)stream)
+    TG_ENV_SWITCH(p->env_id, tr->dtype, CALL)
+#undef CALL
+}
+
+int tg_rollout_finish(const tg_traj* tr, void* stream) {
+    TG_REQUIRE(tr && tr->d_len && tr->d_counters && tr->n > 0, "tg_rollout_finish: bad trajectory");
+    hipLaunchKernelGGL(rollout_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tr->d_len, tr->n, tr->d_counters);
+    TG_LAUNCH_CHECK("tg_rollout_finish");
+    return TG_OK;
+}
+
+int tg_rng_advance(uint64_t* d_rng, void* stream) {
+    TG_REQUIRE(d_rng != nullptr, "tg_rng_advance: null pointer");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_rng);
+    TG_LAUNCH_CHECK("tg_rng_advance");
+    return TG_OK;
+}
+
+}  // extern "C"

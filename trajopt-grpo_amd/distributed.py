@@ -1,0 +1,73 @@
+"""One process per GPU: shard whole groups across ranks, one flattened gradient all-reduce per
+optimizer step (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
+
+The reference has no distributed code; its only parallelism is the rollout
+process pool (rollout/rollout_manager.py:44-56).  Envs are independent, so the rollout needs
+no collective; the learner needs (a) the summed gradient, (b) PPO's global advantage / return
+moments (algorithms/ppo.py:138-139) and (c) the avg_reward metric (buffers/rollout_buffer.py:70).
+All three are reductions of SUMS, never of local means, so results do not depend on the number
+of ranks beyond floating-point summation order.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_groups(num_groups: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous whole-group range [lo, hi) owned by `rank` (GRPO statistics stay rank-local)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    if num_groups % world != 0:
+        raise ValueError(f"num_workers={num_groups} must be divisible by the number of ranks ({world})")
+    per = num_groups // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    _, world = rank_world(group)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class GradBucket:
+    """All parameter gradients as views into ONE flat buffer, so an optimizer step costs exactly one
+    all-reduce (0.2-2.2 MB for the reference's policies: latency-bound, so one bucket, not many)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+        # optimizers may have replaced .grad (set_to_none); re-attach the views
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def allreduce(self, group=None):
+        allreduce_sum_(self.flat, group)
+
+
+def unbiased_moments(count: float, s1: float, s2: float) -> Tuple[float, float]:
+    """(mean, unbiased std) from (count, sum, sum of squares) -- torch.std's default correction."""
+    mean = s1 / count
+    var = (s2 - s1 * mean) / (count - 1.0) if count > 1 else float("nan")
+    return mean, (max(var, 0.0) ** 0.5 if var == var else var)

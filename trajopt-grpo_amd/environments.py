@@ -1,0 +1,278 @@
+"""Environments with the reference's `Env` surface, stepped by HIP kernels.
+
+Mirrors environments/env.py:10-68, environments/cartpole_env.py:6-182 and
+environments/quadrotor_env.py:353-713, :867-1223 of the reference: same constructor
+arguments, attributes (`max_steps`, `observation_space`, `action_space`, `env_name`,
+`timestep`, `_is_3d`, `state_dict`, `_initial_state`) and `reset/restart/step` return
+shapes.  A single instance is a drop-in for the reference's scalar env (every call is one
+kernel launch on one env: correct, not fast); the throughput path is
+`rollout.DeviceRollout`, which steps `num_envs x horizon` from the same parameters.
+`render` is out of scope (matplotlib) and raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class Box:
+    """The slice of gymnasium.spaces.Box the reference touches (env.py, rollout_worker.py:34-35)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.shape = tuple(shape) if shape is not None else tuple(np.shape(low))
+        self.dtype = np.dtype(dtype)
+        self.low = np.broadcast_to(np.asarray(low, dtype=np.float64), self.shape)
+        self.high = np.broadcast_to(np.asarray(high, dtype=np.float64), self.shape)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"Box(shape={self.shape}, dtype={self.dtype})"
+
+
+class Env:
+    """Base class (environments/env.py:10-68): reset / restart / step / render."""
+
+    ENV_ID = None
+    _state_split = None    # ((key, size), ...) of state_dict, as the reference stores it
+
+    def __init__(self, env_name: str, device=None, dtype=torch.float64):
+        self.env_name = env_name
+        self._device = torch.device(device) if device is not None else torch.device("cuda", 0)
+        self._dtype = dtype
+        self._state = None           # device [S][1]
+        self._initial = None
+        self._steps_t = None
+        self._tb_t = None
+        self._seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self._reset_count = 0
+        self._time_balanced = 0
+        self._steps = 0
+        self._time = 0
+        self._initial_state = None
+
+    # -- parameters -------------------------------------------------------
+    def native_params(self) -> N.EnvParams:
+        """tg_env_params built from the instance attributes (users may edit them, like the reference's)."""
+        p = N.default_params(self.ENV_ID, self.max_steps)
+        p.timestep = float(self.timestep)
+        self._fill_params(p)
+        N.check(N.load().tg_env_finalize_params(C.byref(p)), "tg_env_finalize_params")
+        return p
+
+    def _fill_params(self, p):
+        raise NotImplementedError
+
+    @property
+    def obs_dim(self):
+        return self.observation_space.shape[0]
+
+    @property
+    def act_dim(self):
+        return self.action_space.shape[0]
+
+    # -- scalar drop-in API ----------------------------------------------
+    def _alloc(self):
+        if self._state is None:
+            S = self.obs_dim
+            self._state = torch.zeros(S, 1, dtype=self._dtype, device=self._device)
+            self._steps_t = torch.zeros(1, dtype=torch.int32, device=self._device)
+            self._tb_t = torch.zeros(1, dtype=self._dtype, device=self._device)
+            self._rew_t = torch.zeros(1, dtype=self._dtype, device=self._device)
+            self._trunc_t = torch.zeros(1, dtype=torch.uint8, device=self._device)
+            self._act_t = torch.zeros(self.act_dim, 1, dtype=torch.float32, device=self._device)
+
+    def _obs_np(self):
+        return self._state[:, 0].double().cpu().numpy()
+
+    def _sync_state_dict(self):
+        o = self._obs_np()
+        off = 0
+        for key, size in self._state_split:
+            self.state_dict[key] = o[off:off + size].copy()
+            off += size
+
+    def _get_info(self):
+        return {"time_balanced": self._time_balanced}
+
+    def reset(self):
+        self._alloc()
+        p = self.native_params()
+        self._reset_count += 1
+        N.check(N.load().tg_env_reset(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1, 1,
+                                      self._seed, self._reset_count, 0, 1, N.stream_ptr(self._device)), "tg_env_reset")
+        self._initial = self._state.clone()
+        self._steps_t.zero_()
+        self._tb_t.zero_()
+        self._steps, self._time, self._time_balanced = 0, 0, 0
+        self._sync_state_dict()
+        self._initial_state = {k: v.copy() for k, v in self.state_dict.items()}
+        return self._obs_np(), self._get_info()
+
+    def set_state(self, state):
+        """Place the env in `state` (S,) and make it the restart point (used by parity tests)."""
+        self._alloc()
+        self._state.copy_(torch.as_tensor(np.asarray(state), dtype=self._dtype).reshape(-1, 1))
+        self._initial = self._state.clone()
+        self._steps_t.zero_()
+        self._tb_t.zero_()
+        self._steps, self._time, self._time_balanced = 0, 0, 0
+        self._sync_state_dict()
+        self._initial_state = {k: v.copy() for k, v in self.state_dict.items()}
+        return self._obs_np()
+
+    def restart(self):
+        if self._initial is None:
+            raise RuntimeError("restart() before reset()")
+        self._state.copy_(self._initial)
+        self._steps_t.zero_()
+        self._tb_t.zero_()
+        self._steps, self._time, self._time_balanced = 0, 0, 0
+        self._sync_state_dict()
+        return self._obs_np(), self._get_info()
+
+    def step(self, action):
+        if self._state is None:
+            raise RuntimeError("step() before reset()")
+        p = self.native_params()
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(self.act_dim, 1), device=self._device)
+        self._act_t.copy_(a)
+        info = self._get_info()     # the reference builds `info` BEFORE updating time_balanced
+        N.check(N.load().tg_env_step(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1,
+                                     self._act_t.data_ptr(), 1, self._state.data_ptr(), 1, self._steps_t.data_ptr(),
+                                     self._tb_t.data_ptr(), self._rew_t.data_ptr(), self._trunc_t.data_ptr(), 1,
+                                     N.stream_ptr(self._device)), "tg_env_step")
+        self._steps += 1
+        self._time += self.timestep
+        self._time_balanced = float(self._tb_t.item())
+        self._sync_state_dict()
+        reward = float(self._rew_t.item())
+        truncated = bool(self._trunc_t.item())
+        return self._obs_np(), reward, False, truncated, info
+
+    def render(self, *a, **k):
+        raise NotImplementedError("render() is matplotlib plotting in the reference and is out of scope here")
+
+
+class CartPole(Env):
+    """Swing-up cart-pole.  environments/cartpole_env.py:6-182."""
+    ENV_ID = N.TG_ENV_CARTPOLE
+    _state_split = (("cartpole", 5),)
+
+    def __init__(self, env_name: str = "CartPole", masscart: float = 1.0, masspole: float = 1.0, length: float = 0.5,
+                 gravity: float = 9.80665, timestep: float = 0.02, max_steps: int = 500, device=None,
+                 dtype=torch.float64):
+        super().__init__(env_name, device, dtype)
+        self.masscart, self.masspole, self.length, self.gravity = masscart, masspole, length, gravity
+        self.timestep, self.max_steps = timestep, max_steps
+        self.max_time = max_steps * timestep
+        self.state_dict = {"cartpole": np.zeros(5)}
+        self._is_3d = False
+        self.observation_space = Box(low=-1, high=1, shape=(5,), dtype=np.float32)
+        self.action_space = Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+
+    def _fill_params(self, p):
+        p.p[0], p.p[1], p.p[2], p.p[3] = self.masscart, self.masspole, self.length, self.gravity
+
+
+class QuadPole2D(Env):
+    """Planar quadrotor + pendulum payload.  environments/quadrotor_env.py:867-1223."""
+    ENV_ID = N.TG_ENV_QUADPOLE2D
+    _state_split = (("quadrotor", 8), ("pendulum", 2))     # as _propogate leaves it (:1041-1042)
+
+    def __init__(self, env_name="QuadPole2D", max_steps=500, timestep=0.02, device=None, dtype=torch.float64):
+        super().__init__(env_name, device, dtype)
+        self.mq, self.mp, self.I, self.Lq, self.Lp = 1.5, 0.5, 4e-1, 0.5, 0.75
+        self.gravity, self.timestep, self.max_steps = 9.80665, timestep, max_steps
+        self.spatial_bounds = ((-2.0, 2.0), (-2.0, 2.0))
+        self.balance_radius = 0.25
+        self._is_3d = False
+        self._xbounds, self._zbounds = self.spatial_bounds
+        self.hover_force = (self.mq + self.mp) * self.gravity / 2
+        self.state_dict = {"quadrotor": np.zeros(8), "pendulum": np.zeros(4)}
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(10,), dtype=np.float32)
+        self.action_space = Box(low=0.0, high=20.0, shape=(2,), dtype=np.float32)
+
+    def _fill_params(self, p):
+        b = self.spatial_bounds
+        if not (b[0][1] == b[1][1] == -b[0][0] == -b[1][0]):
+            raise ValueError("the HIP kernel supports symmetric, equal spatial bounds only")
+        for i, v in enumerate((self.mq, self.mp, self.I, self.Lq, self.Lp, self.gravity, b[0][1], self.balance_radius)):
+            p.p[i] = v
+
+
+class QuadPole(Env):
+    """3-D quadrotor (quaternion attitude) + tethered payload.  environments/quadrotor_env.py:353-713."""
+    ENV_ID = N.TG_ENV_QUADPOLE
+    _state_split = (("quadrotor", 13), ("pendulum", 7))
+
+    def __init__(self, env_name="QuadPole", max_steps=500, device=None, dtype=torch.float64):
+        super().__init__(env_name, device, dtype)
+        self.max_steps = max_steps
+        self.mass, self.load_mass, self.gravity, self.tether_length = 1.5, 0.5, 9.80665, 0.5
+        self.Ixx, self.Iyy, self.Izz = 4e-1, 4e-1, 2.5e-1
+        self.torque_constant, self.arm_length, self.timestep = 0.1, 0.5, 0.02
+        self.hover_force = (self.mass + self.load_mass) * self.gravity / 4
+        self.spatial_bounds = ((-1.5, 1.5), (-1.5, 1.5), (-1.5, 1.5))
+        self._xbounds, self._ybounds, self._zbounds = self.spatial_bounds
+        self.state_dict = {"quadrotor": np.zeros(13), "pendulum": np.zeros(7)}
+        self._is_3d = True
+        self.detailed_rendering = False
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(20,), dtype=np.float32)
+        self.action_space = Box(low=0.0, high=20.0, shape=(4,), dtype=np.float32)
+
+    def _fill_params(self, p):
+        b = self.spatial_bounds
+        hi = b[0][1]
+        if not all(x[1] == hi and x[0] == -hi for x in b):
+            raise ValueError("the HIP kernel supports symmetric, equal spatial bounds only")
+        for i, v in enumerate((self.mass, self.load_mass, self.gravity, self.tether_length, self.Ixx, self.Iyy,
+                               self.Izz, self.torque_constant, self.arm_length, hi)):
+            p.p[i] = v
+
+
+class Quadrotor:
+    """The reference's `Quadrotor` is a stub whose only usable member is `_dynamics`
+    (environments/quadrotor_env.py:6-182); this mirrors that pure function, batched."""
+
+    def __init__(self, mass=1.0, arm_length=0.2, Ixx=0.005, Iyy=0.005, Izz=0.006, torque_constant=0.017,
+                 gravity=9.80665, timestep=0.05, max_steps=200, device=None):
+        self.mass, self.arm_length, self.Ixx, self.Iyy, self.Izz = mass, arm_length, Ixx, Iyy, Izz
+        self.torque_constant, self.gravity, self.timestep, self.max_steps = torque_constant, gravity, timestep, max_steps
+        self._device = torch.device(device) if device is not None else torch.device("cuda", 0)
+
+    def _dynamics(self, state, control):
+        """state (12,) or (n,12), control (4,) or (n,4) -> next state, same shape (NumPy float64)."""
+        st = np.atleast_2d(np.asarray(state, dtype=np.float64))
+        ct = np.atleast_2d(np.asarray(control, dtype=np.float64))
+        n = st.shape[0]
+        p = N.default_params(N.TG_ENV_QUADROTOR12, self.max_steps)
+        p.timestep = float(self.timestep)
+        for i, v in enumerate((self.mass, self.arm_length, self.Ixx, self.Iyy, self.Izz, self.torque_constant, self.gravity)):
+            p.p[i] = v
+        s_d = torch.as_tensor(st.T.copy(), device=self._device)
+        c_d = torch.as_tensor(ct.T.copy(), device=self._device)
+        o_d = torch.empty_like(s_d)
+        N.check(N.load().tg_quadrotor12_dynamics(C.byref(p), N.TG_F64, s_d.data_ptr(), n, c_d.data_ptr(), n,
+                                                 o_d.data_ptr(), n, n, N.stream_ptr(self._device)), "tg_quadrotor12_dynamics")
+        out = o_d.cpu().numpy().T
+        return out[0] if np.ndim(state) == 1 else out
+
+
+class QuadrotorSwarm(Quadrotor):
+    """`class QuadrotorSwarm(Quadrotor): pass` in the reference (quadrotor_env.py:185-186)."""
+    pass
+
+
+ENV_CLASSES = {"CartPole": CartPole, "QuadPole2D": QuadPole2D, "QuadPole": QuadPole}

@@ -1,0 +1,134 @@
+"""Tensor-level wrappers over the C ABI for the returns / advantage / loss kernels.
+
+Every function takes CUDA (ROCm) tensors and enqueues on torch's current stream; none has a
+CPU fallback.  Layouts are the time-major SoA of the device trajectory: `[T][n]`, env fastest.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+
+def _st(t):
+    return N.stream_ptr(t.device)
+
+
+def rtg_scan(rew: torch.Tensor, mask: torch.Tensor, gamma: float) -> torch.Tensor:
+    """Reward-to-go (algorithms/grpo.py:66-74 == algorithms/ppo.py:100-111).  rew f32 [T][n], mask u8 [T][n]."""
+    N.require_cuda(rew, mask)
+    assert rew.dtype == torch.float32 and mask.dtype == torch.uint8 and rew.is_contiguous() and mask.is_contiguous()
+    T, n = rew.shape
+    out = torch.empty_like(rew)
+    N.check(N.load().tg_rtg_scan(rew.data_ptr(), mask.data_ptr(), float(gamma), out.data_ptr(), n, T, _st(rew)), "tg_rtg_scan")
+    return out
+
+
+def gae_scan(rew, values, mask, gamma: float, lam: float):
+    """GAE advantages and returns (algorithms/ppo.py:112-124)."""
+    N.require_cuda(rew, values, mask)
+    assert rew.dtype == values.dtype == torch.float32 and mask.dtype == torch.uint8
+    assert rew.is_contiguous() and values.is_contiguous() and mask.is_contiguous()
+    T, n = rew.shape
+    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    N.check(N.load().tg_gae_scan(rew.data_ptr(), values.data_ptr(), mask.data_ptr(), float(gamma), float(lam),
+                                 adv.data_ptr(), ret.data_ptr(), n, T, _st(rew)), "tg_gae_scan")
+    return adv, ret
+
+
+def masked_moments(x: torch.Tensor, mask: torch.Tensor, group_size: int) -> torch.Tensor:
+    """f64 [n/group_size][3] = (count, sum, sum of squares) over the valid entries of each group."""
+    N.require_cuda(x, mask)
+    assert x.dtype == torch.float32 and mask.dtype == torch.uint8 and x.is_contiguous() and mask.is_contiguous()
+    T, n = x.shape
+    out = torch.empty(n // group_size, 3, dtype=torch.float64, device=x.device)
+    work = torch.empty(3 * n, dtype=torch.float64, device=x.device)
+    N.check(N.load().tg_masked_moments(x.data_ptr(), mask.data_ptr(), n, T, int(group_size), out.data_ptr(),
+                                       work.data_ptr(), _st(x)), "tg_masked_moments")
+    return out
+
+
+def group_normalize(x, mask, moments, mode: int, group_size: int) -> torch.Tensor:
+    """mode 0: (x-mean_g)/std_g (GRPO, grpo.py:115); mode 1: /(std_g+1e-8) (PPO, ppo.py:138-139)."""
+    N.require_cuda(x, mask, moments)
+    assert moments.dtype == torch.float64 and moments.is_contiguous()
+    T, n = x.shape
+    out = torch.empty_like(x)
+    N.check(N.load().tg_group_normalize(x.data_ptr(), mask.data_ptr(), moments.data_ptr(), int(mode), out.data_ptr(),
+                                        n, T, int(group_size), _st(x)), "tg_group_normalize")
+    return out
+
+
+def _var_array(var):
+    v = [float(x) for x in var]
+    return (C.c_float * len(v))(*v), len(v)
+
+
+def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var) -> torch.Tensor:
+    """log N(act; mean, diag(var)) per row (actor_critic.py:159-160).  mean [M][A] f32 (row stride free),
+    act any 2-D strided [M][A] f32."""
+    N.require_cuda(mean, act)
+    assert mean.dtype == act.dtype == torch.float32 and mean.dim() == 2 and mean.stride(1) == 1
+    M, A = mean.shape
+    va, k = _var_array(var)
+    assert k == A
+    out = torch.empty(M, dtype=torch.float32, device=mean.device)
+    N.check(N.load().tg_gaussian_logp(mean.data_ptr(), mean.stride(0), act.data_ptr(), act.stride(0), act.stride(1),
+                                      va, A, out.data_ptr(), M, _st(mean)), "tg_gaussian_logp")
+    return out
+
+
+class SurrogateLoss(torch.autograd.Function):
+    """Fused clipped-surrogate (+ value MSE + KL-ish penalty) head: one kernel computes the loss sums
+    AND d(total)/d(mean), d(total)/d(value); backward just hands those to autograd so the MLP
+    forward/backward stay on PyTorch-ROCm.
+
+        total = surr_coef * sum_i min(rho_i A_i, clip(rho_i) A_i)
+              + critic_coef * sum_i (V_i - R_i)^2 + kl_coef * sum_i exp(lp_old_i)(lp_old_i - lp_i)
+
+    GRPO (grpo.py:137-145): surr_coef=+1/G, descent on J as the reference writes it.
+    PPO  (ppo.py:159-179): surr_coef=-1/n, critic_coef=c1/n, kl_coef=kl_coeff/n.
+    Returns (total f32 scalar, sums f64[4] = [sum surrogate, sum sq err, sum kl, #valid]).
+    """
+
+    @staticmethod
+    def forward(ctx, mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
+        N.require_cuda(mean, act, logp_old, adv)
+        assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.is_contiguous()
+        M, A = mean.shape
+        a = N.LossArgs()
+        a.d_mean, a.mean_row_stride = mean.data_ptr(), mean.stride(0)
+        a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
+        a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
+        grad_value = None
+        if value is not None:
+            assert value.dtype == torch.float32 and value.is_contiguous() and ret is not None and ret.is_contiguous()
+            grad_value = torch.empty_like(value)
+            a.d_value, a.d_ret, a.d_grad_value = value.data_ptr(), ret.data_ptr(), grad_value.data_ptr()
+        a.d_mask = N.ptr(mask)
+        a.d_norm = N.ptr(norm)
+        va, k = _var_array(var)
+        assert k == A
+        for i in range(A):
+            a.var[i] = va[i]
+        a.act_dim, a.epsilon = A, float(epsilon)
+        a.surr_coef, a.critic_coef, a.kl_coef = float(surr_coef), float(critic_coef), float(kl_coef)
+        grad_mean = torch.empty_like(mean)
+        sums = torch.empty(4, dtype=torch.float64, device=mean.device)
+        work = torch.empty(4 * N.load().tg_loss_work_blocks(), dtype=torch.float64, device=mean.device)
+        a.d_grad_mean, a.d_sums, a.d_work, a.M = grad_mean.data_ptr(), sums.data_ptr(), work.data_ptr(), M
+        N.check(N.load().tg_surrogate_loss(C.byref(a), _st(mean)), "tg_surrogate_loss")
+        ctx.save_for_backward(grad_mean, grad_value)
+        ctx.has_value = value is not None
+        total = (surr_coef * sums[0] + critic_coef * sums[1] + kl_coef * sums[2]).float()
+        ctx.mark_non_differentiable(sums)
+        return total, sums
+
+    @staticmethod
+    def backward(ctx, g_total, g_sums):
+        grad_mean, grad_value = ctx.saved_tensors
+        gm = grad_mean * g_total
+        gv = grad_value * g_total if ctx.has_value else None
+        return (gm, gv) + (None,) * 11

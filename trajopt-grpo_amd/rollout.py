@@ -1,0 +1,285 @@
+"""GPU-resident rollout: replaces the reference's RolloutManager / RolloutWorker process pool.
+
+Reference: rollout/rollout_manager.py:8-133 and rollout/rollout_worker.py:5-84.  There a
+pool of CPU workers each steps ONE NumPy env and calls the policy on ONE observation per
+step.  Here all `N = num_workers x num_episodes_per_worker` episodes of a rollout run in
+lock-step on the GPU: per time step one batched actor forward (PyTorch-ROCm GEMMs) and one
+fused HIP kernel (sample action -> Env.step -> record -> terminate).  The trajectory never
+leaves HBM; the reference's CPU float32 `(G,E,T,.)` 5-tuple is materialised only when a
+legacy caller asks for it (`rollout()` / buffer attributes).
+
+Device layout (env index fastest, see include/trajopt_grpo_hip.h):
+    obs [S][T+1][N]   act [A][T][N] f32   rew [T][N]   mask [T][N] u8   len [N] i32
+Flat env index n = g*E + e (buffers/rollout_buffer.py:85-89).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+from . import distributed as D
+
+
+class DeviceTrajectory:
+    """The tensors of one rollout, on the device, plus views the learner consumes."""
+
+    def __init__(self, S, A, T, n, G, E, dtype, device):
+        self.S, self.A, self.T, self.n, self.G, self.E = S, A, T, n, G, E
+        self.dtype, self.device = dtype, device
+        self.obs = torch.zeros(S, T + 1, n, dtype=dtype, device=device)
+        self.act = torch.zeros(A, T, n, dtype=torch.float32, device=device)
+        self.rew = torch.zeros(T, n, dtype=dtype, device=device)
+        self.mask = torch.zeros(T, n, dtype=torch.uint8, device=device)
+        self.len = torch.zeros(n, dtype=torch.int32, device=device)
+        self.counters = torch.zeros(4, dtype=torch.int64, device=device)
+
+    def native(self) -> N.Traj:
+        t = N.Traj()
+        t.d_obs, t.d_act, t.d_rew = self.obs.data_ptr(), self.act.data_ptr(), self.rew.data_ptr()
+        t.d_mask, t.d_len, t.d_counters = self.mask.data_ptr(), self.len.data_ptr(), self.counters.data_ptr()
+        t.n, t.horizon, t.dtype = self.n, self.T, N.dtype_code(self.dtype)
+        return t
+
+    # ---- learner views (no copies) ----------------------------------------
+    def obs_rows(self) -> torch.Tensor:
+        """[T*N][S] strided view: row i = t*N + n is the observation before action t of env n."""
+        return self.obs[:, :self.T, :].reshape(self.S, self.T * self.n).t()
+
+    def act_rows(self) -> torch.Tensor:
+        return self.act.reshape(self.A, self.T * self.n).t()
+
+    def env_steps(self) -> int:
+        return int(self.counters[0].item())
+
+    # ---- reference layout (CPU float32), rollout_manager.py:86-90 -------------------
+    def to_reference(self):
+        G, E, T = self.G, self.E, self.T
+        obs = self.obs[:, :T, :].permute(2, 1, 0).reshape(G, E, T, self.S).float().cpu()
+        act = self.act.permute(2, 1, 0).reshape(G, E, T, self.A).float().cpu()
+        rew = self.rew.t().reshape(G, E, T).float().cpu()
+        mask = self.mask.t().reshape(G, E, T).float().cpu()
+        ln = self.len.reshape(G, E).float().cpu()          # float32, like the manager's torch.zeros (:89)
+        return obs, act, rew, ln, mask
+
+
+class DeviceRollout:
+    """Runs `num_groups x episodes_per_group` episodes of `env` under `policy` on one GPU.
+
+    restart=False: every episode draws its own initial state (rollout_worker.py:72-73).
+    restart=True : the E episodes of a group share the group's initial state (:70-71), the
+                   GRPO "same prompt, different samples" arrangement.
+    """
+
+    def __init__(self, env, policy, num_groups: int, episodes_per_group: int, restart: bool = False,
+                 dtype=torch.float32, device=None, seed: int = 0, group_offset: int = 0,
+                 compute_dtype: Optional[torch.dtype] = None, use_graph: bool = False):
+        self.lib = N.load()
+        self.env, self.policy = env, policy
+        self.G, self.E = int(num_groups), int(episodes_per_group)
+        self.n = self.G * self.E
+        self.restart = bool(restart)
+        self.device = torch.device(device) if device is not None else policy.device
+        if self.device.type != "cuda":
+            raise N.NativeLibraryError("DeviceRollout needs an MI355X (cuda) device; there is no CPU fallback")
+        self.S, self.A, self.T = env.obs_dim, env.act_dim, int(env.max_steps)
+        self.dtype = dtype
+        self.compute_dtype = compute_dtype
+        self.group_offset = int(group_offset)
+        self.traj = DeviceTrajectory(self.S, self.A, self.T, self.n, self.G, self.E, dtype, self.device)
+        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64, device=self.device)
+        self.params = env.native_params()
+        self._sigma = (C.c_float * self.A)(*[float(v) for v in torch.sqrt(policy.var)])
+        self._linears = [m for m in policy.actor.network if isinstance(m, torch.nn.Linear)]
+        self._lowp = None
+        if compute_dtype is not None and compute_dtype != torch.float32:
+            self._lowp = [(torch.empty_like(l.weight, dtype=compute_dtype), torch.empty_like(l.bias, dtype=compute_dtype))
+                          for l in self._linears]
+        self.use_graph = use_graph
+        self._graph = None
+
+    # ---- policy mean for time step t -------------------------------------------------
+    def _refresh_weights(self):
+        if self._lowp is not None:
+            for (w, b), lin in zip(self._lowp, self._linears):
+                w.copy_(lin.weight)
+                b.copy_(lin.bias)
+
+    def _actor_mean(self, t: int) -> torch.Tensor:
+        x = self.traj.obs[:, t, :].t()                        # [N][S] view of the SoA slot
+        if self._lowp is None:
+            h = x if x.dtype == torch.float32 else x.float()
+            return self.policy.actor(h).contiguous()
+        h = x.to(self.compute_dtype)
+        li = 0
+        for mod in self.policy.actor.network:
+            if isinstance(mod, torch.nn.Linear):
+                w, b = self._lowp[li]
+                li += 1
+                h = F.linear(h, w, b)
+            else:
+                h = mod(h)
+        return h.float().contiguous()
+
+    # ---- one rollout -------------------------------------------------------------------
+    def _reset(self, tr, st):
+        # initial states go to slot 0 of obs; the draw is keyed by the global env (or group) index and
+        # by the rollout counter rng[1] (read on the host: it only selects the Philox stream)
+        seed, stream_id = int(self._seed_host), int(self._stream_host)
+        N.check(self.lib.tg_env_reset(C.byref(self.params), tr.dtype, tr.d_obs, (self.T + 1) * self.n, self.n,
+                                      seed, stream_id, self.group_offset * self.E, self.E if self.restart else 1, st),
+                "tg_env_reset")
+
+    @torch.no_grad()
+    def run(self, initial_states=None, forced_actions=None) -> DeviceTrajectory:
+        """One rollout.  `initial_states` (N,S) and `forced_actions` (N,T,A) or (G,E,T,A)
+        replace the RNG draws (teacher-forced parity runs)."""
+        self.params = self.env.native_params()
+        if not hasattr(self, "_stream_host"):
+            self._seed_host, self._stream_host = int(self.rng[0].item()), 0
+        sample = forced_actions is None
+        if self.use_graph and sample and initial_states is None:
+            self._run_graph()
+        else:
+            with torch.cuda.device(self.device):
+                if forced_actions is not None:
+                    fa = torch.as_tensor(np.asarray(forced_actions), dtype=torch.float32).reshape(self.n, self.T, self.A)
+                    self._enqueue_prepare(initial_states)
+                    self.traj.act.copy_(fa.permute(2, 1, 0).to(self.device))
+                    self._enqueue_steps(sample=False)
+                else:
+                    self._enqueue_prepare(initial_states)
+                    self._enqueue_steps(sample=True)
+        self._stream_host += 1
+        return self.traj
+
+    def _enqueue_prepare(self, initial_states):
+        lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
+        N.check(lib.tg_rollout_begin(C.byref(tr), self.S, self.A, st), "tg_rollout_begin")
+        if initial_states is None:
+            self._reset(tr, st)
+        else:
+            init = torch.as_tensor(np.asarray(initial_states), dtype=self.dtype).reshape(self.n, self.S)
+            self.traj.obs[:, 0, :].copy_(init.t().to(self.device))
+
+    def _enqueue_steps(self, sample: bool):
+        lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
+        p = C.byref(self.params)
+        if sample:
+            self._refresh_weights()
+        env_offset = self.group_offset * self.E
+        for t in range(self.T):
+            if sample:
+                mean = self._actor_mean(t)
+                N.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), self.A, self._sigma,
+                                            self.rng.data_ptr(), env_offset, st), "tg_rollout_step")
+            else:
+                N.check(lib.tg_rollout_step(p, C.byref(tr), t, None, 0, None, None, env_offset, st), "tg_rollout_step")
+        N.check(lib.tg_rollout_finish(C.byref(tr), st), "tg_rollout_finish")
+        N.check(lib.tg_rng_advance(self.rng.data_ptr(), st), "tg_rng_advance")
+
+    # ---- hipGraph replay of the whole T-step loop ---------------------------------------------
+    def _run_graph(self):
+        with torch.cuda.device(self.device):
+            # the reset draw depends on the host-side stream id, so it stays outside the graph
+            lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
+            N.check(lib.tg_rollout_begin(C.byref(tr), self.S, self.A, st), "tg_rollout_begin")
+            self._reset(tr, st)
+            if self._graph is None:
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):      # warm-up outside capture (library init, autotune)
+                    self._refresh_weights()
+                    self._actor_mean(0)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_steps(sample=True)
+                self._graph = g
+            self._graph.replay()
+
+
+# ---------------------------------------------------------------------------
+# drop-in classes
+# ---------------------------------------------------------------------------
+class RolloutWorker:
+    """rollout/rollout_worker.py:5-84.  `run_episodes` runs the E episodes in parallel on the GPU
+    and returns the reference's CPU tensors: obs (E,T,S), act (E,T,A), rew (E,T), len (E,) int32, mask (E,T)."""
+
+    def __init__(self, worker_id: int, env, policy, episodes_completed, **rollout_kwargs):
+        self.worker_id, self.env, self.policy = worker_id, env, policy
+        self.episodes_completed = episodes_completed
+        self._kw = rollout_kwargs
+        self._engines = {}
+
+    def _engine(self, num_episodes, restart):
+        key = (num_episodes, bool(restart))
+        if key not in self._engines:
+            kw = dict(self._kw)
+            kw.setdefault("seed", 0x9E3779B9 * (self.worker_id + 1) & 0x7FFFFFFF)
+            self._engines[key] = DeviceRollout(self.env, self.policy, 1, num_episodes, restart, **kw)
+        return self._engines[key]
+
+    def run_episodes(self, num_episodes: int = 5, restart: bool = False, initial_states=None, forced_actions=None):
+        traj = self._engine(num_episodes, restart).run(initial_states, forced_actions)
+        obs, act, rew, ln, mask = traj.to_reference()
+        self.episodes_completed[self.worker_id] = num_episodes
+        return obs[0], act[0], rew[0], ln[0].int(), mask[0]
+
+
+class RolloutManager:
+    """rollout/rollout_manager.py:21-133, same constructor.  `use_multiprocessing` and
+    `worker_class` are accepted for signature compatibility; the GPU pipeline replaces both.
+
+    Under torch.distributed (one process per GPU) the `num_workers` groups are split into
+    contiguous whole-group ranges per rank: this object then holds rank-local
+    groups and `rollout()` returns the local shard.
+    """
+
+    def __init__(self, env_fn, policy, worker_class=RolloutWorker, restart=False, num_workers: int = 4,
+                 num_episodes_per_worker: int = 5, use_multiprocessing: bool = True, *, dtype=torch.float32,
+                 device=None, seed: int = 0, compute_dtype=None, use_graph: bool = False, process_group=None):
+        self.env_fn, self.worker_class, self.policy = env_fn, worker_class, policy
+        self.restart = restart
+        self.num_workers = num_workers
+        self.num_episodes_per_worker = num_episodes_per_worker
+        self.use_multiprocessing = use_multiprocessing
+        self.env = env_fn()
+        self.obs_dim = self.env.observation_space.shape[0]
+        self.act_dim = self.env.action_space.shape[0]
+        self.max_steps = self.env.max_steps
+        self.process_group = process_group
+        self.rank, self.world_size = D.rank_world(process_group)
+        self.group_lo, self.group_hi = D.shard_groups(num_workers, self.rank, self.world_size)
+        self.local_groups = self.group_hi - self.group_lo
+        self.episodes_completed = [0 for _ in range(num_workers)]
+        self._engine_kw = dict(dtype=dtype, device=device, seed=seed, compute_dtype=compute_dtype, use_graph=use_graph)
+        self._engine = None
+
+    @property
+    def engine(self) -> DeviceRollout:
+        if self._engine is None:
+            self._engine = DeviceRollout(self.env, self.policy, self.local_groups, self.num_episodes_per_worker,
+                                         self.restart, group_offset=self.group_lo, **self._engine_kw)
+        return self._engine
+
+    def rollout_device(self, initial_states=None, forced_actions=None) -> DeviceTrajectory:
+        traj = self.engine.run(initial_states, forced_actions)
+        for g in range(self.group_lo, self.group_hi):
+            self.episodes_completed[g] = self.num_episodes_per_worker
+        return traj
+
+    def rollout(self, initial_states=None, forced_actions=None):
+        """-> (obs (G,E,T,S), act (G,E,T,A), rew (G,E,T), len (G,E), mask (G,E,T)) float32 CPU tensors,
+        zero beyond each episode's length (rollout_manager.py:85-125)."""
+        return self.rollout_device(initial_states, forced_actions).to_reference()
+
+    def print_progress(self):      # cosmetic ANSI bars in the reference (:63-83); nothing to draw here
+        pass
+
+    def shutdown(self):
+        self._engine = None
