@@ -3,8 +3,8 @@
 //
 // The reference computes the *wrapped control* in float32 (NumPy keeps
 // `hover + hover*np.clip(action,-1,1)` in the float32 dtype of the policy's action) and the
-// rest in float64.  That float32 control path is reproduced with explicitly rounded
-// __fmul_rn/__fadd_rn so the double build agrees with the reference to rounding noise.
+// rest in float64.  That float32 control path is reproduced with individually rounded
+// rn_mul/rn_add so the double build agrees with the reference to rounding noise.
 //
 // Citations: environments/cartpole_env.py, environments/quadrotor_env.py of the reference.
 #pragma once
@@ -54,7 +54,7 @@ template <typename R> struct CartPoleEnv {
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
         using M = Math<R>;
-        const float u32 = __fmul_rn(5.0f, clip1(a[0]));                       // :49
+        const float u32 = rn_mul(5.0f, clip1(a[0]));                       // :49
         const R u = (R)u32;                                                   // :60
         const R x = s[0], xd = s[1], sn = s[2], cs = s[3];
         const R thd = fmin(fmax(s[4], (R)-10), (R)10);                        // :58
@@ -74,7 +74,7 @@ template <typename R> struct CartPoleEnv {
         // reward on the new state; three summands (missing comma at :164-165)
         const R theta_cost = -(cs_n * cs_n * cs_n);
         const R thd_cost = thd_n * thd_n;
-        const float energy32 = __fmul_rn(0.001f, __fmul_rn(u32, u32));        // float32 in the reference
+        const float energy32 = rn_mul(0.001f, rn_mul(u32, u32));        // float32 in the reference
         const R e1 = (R)-5 * (x_n * x_n);
         const R e2 = (R)-0.5 * (xd_n * xd_n);
         const R e3 = -((R)20 * theta_cost - (R)20) * ((R)1 / ((R)1 + (R)2 * thd_cost)) - (R)energy32;
@@ -123,19 +123,19 @@ template <typename R> struct QuadPole2DEnv {
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
         using M = Math<R>;
-        const float u1 = __fadd_rn(c.hover32, __fmul_rn(c.hover32, clip1(a[0])));   // :928 (float32)
-        const float u2 = __fadd_rn(c.hover32, __fmul_rn(c.hover32, clip1(a[1])));
+        const float u1 = rn_add(c.hover32, rn_mul(c.hover32, clip1(a[0])));   // :928 (float32)
+        const float u2 = rn_add(c.hover32, rn_mul(c.hover32, clip1(a[1])));
         const R x = s[0], z = s[1], vx = s[2], vz = s[3], sth = s[4], cth = s[5], thd = s[6],
                 sph = s[7], cph = s[8], phd = s[9];
-        const R F = (R)__fadd_rn(u2, u1);                                     // :1085
-        const float ddtheta32 = __fmul_rn(c.Lq_over_I32, __fsub_rn(u2, u1));  // :1090 (float32)
+        const R F = (R)rn_add(u2, u1);                                     // :1085
+        const float ddtheta32 = rn_mul(c.Lq_over_I32, rn_sub(u2, u1));  // :1090 (float32)
         const R ddphi = -F * (sph * cth - sth * cph) / c.mq_Lp;               // :1094
         const R phd2 = phd * phd;
         const R ddx = (-sth * F - c.mpLp * cph * ddphi + c.mpLp * sph * phd2) / c.M;             // :1098
         const R ddz = (cth * F - c.M * c.g - c.mpLp * sph * ddphi - c.mpLp * cph * phd2) / c.M;  // :1101
         const R vx_n = vx + ddx * c.dt;                                       // :1105-1108
         const R vz_n = vz + ddz * c.dt;
-        const R thd_n = thd + (R)__fmul_rn(ddtheta32, c.dt32);
+        const R thd_n = thd + (R)rn_mul(ddtheta32, c.dt32);
         const R phd_n = phd + ddphi * c.dt;
         const R x_n = x + vx_n * c.dt;                                        // :1111-1112
         const R z_n = z + vz_n * c.dt;
@@ -215,8 +215,8 @@ template <typename R> struct QuadPoleEnv {
         using M = Math<R>;
         float u[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = __fadd_rn(c.hover32, __fmul_rn(c.hover32, clip1(a[i])));  // :413
-        const R u_tot = (R)__fadd_rn(__fadd_rn(__fadd_rn(u[0], u[1]), u[2]), u[3]);                  // :445
+        for (int i = 0; i < 4; ++i) u[i] = rn_add(c.hover32, rn_mul(c.hover32, clip1(a[i])));  // :413
+        const R u_tot = (R)rn_add(rn_add(rn_add(u[0], u[1]), u[2]), u[3]);                  // :445
 
         const R q[4] = {s[6], s[7], s[8], s[9]};
         const R om[3] = {s[10], s[11], s[12]};
@@ -248,12 +248,12 @@ template <typename R> struct QuadPoleEnv {
             pos_n[i] = s[i] + vel_n[i] * c.dt;                                // :484
         }
         // torques; the gyroscopic term is applied twice in the reference (kept).  :487-500
-        const R d_x = (R)__fsub_rn(__fsub_rn(__fadd_rn(u[0], u[2]), u[1]), u[3]);
-        const R d_y = (R)__fsub_rn(__fsub_rn(__fadd_rn(u[2], u[3]), u[0]), u[1]);
-        const float d_z32 = __fsub_rn(__fsub_rn(__fadd_rn(u[0], u[3]), u[1]), u[2]);
+        const R d_x = (R)rn_sub(rn_sub(rn_add(u[0], u[2]), u[1]), u[3]);
+        const R d_y = (R)rn_sub(rn_sub(rn_add(u[2], u[3]), u[0]), u[1]);
+        const float d_z32 = rn_sub(rn_sub(rn_add(u[0], u[3]), u[1]), u[2]);
         const R tau_x = c.s22 * d_x * c.arm - (c.Izz - c.Iyy) * om[1] * om[2];
         const R tau_y = c.s22 * d_y * c.arm - (c.Izz - c.Ixx) * om[0] * om[2];
-        const R tau_z = (R)__fmul_rn(c.tc32, d_z32);
+        const R tau_z = (R)rn_mul(c.tc32, d_z32);
         const R Jo[3] = {c.Ixx * om[0], c.Iyy * om[1], c.Izz * om[2]};
         const R cr[3] = {om[1] * Jo[2] - om[2] * Jo[1], om[2] * Jo[0] - om[0] * Jo[2], om[0] * Jo[1] - om[1] * Jo[0]};
         R om_n[3];

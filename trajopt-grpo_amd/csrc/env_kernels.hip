@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
         }
 #pragma unroll
         for (int k = 0; k < A; ++k) {
-            a[k] = __fadd_rn(mean[i * mean_rs + k], __fmul_rn(sigma.v[k], eps[k]));
+            a[k] = rn_add(mean[i * mean_rs + k], rn_mul(sigma.v[k], eps[k]));
             act[((int64_t)k * T + t) * n + i] = a[k];
         }
     } else {

@@ -34,9 +34,9 @@ __global__ __launch_bounds__(256) void rtg_scan_kernel(const float* __restrict__
         for (int k = 0; k < kChunk; ++k) {
             if (k < cnt) {
                 const float mf = (float)m[k];
-                const float R = __fadd_rn(__fmul_rn(r[k], mf), carry);
+                const float R = rn_add(rn_mul(r[k], mf), carry);
                 rtg[(int64_t)(t_hi - 1 - k) * n + i] = R;
-                carry = __fmul_rn(__fmul_rn(gamma, R), mf);
+                carry = rn_mul(rn_mul(gamma, R), mf);
             }
         }
     }
@@ -52,21 +52,21 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__
     if (i >= n) return;
     float next_v_m = 0.0f;   // V[t+1] * m[t+1]
     float next_a_m = 0.0f;   // (gamma*lam*A[t+1]) * m[t+1]
-    const float gl = __fmul_rn(gamma, lam);
+    const float gl = rn_mul(gamma, lam);
     for (int32_t t = T - 1; t >= 0; --t) {
         const int64_t idx = (int64_t)t * n + i;
         const float r = rew[idx], v = val[idx], mf = (float)mask[idx];
         float a;
         if (t == T - 1) {
-            a = __fsub_rn(r, v);
+            a = rn_sub(r, v);
         } else {
-            const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(gamma, next_v_m)), v);
-            a = __fadd_rn(delta, next_a_m);
+            const float delta = rn_sub(rn_add(r, rn_mul(gamma, next_v_m)), v);
+            a = rn_add(delta, next_a_m);
         }
         adv[idx] = a;
-        ret[idx] = __fadd_rn(v, a);
-        next_v_m = __fmul_rn(v, mf);
-        next_a_m = __fmul_rn(__fmul_rn(gl, a), mf);
+        ret[idx] = rn_add(v, a);
+        next_v_m = rn_mul(v, mf);
+        next_a_m = rn_mul(rn_mul(gl, a), mf);
     }
 }
 
@@ -144,14 +144,14 @@ __global__ __launch_bounds__(256) void group_normalize_kernel(const float* __res
     const double var = (s2 - s1 * mean) / (cnt - 1.0);
     const float meanf = (float)mean;
     const float stdf = (float)sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
-    const float denom = mode == 0 ? stdf : __fadd_rn(stdf, 1e-8f);
+    const float denom = mode == 0 ? stdf : rn_add(stdf, 1e-8f);
     const int32_t c = (T - t0) < kChunk ? (T - t0) : kChunk;
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) {
         if (k < c) {
             const int64_t idx = (int64_t)(t0 + k) * n + i;
             const float v = x[idx];
-            out[idx] = mask[idx] ? __fdiv_rn(__fsub_rn(v, meanf), denom) : 0.0f;
+            out[idx] = mask[idx] ? rn_div(rn_sub(v, meanf), denom) : 0.0f;
         }
     }
 }

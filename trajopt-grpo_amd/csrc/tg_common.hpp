@@ -25,6 +25,27 @@ int set_error(int code, const char* fmt, ...);
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Individually rounded fp32 operations.  HIP's __fmul_rn/__fadd_rn are plain `*`/`+` and get
+// contracted into FMAs under the default -ffp-contract=fast-honor-pragmas; the reference (NumPy /
+// torch CPU) rounds every operation, so the float32 control path and the reward-to-go recurrence
+// use these to stay bit-compatible.
+__device__ static inline float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ static inline float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ static inline float rn_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ static inline float rn_div(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------
