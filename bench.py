@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: GPU-resident rollout + PPO update on QuadPole ("quadrotor_env.py").
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: a 65,536-env x 256-step QuadPole rollout
+(reset -> [actor GEMMs -> fused sample+step HIP kernel] x T) followed by PPO.learn on that buffer with
+the reference factory's hyper-parameters (pipelines/quadpole_pipeline_ppo.py: 20-256x5-{4,1}
+actor-critic, cov 0.3, gamma 0.999, 32 full-batch updates, Adam 3e-4), i.e. BASELINE.json configs[2]
+(C3).  Metric: env-steps/s, where an env-step is one valid (mask == 1) Env.step.  Weak scaling: every
+rank runs 65,536 envs; gradients are all-reduced once per optimizer step (RCCL).
+
+Besides the contract fields, the JSON line carries
+  roofline      HBM roofline of the dynamics kernel (tg rollout_step_kernel): algorithmic bytes
+                (state-in-trajectory variant: 189 B / env-step for QuadPole) x env-steps
+                processed per launch / measured launch time (HIP events on the launch stream, in the
+                timed region, event-pair overhead calibrated and subtracted);
+  cpu_baseline  the CPU port of the reference path (oracle/: scalar fp64 env + batch-1 torch policy
+                per step in forked worker processes, then PPO.learn on CPU) timed on this box's host
+                cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HIDDEN = (256, 256, 256, 256, 256)
+ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
+HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (runs BEFORE the GPU is initialised: it forks worker processes)
+# ------------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    import numpy as np
+    import torch
+    from oracle import learner as L
+    wid, sd, T, episodes = args
+    torch.set_num_threads(1)
+    torch.manual_seed(1000 + wid)
+    pol = L.OraclePolicy(20, 4, HIDDEN, cov=0.3, critic=True)
+    pol.load_state_dict(sd)
+    env = L.OracleEnv("QuadPole", max_steps=T, rng=np.random.default_rng(1000 + wid))
+    with torch.no_grad():
+        return L.run_episodes(env, pol, episodes, restart=False)
+
+
+def cpu_baseline(T, updates, budget_workers=None, episodes=32):
+    import multiprocessing as mp
+    import torch
+    from oracle import learner as L
+    cores = len(os.sched_getaffinity(0))
+    workers = budget_workers or max(1, min(cores, 16))
+    torch.manual_seed(0)
+    pol = L.OraclePolicy(20, 4, HIDDEN, cov=0.3, critic=True)
+    sd = pol.state_dict()
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        outs = pool.map(_cpu_worker, [(w, sd, T, episodes) for w in range(workers)])
+    t_roll = time.perf_counter() - t0
+    obs, act, rew, ln, mask = (torch.stack([o[i] for o in outs]) for i in range(5))
+    steps = int(mask.sum())
+    torch.set_num_threads(workers)
+    opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+    t1 = time.perf_counter()
+    L.ppo_learn(pol, opt, obs, act, rew, mask, epsilon=0.2, gamma=0.999, lam=0.95, c1=0.5, kl_coeff=0.5,
+                entropy_coeff=0.01, updates_per_iter=updates)
+    t_learn = time.perf_counter() - t1
+    return {"value": steps / (t_roll + t_learn), "unit": "env-steps/s", "cores": workers, "kind": "port",
+            "sample": f"QuadPole T={T}, {workers} forked workers x {episodes} episodes ({steps} env-steps), "
+                      f"256x5 actor-critic, PPO {updates} full-batch updates; rollout {t_roll:.1f}s "
+                      f"({steps / t_roll:.0f} env-steps/s) + learn {t_learn:.1f}s",
+            "rollout_value": steps / t_roll}
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (groups of 256)")
+    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--updates", type=int, default=32, help="PPO updates_per_iter (reference factory: 32)")
+    ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.horizon, args.updates)
+
+    import torch
+    import torch.distributed as dist
+    import trajopt_grpo_amd as tg
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    E = 256
+    G_local = args.envs // E
+    G_global = G_local * world
+    T = args.horizon
+    cdt = torch.bfloat16 if args.policy_dtype == "bf16" else None
+    torch.manual_seed(0)                                      # identical random-init weights on every rank
+    policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
+    mk = lambda: tg.QuadPole(max_steps=T)
+    mgr = tg.RolloutManager(mk, policy, num_workers=G_global, num_episodes_per_worker=E, dtype=torch.float32,
+                            seed=1234, compute_dtype=cdt, use_graph=args.graph)
+    buf = tg.Rollout_Buffer(mgr)
+    algo = tg.PPO(epsilon=0.2, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4), ref_model=None,
+                  updates_per_iter=args.updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,
+                  batch_size=None, autocast_dtype=cdt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        buf.sample()
+        algo.learn(buf)
+
+    for _ in range(args.warmup):
+        one_step()
+    # event-pair overhead (no kernel in between), for the per-launch timing below
+    pairs = []
+    for _ in range(200):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    ev_overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+
+    env_steps = 0
+    t_roll = 0.0
+    launches = []            # (duration ms, env-steps in that launch)
+    if not args.graph:
+        mgr.engine.step_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r0 = time.perf_counter()
+        buf.sample()                        # ends with a host read of avg_reward -> rollout is complete here
+        t_roll += time.perf_counter() - r0
+        env_steps += buf.device_traj.env_steps()
+        if mgr.engine.step_events:
+            alive = buf.device_traj.mask.sum(1, dtype=torch.int64).tolist()
+            launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
+            mgr.engine.step_events = []
+        algo.learn(buf)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([float(env_steps), dt, t_roll], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_steps, dt, t_roll = float(tot[0]), float(mx[1]), float(mx[2])
+    else:
+        total_steps = float(env_steps)
+
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec at 65k parallel quadrotor envs (rollout + PPO update)",
+            "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 env state / %s policy" % args.policy_dtype, "data": "synthetic",
+            "config": {"workload": f"C3: QuadPole (quadrotor_env.py) PPO, {args.envs} envs/GPU x {T}-step horizon, "
+                                   f"natural termination, actor-critic 20-256x5-{{4,1}}, {args.updates} full-batch "
+                                   f"updates/iter, {args.policy_dtype} policy",
+                       "envs_per_gpu": args.envs, "horizon": T, "updates_per_iter": args.updates,
+                       "parallelism": f"env-shard x{world}, 1 grad all-reduce/step"},
+            "rollout_only_env_steps_per_s": total_steps / t_roll if t_roll > 0 else None,
+            "rollout_ms": 1e3 * t_roll / args.steps,
+            "env_steps_per_step": total_steps / args.steps,
+        }
+        if launches:
+            dur = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in launches) * 1e-3
+            units = sum(u for _, u in launches)
+            full = [(d, u) for d, u in launches if u == args.envs]
+            ach = ALGO_BYTES["QuadPole"] * units / dur / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>",
+                               "bytes_per_env_step": ALGO_BYTES["QuadPole"], "launches": len(launches),
+                               "avg_launch_us": 1e6 * dur / len(launches),
+                               "event_pair_overhead_us": 1e3 * ev_overhead_ms}
+            if full:
+                d_full = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in full) * 1e-3 / len(full)
+                out["roofline"]["full_launch_us"] = 1e6 * d_full
+                out["roofline"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,14 @@ typedef struct tg_loss_args {
 int  tg_loss_work_blocks(void);
 int  tg_surrogate_loss(const tg_loss_args* a, void* stream);
 
+/* ---- MLP backward glue (models/neural_network.py:67-77 under torch autograd in the reference) ----
+ * dZ = dA * (A > 0) in place (A = post-ReLU activations) fused with the bias-gradient column sums:
+ * d_partial f32 [tg_relu_bwd_bias_blocks()][cols]; the caller sums it over axis 0.
+ * Row-major [rows][cols]; bf16 needs cols % 8 == 0, f32 cols % 4 == 0. */
+int  tg_relu_bwd_bias_blocks(void);
+int  tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, int32_t is_bf16,
+                      float* d_partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

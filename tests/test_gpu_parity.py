@@ -524,3 +524,64 @@ def test_pipeline_trains_and_checkpoints(tg, dev, tmp_path, monkeypatch):
         assert torch.equal(a, b)
     assert len(pipe2.buffer.avg_reward) >= 1
     pipe2.shutdown()
+
+
+# --------------------------------------------------------------------------------------------
+# hand-scheduled MLP (GEMM chain + tg_relu_bwd_bias) against torch autograd
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dims", [(20, 4, (256, 256, 256)), (5, 1, (128, 64)), (10, 2, (32,))])
+def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
+    """Reference = torch autograd of the same module in the same compute dtype (autocast for bf16).
+    Gradients are sums over ~25k rows through ReLU masks: a single mask flip from rounding moves a
+    hidden-layer gradient by ~5e-4 relative (also seen between torch fp32 and fp64), so hidden layers
+    are compared in relative L2 norm; the head (no mask above it) is compared tightly."""
+    S, A, hidden = dims
+    torch.manual_seed(4)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    assert tg.mlp.supports(net)
+    m = tg.mlp.GemmMLP(net, cd)
+    rows = 3 * 8192 + 777                                     # three split-K blocks + a ragged tail
+    X = torch.randn(rows, S, device=dev)
+    g = torch.randn(rows, A, device=dev)
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    out = m.forward(m.prepare_input(X), keep=True)
+    m.backward(g)
+    got = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
+        ref = net(X)
+    ref = ref.float()
+    ref.backward(g)
+    bf = cd == torch.bfloat16
+    assert float((out - ref.detach()).abs().max()) <= (2e-2 if bf else 2e-6) * float(ref.abs().max())
+    names = [n for n, _ in net.named_parameters()]
+    for n, a, p in zip(names, got, net.parameters()):
+        rel = float((a - p.grad).norm() / p.grad.norm())
+        head = n.startswith(f"network.{2 * len(hidden)}.")
+        assert rel <= (5e-3 if bf else (5e-6 if head else 3e-3)), (n, rel)
+    pad = m.forward(m.prepare_input(X), keep=False, padded=True)
+    assert pad.shape[1] % 8 == 0 and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
+    assert not tg.mlp.supports(tg.NeuralNetwork(S, A, hidden, "Tanh"))
+
+
+def test_learners_fall_back_to_autograd_for_non_relu_nets(tg, dev):
+    """A Tanh policy cannot use the GEMM chain; learn() must still run (torch autograd path) and move the weights."""
+    torch.manual_seed(5)
+    pol = tg.GaussianActorCritic_NeuralNetwork(5, 1, (32, 32), activation="Tanh", cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=32), pol, num_workers=2, num_episodes_per_worker=64)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=1e-3), ref_model=None,
+                  updates_per_iter=2, batch_size=None)
+    before = [p.detach().clone() for p in pol.parameters()]
+    algo.learn(buf)
+    assert all(not torch.equal(a, b) for a, b in zip(before, pol.parameters()))
+    assert np.isfinite(algo.last_stats["total_loss"]).all()
+    # minibatch mode (batch_size set) takes several optimizer steps per epoch
+    algo2 = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=1e-3), ref_model=None,
+                   updates_per_iter=1, batch_size=1024)
+    algo2.learn(buf)
+    assert len(algo2.last_stats["total_loss"]) == -(-int(algo2.last_stats["n_valid"]) // 1024)

@@ -69,6 +69,8 @@ SIGNATURES = {
     "tg_gaussian_logp": (C.c_int, [_VP, _I64, _VP, _I64, _I64, _P(_F), C.c_int, _VP, _I64, _VP]),
     "tg_loss_work_blocks": (C.c_int, []),
     "tg_surrogate_loss": (C.c_int, [_P(LossArgs), _VP]),
+    "tg_relu_bwd_bias_blocks": (C.c_int, []),
+    "tg_relu_bwd_bias": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP, _VP]),
 }
 
 _lib = None

@@ -25,6 +25,7 @@ import torch
 
 from . import distributed as D
 from . import hip_ops as K
+from . import mlp as M
 from .rollout import DeviceTrajectory
 
 
@@ -73,13 +74,15 @@ def device_trajectory(buffer, device) -> DeviceTrajectory:
 class _GpuLearner(Algorithm):
     chunk_rows = 1 << 20
 
-    def _setup(self, policy, optimizer, chunk_rows, autocast_dtype, process_group):
+    def _setup(self, policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp=True):
         self.policy, self.optimizer = policy, optimizer
         if chunk_rows is not None:
             self.chunk_rows = int(chunk_rows)
         self.autocast_dtype = autocast_dtype
         self.process_group = process_group
+        self.fused_mlp = fused_mlp
         self._bucket = None
+        self._mlps = {}
         self.last_stats = {}
 
     @property
@@ -88,12 +91,42 @@ class _GpuLearner(Algorithm):
             self._bucket = D.GradBucket(list(self.policy.parameters()))
         return self._bucket
 
-    def _forward(self, net, x):
-        if self.autocast_dtype is not None:
-            with torch.autocast("cuda", dtype=self.autocast_dtype):
-                y = net(x)
-            return y.float()
-        return net(x)
+    # ---- MLP execution: hand-scheduled GEMM path (mlp.py) when the net is a ReLU MLP, else autograd ----
+    def _mlp(self, net):
+        key = id(net)
+        if key not in self._mlps:
+            ok = self.fused_mlp and M.supports(net) and next(net.parameters()).is_cuda
+            self._mlps[key] = M.GemmMLP(net, self.autocast_dtype or torch.float32) if ok else None
+        return self._mlps[key]
+
+    def _refresh(self, *nets):
+        for net in nets:
+            m = self._mlp(net)
+            if m is not None:
+                m.refresh()
+
+    def _prep(self, net, X):
+        m = self._mlp(net)
+        return m.prepare_input(X) if m is not None else X
+
+    def _forward(self, net, x, train=False):
+        """fp32 output [rows][out].  train=True keeps what backward needs (activations or the autograd graph)."""
+        m = self._mlp(net)
+        if m is not None:
+            return m.forward(x, keep=train)
+        with torch.set_grad_enabled(train):
+            if self.autocast_dtype is not None:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    y = net(x)
+                return y.float()
+            return net(x)
+
+    def _backward(self, net, out, grad):
+        m = self._mlp(net)
+        if m is not None:
+            m.backward(grad)
+        else:
+            out.backward(grad)
 
     def _gather_valid(self, traj):
         """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
@@ -104,13 +137,12 @@ class _GpuLearner(Algorithm):
         act = traj.act_rows().index_select(0, idx)
         return idx, X.contiguous(), act.contiguous()
 
-    def _logp_nograd(self, actor, X, act, var):
-        out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
-        with torch.no_grad():
-            for lo in range(0, X.shape[0], self.chunk_rows):
-                hi = min(lo + self.chunk_rows, X.shape[0])
-                mean = self._forward(actor, X[lo:hi]).contiguous()
-                out[lo:hi] = K.gaussian_logp(mean, act[lo:hi], var)
+    def _logp_nograd(self, actor, xin, act, var):
+        out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
+        for lo in range(0, xin.shape[0], self.chunk_rows):
+            hi = min(lo + self.chunk_rows, xin.shape[0])
+            mean = self._forward(actor, xin[lo:hi]).contiguous()
+            out[lo:hi] = K.gaussian_logp(mean, act[lo:hi], var)
         return out
 
 
@@ -119,12 +151,12 @@ class GRPO(_GpuLearner):
 
     def __init__(self, epsilon: float, beta: float, gamma: float, policy, optimizer, ref_model=None,
                  updates_per_iter: int = 10, *, maximize: bool = False, chunk_rows=None, autocast_dtype=None,
-                 process_group=None):
+                 process_group=None, fused_mlp: bool = True):
         self.epsilon, self.beta, self.gamma = epsilon, beta, gamma
         self.ref_model = ref_model
         self.updates_per_iter = updates_per_iter
         self.maximize = maximize
-        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group)
+        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp)
         self.old_policy = copy.deepcopy(self.policy)                        # grpo.py:48
 
     def learn(self, buffer) -> None:
@@ -142,20 +174,24 @@ class GRPO(_GpuLearner):
         _, world = D.rank_world(self.process_group)
         G_global = traj.G * world
         coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
-        old_logp = self._logp_nograd(self.old_policy.actor, X, act, var)    # grpo.py:118-119
+        actor = self.policy.actor
+        self._refresh(actor, self.old_policy.actor)
+        xin = self._prep(actor, X)
+        old_logp = self._logp_nograd(self.old_policy.actor, xin, act, var)  # grpo.py:118-119
         Js = []
         for _ in range(self.updates_per_iter):
             self.bucket.zero_()
             sums = torch.zeros(4, dtype=torch.float64, device=X.device)
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
-                mean = self._forward(self.policy.actor, X[lo:hi]).contiguous()
-                total, s = K.SurrogateLoss.apply(mean, None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None, None, None,
-                                                 var, self.epsilon, coef, 0.0, 0.0)
-                total.backward()
+                mean = self._forward(actor, xin[lo:hi], train=True).contiguous()
+                _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
+                                                   None, None, var, self.epsilon, coef, 0.0, 0.0)
+                self._backward(actor, mean, g_mean)
                 sums += s
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
             self.optimizer.step()
+            self._refresh(actor)
             Js.append(sums)
         self.old_policy.load_state_dict(self.policy.state_dict())           # grpo.py:148
         if Js:
@@ -180,39 +216,42 @@ class PPO(_GpuLearner):
     def __init__(self, epsilon: float, policy, optimizer, ref_model, updates_per_iter: int, c1: float = 0.5,
                  kl_coeff: float = 0.5, gamma: float = 0.99, lam: float = 0.95, entropy: float = 0.01,
                  batch_size: int = 64, monte_carlo: bool = True, *, chunk_rows=None, autocast_dtype=None,
-                 process_group=None, seed: int = 0):
+                 process_group=None, seed: int = 0, fused_mlp: bool = True):
         self.epsilon, self.c1, self.ref_model = epsilon, c1, ref_model
         self.updates_per_iter = updates_per_iter
         self.gamma, self.lam, self.entropy = gamma, lam, entropy
         self.batch_size, self.kl_coeff, self.monte_carlo = batch_size, kl_coeff, monte_carlo
-        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group)
+        self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp)
         self.old_policy = copy.deepcopy(self.policy)                        # ppo.py:62 (never read in learn)
         self._seed = seed
         self._gen = None
 
-    def _values_nograd(self, X):
-        out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
-        with torch.no_grad():
-            for lo in range(0, X.shape[0], self.chunk_rows):
-                hi = min(lo + self.chunk_rows, X.shape[0])
-                out[lo:hi] = self._forward(self.policy.critic, X[lo:hi]).reshape(-1)
+    def _values_nograd(self, xin):
+        out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
+        for lo in range(0, xin.shape[0], self.chunk_rows):
+            hi = min(lo + self.chunk_rows, xin.shape[0])
+            out[lo:hi] = self._forward(self.policy.critic, xin[lo:hi]).reshape(-1)
         return out
 
-    def _step(self, X, act, adv, ret, old_logp, norm, var, n_global, sums_out):
+    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out):
         """One optimizer step on the given rows (all local rows, or one minibatch)."""
+        actor, critic = self.policy.actor, self.policy.critic
         self.bucket.zero_()
-        sums = torch.zeros(4, dtype=torch.float64, device=X.device)
-        for lo in range(0, X.shape[0], self.chunk_rows):
-            hi = min(lo + self.chunk_rows, X.shape[0])
-            mean = self._forward(self.policy.actor, X[lo:hi]).contiguous()
-            value = self._forward(self.policy.critic, X[lo:hi]).reshape(-1).contiguous()
-            total, s = K.SurrogateLoss.apply(mean, value, act[lo:hi], old_logp[lo:hi], adv[lo:hi], ret[lo:hi], None, norm,
-                                             var, self.epsilon, -1.0 / n_global, self.c1 / n_global,
-                                             self.kl_coeff / n_global)
-            total.backward()
+        sums = torch.zeros(4, dtype=torch.float64, device=xin.device)
+        for lo in range(0, xin.shape[0], self.chunk_rows):
+            hi = min(lo + self.chunk_rows, xin.shape[0])
+            mean = self._forward(actor, xin[lo:hi], train=True).contiguous()
+            vout = self._forward(critic, xin[lo:hi], train=True)
+            value = vout.reshape(-1).contiguous()
+            _, s, g_mean, g_val = K.surrogate_loss(mean.detach(), value.detach(), act[lo:hi], old_logp[lo:hi], adv[lo:hi],
+                                                   ret[lo:hi], None, norm, var, self.epsilon, -1.0 / n_global,
+                                                   self.c1 / n_global, self.kl_coeff / n_global)
+            self._backward(actor, mean, g_mean)
+            self._backward(critic, vout, g_val.view_as(vout))
             sums += s
         self.bucket.allreduce(self.process_group)                            # one RCCL all-reduce / step
         self.optimizer.step()
+        self._refresh(actor, critic)
         sums_out.append(sums)
 
     def learn(self, buffer) -> None:
@@ -221,8 +260,10 @@ class PPO(_GpuLearner):
         T, n = traj.T, traj.n
         idx, X, act = self._gather_valid(traj)
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
+        self._refresh(self.policy.actor, self.policy.critic)
+        xin = self._prep(self.policy.actor, X)          # actor and critic share input width / compute dtype
         # V on valid rows only; padded rows never reach a result (they are masked in both scans)
-        v_valid = self._values_nograd(X)                                    # ppo.py:93
+        v_valid = self._values_nograd(xin)                                  # ppo.py:93
         V = torch.zeros(T * n, dtype=torch.float32, device=X.device)
         V.index_copy_(0, idx, v_valid)
         V = V.view(T, n)
@@ -242,14 +283,14 @@ class PPO(_GpuLearner):
         n_global = float(cnt[0].item())
         adv = adv_full.reshape(-1).index_select(0, idx)
         ret = rtg.reshape(-1).index_select(0, idx)
-        old_logp = self._logp_nograd(self.policy.actor, X, act, var)        # ppo.py:142-143 (current policy)
+        old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)
         M = X.shape[0]
         _, world = D.rank_world(self.process_group)
         all_sums = []
         for _ in range(self.updates_per_iter):
             if self.batch_size is None:
                 # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
-                self._step(X, act, adv, ret, old_logp, norm, var, n_global, all_sums)
+                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums)
             else:
                 if self._gen is None:
                     self._gen = torch.Generator(device=X.device)
@@ -260,7 +301,7 @@ class PPO(_GpuLearner):
                     b = perm[lo:lo + local_bs]
                     nb = torch.tensor([float(b.numel())], dtype=torch.float64, device=X.device)
                     D.allreduce_sum_(nb, self.process_group)
-                    self._step(X.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
+                    self._step(xin.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
                                ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(nb.item()), all_sums)
         self.old_policy.load_state_dict(self.policy.state_dict())           # ppo.py:186
         if all_sums:

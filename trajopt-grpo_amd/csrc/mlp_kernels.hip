@@ -1,0 +1,112 @@
+// Elementwise pieces of the MLP backward that PyTorch would run as separate passes:
+// ReLU backward fused with the bias-gradient column sums (one read of dA and A, one write of dZ).
+#include "tg_common.hpp"
+
+namespace tg {
+
+constexpr int kReluBlocks = 2048;
+
+__device__ static inline float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// dZ = dA * (A > 0) in place;  partial[block][c] = sum over the block's rows of dZ[:, c].
+// bf16, row-major [rows][cols], cols % 8 == 0 and cols <= 2048.  Each thread owns 8 consecutive columns.
+__global__ __launch_bounds__(256) void relu_bwd_bias_bf16_kernel(uint16_t* __restrict__ dA, const uint16_t* __restrict__ A,
+                                                                 int64_t rows, int cols, float* __restrict__ partial) {
+    extern __shared__ float sh[];                   // [rows_per_pass][cols]
+    const int tpr = cols >> 3;                      // threads per row
+    const int rpp = blockDim.x / tpr;               // rows per pass
+    const int rl = threadIdx.x / tpr, cl = (threadIdx.x % tpr) << 3;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (rl < rpp) {
+        for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < rows; r += (int64_t)gridDim.x * rpp) {
+            const int64_t off = r * cols + cl;
+            uint4 d = *reinterpret_cast<const uint4*>(dA + off);
+            const uint4 a = *reinterpret_cast<const uint4*>(A + off);
+            uint32_t dv[4] = {d.x, d.y, d.z, d.w};
+            const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // post-ReLU activations are >= 0: positive  <=>  nonzero magnitude bits and sign clear
+                const uint16_t a_lo = (uint16_t)(av[j] & 0xFFFFu), a_hi = (uint16_t)(av[j] >> 16);
+                const bool p_lo = (a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u);
+                const bool p_hi = (a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u);
+                uint32_t v = dv[j];
+                if (!p_lo) v &= 0xFFFF0000u;
+                if (!p_hi) v &= 0x0000FFFFu;
+                dv[j] = v;
+                acc[2 * j] += bf16_to_f32((uint16_t)(v & 0xFFFFu));
+                acc[2 * j + 1] += bf16_to_f32((uint16_t)(v >> 16));
+            }
+            d.x = dv[0]; d.y = dv[1]; d.z = dv[2]; d.w = dv[3];
+            *reinterpret_cast<uint4*>(dA + off) = d;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[rl * cols + cl + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += sh[r * cols + c];
+        partial[(int64_t)blockIdx.x * cols + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_bias_f32_kernel(float* __restrict__ dA, const float* __restrict__ A,
+                                                                int64_t rows, int cols, float* __restrict__ partial) {
+    extern __shared__ float sh[];
+    const int tpr = cols >> 2;                      // 4 floats (16 B) per thread
+    const int rpp = blockDim.x / tpr;
+    const int rl = threadIdx.x / tpr, cl = (threadIdx.x % tpr) << 2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rpp) {
+        for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < rows; r += (int64_t)gridDim.x * rpp) {
+            const int64_t off = r * cols + cl;
+            float4 d = *reinterpret_cast<const float4*>(dA + off);
+            const float4 a = *reinterpret_cast<const float4*>(A + off);
+            d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f;
+            d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+            acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
+            *reinterpret_cast<float4*>(dA + off) = d;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[rl * cols + cl + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += sh[r * cols + c];
+        partial[(int64_t)blockIdx.x * cols + c] = s;
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_relu_bwd_bias_blocks(void) { return kReluBlocks; }
+
+int tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial,
+                     void* stream) {
+    TG_REQUIRE(d_dA && d_A && d_partial, "tg_relu_bwd_bias: null pointer");
+    const int per = is_bf16 ? 8 : 4;
+    TG_REQUIRE(rows >= 0 && cols > 0 && cols % per == 0 && cols / per <= 256,
+               "tg_relu_bwd_bias: cols=%d must be a multiple of %d and <= %d", cols, per, 256 * per);
+    const int tpr = cols / per, rpp = 256 / tpr;
+    const size_t shmem = (size_t)rpp * cols * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16) {
+        hipLaunchKernelGGL(relu_bwd_bias_bf16_kernel, dim3(kReluBlocks), dim3(256), shmem, st, (uint16_t*)d_dA,
+                           (const uint16_t*)d_A, rows, cols, d_partial);
+    } else {
+        hipLaunchKernelGGL(relu_bwd_bias_f32_kernel, dim3(kReluBlocks), dim3(256), shmem, st, (float*)d_dA, (const float*)d_A,
+                           rows, cols, d_partial);
+    }
+    TG_LAUNCH_CHECK("tg_relu_bwd_bias");
+    return TG_OK;
+}
+
+}  // extern "C"

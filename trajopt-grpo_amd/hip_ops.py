@@ -80,6 +80,37 @@ def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var) -> torch.Tensor:
     return out
 
 
+def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
+    """One launch of tg_surrogate_loss: returns (total f32 scalar, sums f64[4], d total/d mean, d total/d value|None)."""
+    N.require_cuda(mean, act, logp_old, adv)
+    assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.is_contiguous()
+    M, A = mean.shape
+    a = N.LossArgs()
+    a.d_mean, a.mean_row_stride = mean.data_ptr(), mean.stride(0)
+    a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
+    a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
+    grad_value = None
+    if value is not None:
+        assert value.dtype == torch.float32 and value.is_contiguous() and ret is not None and ret.is_contiguous()
+        grad_value = torch.empty_like(value)
+        a.d_value, a.d_ret, a.d_grad_value = value.data_ptr(), ret.data_ptr(), grad_value.data_ptr()
+    a.d_mask = N.ptr(mask)
+    a.d_norm = N.ptr(norm)
+    va, k = _var_array(var)
+    assert k == A
+    for i in range(A):
+        a.var[i] = va[i]
+    a.act_dim, a.epsilon = A, float(epsilon)
+    a.surr_coef, a.critic_coef, a.kl_coef = float(surr_coef), float(critic_coef), float(kl_coef)
+    grad_mean = torch.empty_like(mean)
+    sums = torch.empty(4, dtype=torch.float64, device=mean.device)
+    work = torch.empty(4 * N.load().tg_loss_work_blocks(), dtype=torch.float64, device=mean.device)
+    a.d_grad_mean, a.d_sums, a.d_work, a.M = grad_mean.data_ptr(), sums.data_ptr(), work.data_ptr(), M
+    N.check(N.load().tg_surrogate_loss(C.byref(a), _st(mean)), "tg_surrogate_loss")
+    total = (surr_coef * sums[0] + critic_coef * sums[1] + kl_coef * sums[2]).float()
+    return total, sums, grad_mean, grad_value
+
+
 class SurrogateLoss(torch.autograd.Function):
     """Fused clipped-surrogate (+ value MSE + KL-ish penalty) head: one kernel computes the loss sums
     AND d(total)/d(mean), d(total)/d(value); backward just hands those to autograd so the MLP
@@ -95,34 +126,10 @@ class SurrogateLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
-        N.require_cuda(mean, act, logp_old, adv)
-        assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.is_contiguous()
-        M, A = mean.shape
-        a = N.LossArgs()
-        a.d_mean, a.mean_row_stride = mean.data_ptr(), mean.stride(0)
-        a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
-        a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
-        grad_value = None
-        if value is not None:
-            assert value.dtype == torch.float32 and value.is_contiguous() and ret is not None and ret.is_contiguous()
-            grad_value = torch.empty_like(value)
-            a.d_value, a.d_ret, a.d_grad_value = value.data_ptr(), ret.data_ptr(), grad_value.data_ptr()
-        a.d_mask = N.ptr(mask)
-        a.d_norm = N.ptr(norm)
-        va, k = _var_array(var)
-        assert k == A
-        for i in range(A):
-            a.var[i] = va[i]
-        a.act_dim, a.epsilon = A, float(epsilon)
-        a.surr_coef, a.critic_coef, a.kl_coef = float(surr_coef), float(critic_coef), float(kl_coef)
-        grad_mean = torch.empty_like(mean)
-        sums = torch.empty(4, dtype=torch.float64, device=mean.device)
-        work = torch.empty(4 * N.load().tg_loss_work_blocks(), dtype=torch.float64, device=mean.device)
-        a.d_grad_mean, a.d_sums, a.d_work, a.M = grad_mean.data_ptr(), sums.data_ptr(), work.data_ptr(), M
-        N.check(N.load().tg_surrogate_loss(C.byref(a), _st(mean)), "tg_surrogate_loss")
+        total, sums, grad_mean, grad_value = surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var,
+                                                            epsilon, surr_coef, critic_coef, kl_coef)
         ctx.save_for_backward(grad_mean, grad_value)
         ctx.has_value = value is not None
-        total = (surr_coef * sums[0] + critic_coef * sums[1] + kl_coef * sums[2]).float()
         ctx.mark_non_differentiable(sums)
         return total, sums
 

@@ -1,0 +1,140 @@
+"""Hand-scheduled forward/backward of the reference's ReLU MLP on PyTorch-ROCm GEMMs.
+
+`models/neural_network.py:48-66` is `Sequential(Linear, ReLU, ..., Linear)`; under torch autograd
+(the reference, algorithms/*.py `loss.backward()`) that costs ~12 launches per layer and, at the
+shapes of this path (10^6..10^7 rows x 256 features), two pathologies on MI355X:
+  * the weight gradient dW = dZ^T A is a [256 x rows] x [rows x 256] GEMM: 16 output tiles on 256
+    CUs, no split-K -> 1.6-1.9 ms per 2^20 rows.  Here it is a batched GEMM over row blocks
+    (fp32 partials) plus one small reduction: 0.24 ms;
+  * N = 1 (critic head) and K = 20 (first layer) hit slow hipBLASLt paths: the head is padded to
+    8 outputs and the input to 32 features (zero weights / zero columns; results unchanged).
+Bias + ReLU ride in the forward GEMM epilogue (`torch._addmm_activation`), ReLU-backward and the
+bias gradient are one HIP kernel (`tg_relu_bwd_bias`).  Gradients are accumulated in fp32 straight
+into `param.grad` (the learner's flat all-reduce bucket).
+
+Only ReLU hidden activations take this path; anything else stays on torch autograd.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+
+_ROW_BLOCK = 8192
+
+
+def supports(net) -> bool:
+    mods = list(net.network)
+    if len(mods) < 3 or len(mods) % 2 == 0:
+        return False
+    for i, m in enumerate(mods):
+        if i % 2 == 0 and not isinstance(m, torch.nn.Linear):
+            return False
+        if i % 2 == 1 and not isinstance(m, torch.nn.ReLU):
+            return False
+    return all(l.out_features % 8 == 0 for l in mods[0:-1:2])
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class GemmMLP:
+    def __init__(self, net, compute_dtype=torch.bfloat16):
+        assert supports(net)
+        self.net = net
+        self.cd = compute_dtype
+        self.linears = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        dev = self.linears[0].weight.device
+        self.in_dim, self.out_dim = self.linears[0].in_features, self.linears[-1].out_features
+        self.in_pad = _round_up(self.in_dim, 32)
+        self.out_pad = _round_up(self.out_dim, 8)
+        self.w, self.b = [], []
+        for i, l in enumerate(self.linears):
+            o = self.out_pad if i == len(self.linears) - 1 else l.out_features
+            k = self.in_pad if i == 0 else l.in_features
+            self.w.append(torch.zeros(o, k, dtype=compute_dtype, device=dev))
+            self.b.append(torch.zeros(o, dtype=compute_dtype, device=dev))
+        self._acts = None
+        self._partial = None
+        self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    def refresh(self):
+        """Copy the fp32 master weights into the (padded) compute-dtype operands."""
+        with torch.no_grad():
+            for w, b, l in zip(self.w, self.b, self.linears):
+                w[:l.out_features, :l.in_features].copy_(l.weight)
+                b[:l.out_features].copy_(l.bias)
+            self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
+
+    def prepare_input(self, X: torch.Tensor) -> torch.Tensor:
+        """[M][in_dim] (any float dtype, any strides) -> contiguous [M][in_pad] compute dtype, zero padded."""
+        xp = torch.zeros(X.shape[0], self.in_pad, dtype=self.cd, device=X.device)
+        xp[:, :self.in_dim].copy_(X)
+        return xp
+
+    @torch.no_grad()
+    def forward(self, xp: torch.Tensor, keep: bool = True, padded: bool = False) -> torch.Tensor:
+        """-> fp32 [rows][out_dim] (contiguous), or the [rows][out_pad] buffer itself with padded=True
+        (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward()."""
+        acts = [xp]
+        h = xp
+        L = len(self.linears)
+        for i in range(L - 1):
+            h = torch._addmm_activation(self.b[i], h, self.w[i].t())       # bias + ReLU in the GEMM epilogue
+            acts.append(h)
+        if self.cd == torch.float32:
+            out = torch.addmm(self.b[-1], h, self.w[-1].t())
+        else:                                                              # fp32 accumulate AND fp32 output for the head
+            out = torch.mm(h, self.w[-1].t(), out_dtype=torch.float32)
+            out += self.bias_out_f32
+        self._acts = acts if keep else None
+        return out if padded else out[:, :self.out_dim].contiguous()
+
+    def _dw(self, dz: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+        """dz^T a in fp32 via a batched GEMM over row blocks (split-K with fp32 partials)."""
+        rows = dz.shape[0]
+        nb = rows // _ROW_BLOCK
+        out = None
+        if nb > 0:
+            main = nb * _ROW_BLOCK
+            p = torch.bmm(dz[:main].view(nb, _ROW_BLOCK, dz.shape[1]).transpose(1, 2),
+                          a[:main].view(nb, _ROW_BLOCK, a.shape[1]), out_dtype=torch.float32)
+            out = p.sum(0)
+        if rows - nb * _ROW_BLOCK > 0:
+            tail = torch.mm(dz[nb * _ROW_BLOCK:].t(), a[nb * _ROW_BLOCK:], out_dtype=torch.float32) \
+                if self.cd != torch.float32 else dz[nb * _ROW_BLOCK:].t() @ a[nb * _ROW_BLOCK:]
+            out = tail if out is None else out + tail
+        return out
+
+    @torch.no_grad()
+    def backward(self, dout: torch.Tensor):
+        """dout fp32 [rows][out_dim] = d loss / d output.  Accumulates into weight.grad / bias.grad (fp32)."""
+        acts = self._acts
+        assert acts is not None, "backward() needs forward(keep=True)"
+        lib = N.load()
+        rows = dout.shape[0]
+        L = len(self.linears)
+        dz = torch.zeros(rows, self.out_pad, dtype=self.cd, device=dout.device)
+        dz[:, :self.out_dim].copy_(dout)
+        lin = self.linears[-1]
+        lin.bias.grad.add_(dout.sum(0))
+        lin.weight.grad.add_(self._dw(dz, acts[L - 1])[:self.out_dim])
+        da = dz @ self.w[-1]
+        is_bf16 = 1 if self.cd == torch.bfloat16 else 0
+        nblk = lib.tg_relu_bwd_bias_blocks()
+        for i in range(L - 2, -1, -1):
+            a = acts[i + 1]
+            cols = a.shape[1]
+            if self._partial is None or self._partial.shape[1] != cols:
+                self._partial = torch.empty(nblk, cols, dtype=torch.float32, device=dout.device)
+            N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, self._partial.data_ptr(),
+                                         N.stream_ptr(dout.device)), "tg_relu_bwd_bias")
+            lin = self.linears[i]
+            lin.bias.grad.add_(self._partial.sum(0))
+            dw = self._dw(da, acts[i])
+            lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
+            if i > 0:
+                da = da @ self.w[i]
+        self._acts = None

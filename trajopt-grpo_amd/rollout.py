@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import _native as N
 from . import distributed as D
+from . import mlp as M
 
 
 class DeviceTrajectory:
@@ -96,21 +97,35 @@ class DeviceRollout:
         self._sigma = (C.c_float * self.A)(*[float(v) for v in torch.sqrt(policy.var)])
         self._linears = [m for m in policy.actor.network if isinstance(m, torch.nn.Linear)]
         self._lowp = None
-        if compute_dtype is not None and compute_dtype != torch.float32:
+        self._mlp = None
+        if M.supports(policy.actor):
+            # hand-scheduled GEMM chain (bias+ReLU in the GEMM epilogue, padded K / head): mlp.py
+            self._mlp = M.GemmMLP(policy.actor, compute_dtype or torch.float32)
+            self._xp = torch.zeros(self.n, self._mlp.in_pad, dtype=self._mlp.cd, device=self.device)
+        elif compute_dtype is not None and compute_dtype != torch.float32:
             self._lowp = [(torch.empty_like(l.weight, dtype=compute_dtype), torch.empty_like(l.bias, dtype=compute_dtype))
                           for l in self._linears]
         self.use_graph = use_graph
         self._graph = None
+        # when set to a list, every tg_rollout_step launch is bracketed by HIP events on the launch
+        # stream (bench.py reads them back for the dynamics kernel's roofline)
+        self.step_events = None
 
     # ---- policy mean for time step t -------------------------------------------------
     def _refresh_weights(self):
+        if self._mlp is not None:
+            self._mlp.refresh()
         if self._lowp is not None:
             for (w, b), lin in zip(self._lowp, self._linears):
                 w.copy_(lin.weight)
                 b.copy_(lin.bias)
 
     def _actor_mean(self, t: int) -> torch.Tensor:
+        """Policy mean for slot t: fp32 [N][>=A] with unit column stride (row stride = .stride(0))."""
         x = self.traj.obs[:, t, :].t()                        # [N][S] view of the SoA slot
+        if self._mlp is not None:
+            self._xp[:, :self.S].copy_(x)
+            return self._mlp.forward(self._xp, keep=False, padded=True)
         if self._lowp is None:
             h = x if x.dtype == torch.float32 else x.float()
             return self.policy.actor(h).contiguous()
@@ -173,12 +188,22 @@ class DeviceRollout:
             self._refresh_weights()
         env_offset = self.group_offset * self.E
         for t in range(self.T):
+            ev = None
             if sample:
                 mean = self._actor_mean(t)
-                N.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), self.A, self._sigma,
+                if self.step_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                N.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), mean.stride(0), self._sigma,
                                             self.rng.data_ptr(), env_offset, st), "tg_rollout_step")
             else:
+                if self.step_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 N.check(lib.tg_rollout_step(p, C.byref(tr), t, None, 0, None, None, env_offset, st), "tg_rollout_step")
+            if ev is not None:
+                ev[1].record()
+                self.step_events.append((t, ev[0], ev[1]))
         N.check(lib.tg_rollout_finish(C.byref(tr), st), "tg_rollout_finish")
         N.check(lib.tg_rng_advance(self.rng.data_ptr(), st), "tg_rng_advance")
 
