@@ -184,7 +184,7 @@ def main():
             "metric": "env-steps/sec at 65k parallel quadrotor envs (rollout + PPO update)",
             "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 env state / %s policy" % args.policy_dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "policy_dtype": args.policy_dtype, "data": "synthetic",
             "config": {"workload": f"C3: QuadPole (quadrotor_env.py) PPO, {args.envs} envs/GPU x {T}-step horizon, "
                                    f"natural termination, actor-critic 20-256x5-{{4,1}}, {args.updates} full-batch "
                                    f"updates/iter, {args.policy_dtype} policy",
@@ -199,8 +199,12 @@ def main():
             units = sum(u for _, u in launches)
             full = [(d, u) for d, u in launches if u == args.envs]
             ach = ALGO_BYTES["QuadPole"] * units / dur / 1e9
+            # HBM bytes of one all-alive launch at 65,536 envs from the PMC passes committed under profiles/
+            # (r01_step_kernel_65536_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction); not re-measured live
+            traffic = 14334976 if args.envs == 65536 else None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (all-alive launch)",
                                "kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>",
                                "bytes_per_env_step": ALGO_BYTES["QuadPole"], "launches": len(launches),
                                "avg_launch_us": 1e6 * dur / len(launches),

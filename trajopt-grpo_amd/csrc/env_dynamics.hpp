@@ -12,8 +12,14 @@
 
 namespace tg {
 
+// div_/inv_sqrt_/norm2_: the double build keeps the reference's exact operation order (division, sqrt then
+// square); the float build uses the 1-ulp hardware reciprocal / rsqrt (v_rcp_f32, v_rsq_f32): a few fp32 ulp
+// per step, far inside the fp32-vs-fp64 trajectory noise, and ~half the VALU work of the kernel.
 template <typename R> struct Math;
 template <> struct Math<float> {
+    static constexpr bool kFast = true;
+    __device__ static inline float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    __device__ static inline float inv_sqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
     __device__ static inline float sqrt_(float x) { return sqrtf(x); }
     __device__ static inline float atan2_(float y, float x) { return atan2f(y, x); }
     __device__ static inline void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
@@ -21,6 +27,9 @@ template <> struct Math<float> {
     __device__ static inline float tan_(float x) { return tanf(x); }
 };
 template <> struct Math<double> {
+    static constexpr bool kFast = false;
+    __device__ static inline double div_(double a, double b) { return a / b; }
+    __device__ static inline double inv_sqrt_(double x) { return 1.0 / sqrt(x); }
     __device__ static inline double sqrt_(double x) { return sqrt(x); }
     __device__ static inline double atan2_(double y, double x) { return atan2(y, x); }
     __device__ static inline void sincos_(double x, double* s, double* c) { sincos(x, s, c); }
@@ -236,9 +245,11 @@ template <typename R> struct QuadPoleEnv {
         const R ut[3] = {rot[1], rot[2], rot[3]};
         const R ud[3] = {omp[1] * ut[2] - omp[2] * ut[1], omp[2] * ut[0] - omp[0] * ut[2],
                          omp[0] * ut[1] - omp[1] * ut[0]};                    // :473
-        const R udn = M::sqrt_(ud[0] * ud[0] + ud[1] * ud[1] + ud[2] * ud[2]);
+        const R ud2 = ud[0] * ud[0] + ud[1] * ud[1] + ud[2] * ud[2];
+        R udn2 = ud2;                                                         // |u_dot|^2
+        if constexpr (!M::kFast) { const R udn = M::sqrt_(ud2); udn2 = udn * udn; }   // norm()**2 as written
         const R Fdot = F[0] * ut[0] + F[1] * ut[1] + F[2] * ut[2];
-        const R T = c.tension_k * (Fdot - c.m0L * (udn * udn));               // :476
+        const R T = c.tension_k * (Fdot - c.m0L * udn2);                      // :476
         const R mg[3] = {0, 0, c.m0 * -c.g};
         R vel_n[3], pos_n[3];
 #pragma unroll
@@ -257,9 +268,9 @@ template <typename R> struct QuadPoleEnv {
         const R Jo[3] = {c.Ixx * om[0], c.Iyy * om[1], c.Izz * om[2]};
         const R cr[3] = {om[1] * Jo[2] - om[2] * Jo[1], om[2] * Jo[0] - om[0] * Jo[2], om[0] * Jo[1] - om[1] * Jo[0]};
         R om_n[3];
-        om_n[0] = om[0] + ((tau_x - cr[0]) / c.Ixx) * c.dt;
-        om_n[1] = om[1] + ((tau_y - cr[1]) / c.Iyy) * c.dt;
-        om_n[2] = om[2] + ((tau_z - cr[2]) / c.Izz) * c.dt;
+        om_n[0] = om[0] + M::div_(tau_x - cr[0], c.Ixx) * c.dt;
+        om_n[1] = om[1] + M::div_(tau_y - cr[1], c.Iyy) * c.dt;
+        om_n[2] = om[2] + M::div_(tau_z - cr[2], c.Izz) * c.dt;
         // q' = normalise(q + 0.5 (q (x) [0, om']) dt)   (NEW omega).  :504-506
         const R om4[4] = {0, om_n[0], om_n[1], om_n[2]};
         R qd[4], q_n[4];
@@ -267,15 +278,21 @@ template <typename R> struct QuadPoleEnv {
         R nn = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { q_n[i] = q[i] + ((R)0.5 * qd[i]) * c.dt; nn += q_n[i] * q_n[i]; }
-        nn = M::sqrt_(nn);
+        if constexpr (M::kFast) {
+            const R inv = M::inv_sqrt_(nn);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q_n[i] = q_n[i] / nn;
+            for (int i = 0; i < 4; ++i) q_n[i] = q_n[i] * inv;
+        } else {
+            nn = M::sqrt_(nn);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q_n[i] = q_n[i] / nn;
+        }
         // payload: omega_p' and q_p' = normalise(q_p + 0.5 ([0, omega_p'] (x) q_p) dt).  :511-517
         const R arm_v[3] = {c.L * ut[0], c.L * ut[1], c.L * ut[2]};
         const R frc[3] = {T * ut[0] + (R)0, T * ut[1] + (R)0, T * ut[2] + (-c.g * c.m_p)};
-        const R ompd[3] = {(arm_v[1] * frc[2] - arm_v[2] * frc[1]) / c.mpL2,
-                           (arm_v[2] * frc[0] - arm_v[0] * frc[2]) / c.mpL2,
-                           (arm_v[0] * frc[1] - arm_v[1] * frc[0]) / c.mpL2};
+        const R ompd[3] = {M::div_(arm_v[1] * frc[2] - arm_v[2] * frc[1], c.mpL2),
+                           M::div_(arm_v[2] * frc[0] - arm_v[0] * frc[2], c.mpL2),
+                           M::div_(arm_v[0] * frc[1] - arm_v[1] * frc[0], c.mpL2)};
         R omp_n[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) omp_n[i] = omp[i] + ompd[i] * c.dt;
@@ -285,9 +302,15 @@ template <typename R> struct QuadPoleEnv {
         R np_ = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { qp_n[i] = qp[i] + ((R)0.5 * qpd[i]) * c.dt; np_ += qp_n[i] * qp_n[i]; }
-        np_ = M::sqrt_(np_);
+        if constexpr (M::kFast) {
+            const R inv = M::inv_sqrt_(np_);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qp_n[i] = qp_n[i] / np_;
+            for (int i = 0; i < 4; ++i) qp_n[i] = qp_n[i] * inv;
+        } else {
+            np_ = M::sqrt_(np_);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qp_n[i] = qp_n[i] / np_;
+        }
 
 #pragma unroll
         for (int i = 0; i < 3; ++i) { o[i] = pos_n[i]; o[3 + i] = vel_n[i]; o[10 + i] = om_n[i]; o[17 + i] = omp_n[i]; }
@@ -302,12 +325,12 @@ template <typename R> struct QuadPoleEnv {
         const R c_rate = (om_n[0] * om_n[0] + om_n[1] * om_n[1]) + om_n[2] * om_n[2];
         const R c_prate = (omp_n[0] * omp_n[0] + omp_n[1] * omp_n[1]) + omp_n[2] * omp_n[2];
         R acc = (R)1;
-        acc = acc + (R)5 / ((R)1 + (R)10 * c_pos);
-        acc = acc + (R)10 / ((R)1 + (R)10 * c_vel);
-        acc = acc + (R)0.1 / ((R)1 + th_q * th_q);
-        acc = acc + (R)5 / ((R)1 + c_rate);
-        acc = acc + (R)10 / ((R)1 + (R)10 * (th_p * th_p));
-        acc = acc + (R)1 / ((R)1 + (R)10 * c_prate);
+        acc = acc + M::div_((R)5, (R)1 + (R)10 * c_pos);
+        acc = acc + M::div_((R)10, (R)1 + (R)10 * c_vel);
+        acc = acc + M::div_((R)0.1, (R)1 + th_q * th_q);
+        acc = acc + M::div_((R)5, (R)1 + c_rate);
+        acc = acc + M::div_((R)10, (R)1 + (R)10 * (th_p * th_p));
+        acc = acc + M::div_((R)1, (R)1 + (R)10 * c_prate);
         R r = c.dt * acc;
         bool oob = false;
 #pragma unroll

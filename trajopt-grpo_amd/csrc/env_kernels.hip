@@ -5,6 +5,7 @@
 #include "env_dynamics.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace tg {
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(256) void step_kernel(typename Env::C c, const R* _
 // ---------------------------------------------------------------------------
 struct Sigma { float v[8]; };
 
-template <typename Env, typename R, bool kSample>
+// kSpec: issue the state / mean loads before the alive test resolves (one memory round trip instead of
+// two on the critical path).  Used for small launches, which are latency-bound; large launches are
+// bandwidth-bound and skip the loads of ended envs instead.
+template <typename Env, typename R, bool kSample, bool kSpec>
 __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R* __restrict__ obs,
                                                            float* __restrict__ act, R* __restrict__ rew,
                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ len,
@@ -67,53 +71,74 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
                                                            const uint64_t* __restrict__ rng, int64_t env_offset) {
     constexpr int S = Env::S, A = Env::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool alive = (i < n) && (len[i] == 0);
-    // wavefront-wide termination: if all 64 envs of this wave have ended, leave before
-    // touching the trajectory (wave-uniform branch, no divergence)
-    if (__ballot(alive) == 0ull) return;
-    if (!alive) return;
-
+    const bool in_range = i < n;
+    const int64_t ic = in_range ? i : n - 1;          // clamp so every lane's addresses are valid
     const int64_t T1 = (int64_t)T + 1;
     R s[S], o[S];
+    float mu[A], a[A];
+    const int32_t my_len = len[ic];
+    if constexpr (kSpec) {
 #pragma unroll
-    for (int k = 0; k < S; ++k) s[k] = obs[(k * T1 + t) * n + i];
-    float a[A];
+        for (int k = 0; k < S; ++k) s[k] = obs[(k * T1 + t) * n + ic];
+        if constexpr (kSample) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) mu[k] = mean[ic * mean_rs + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) a[k] = act[((int64_t)k * T + t) * n + ic];
+        }
+    }
+    const bool alive = in_range && (my_len == 0);
+    // wavefront-wide termination: if all 64 envs of this wave have ended, leave before touching the
+    // trajectory again (wave-uniform branch, no divergence)
+    if (__ballot(alive) == 0ull) return;
+    if constexpr (!kSpec) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = alive ? obs[(k * T1 + t) * n + ic] : (R)0;
+        if constexpr (kSample) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) mu[k] = alive ? mean[ic * mean_rs + k] : 0.0f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < A; ++k) a[k] = alive ? act[((int64_t)k * T + t) * n + ic] : 0.0f;
+        }
+    }
     if constexpr (kSample) {
-        // a = mean + sigma * eps, eps ~ N(0, I): Box-Muller on Philox words keyed by the
-        // GLOBAL env index and t (independent of sharding / launch geometry)
+        // a = mean + sigma * eps, eps ~ N(0, I): Box-Muller on Philox words keyed by the GLOBAL env index
+        // and t (independent of sharding / launch geometry).  Hardware log / sin / cos (revolutions).
         uint32_t rnd[4];
-        Philox::draw(rng[0], (uint64_t)(env_offset + i), (uint32_t)t, (uint32_t)rng[1], rnd);
+        Philox::draw(rng[0], (uint64_t)(env_offset + ic), (uint32_t)t, (uint32_t)rng[1], rnd);
         float eps[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (2 * h < A) {
-                const float rad = sqrtf(-2.0f * logf(Philox::u01(rnd[2 * h])));
-                float sn, cs;
-                sincospif(2.0f * Philox::u01(rnd[2 * h + 1]), &sn, &cs);
-                eps[2 * h] = rad * cs;
-                eps[2 * h + 1] = rad * sn;
+                const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(Philox::u01(rnd[2 * h])));
+                const float rev = Philox::u01(rnd[2 * h + 1]);
+                eps[2 * h] = rad * __builtin_amdgcn_cosf(rev);
+                eps[2 * h + 1] = rad * __builtin_amdgcn_sinf(rev);
             }
         }
 #pragma unroll
-        for (int k = 0; k < A; ++k) {
-            a[k] = rn_add(mean[i * mean_rs + k], rn_mul(sigma.v[k], eps[k]));
-            act[((int64_t)k * T + t) * n + i] = a[k];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < A; ++k) a[k] = act[((int64_t)k * T + t) * n + i];
+        for (int k = 0; k < A; ++k) a[k] = rn_add(mu[k], rn_mul(sigma.v[k], eps[k]));
     }
 
     R r;
     const StepOut out = Env::step(s, a, c, t + 1, o, r);
-    rew[(int64_t)t * n + i] = r;
-    mask[(int64_t)t * n + i] = 1;
     // the worker also stops at t == max_steps (rollout_worker.py:51)
-    if (out.truncated || (t + 1 >= T)) {
-        len[i] = t + 1;
-    } else {
+    const bool done = out.truncated || (t + 1 >= T);
+    const bool carry = alive && !done;
+    if (in_range) {
+        // every lane of a live wave stores (zeros for ended envs, which is what the padding must hold):
+        // whole 256-B lines leave the wave, so no partial-line read-modify-write in L2 / HBM
+        if constexpr (kSample) {
 #pragma unroll
-        for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = o[k];
+            for (int k = 0; k < A; ++k) act[((int64_t)k * T + t) * n + i] = alive ? a[k] : 0.0f;
+        }
+        rew[(int64_t)t * n + i] = alive ? r : (R)0;
+        mask[(int64_t)t * n + i] = alive ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = carry ? o[k] : (R)0;
+        if (alive && done) len[i] = t + 1;
     }
 }
 
@@ -185,7 +210,8 @@ __global__ __launch_bounds__(256) void quadrotor12_kernel(const R* __restrict__ 
 // ---------------------------------------------------------------------------
 static inline dim3 env_grid(int64_t n, int& block) {
     // small launches are latency-bound: one wave per workgroup spreads them over all CUs
-    block = (n <= (int64_t)1 << 18) ? 64 : 256;
+    static const int forced = [] { const char* e = getenv("TG_STEP_BLOCK"); return e ? atoi(e) : 0; }();
+    block = forced > 0 ? forced : ((n <= (int64_t)1 << 18) ? 64 : 256);
     return dim3((unsigned)ceil_div(n, block));
 }
 
@@ -221,14 +247,18 @@ static int rollout_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t
     auto c = EnvT<R>::C::make(*p);
     Sigma sg;
     memset(&sg, 0, sizeof(sg));
+    const bool spec = tr->n <= ((int64_t)1 << 18);
+#define TG_RS(SAMPLE, SPEC)                                                                                            \
+    hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, SAMPLE, SPEC>), grid, dim3(block), 0, st, c, (R*)tr->d_obs,      \
+                       tr->d_act, (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, \
+                       env_offset)
     if (mean != nullptr) {
         for (int k = 0; k < EnvT<R>::A; ++k) sg.v[k] = sigma[k];
-        hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, true>), grid, dim3(block), 0, st, c, (R*)tr->d_obs, tr->d_act,
-                           (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, env_offset);
+        if (spec) TG_RS(true, true); else TG_RS(true, false);
     } else {
-        hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, false>), grid, dim3(block), 0, st, c, (R*)tr->d_obs, tr->d_act,
-                           (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, env_offset);
+        if (spec) TG_RS(false, true); else TG_RS(false, false);
     }
+#undef TG_RS
     TG_LAUNCH_CHECK("tg_rollout_step");
     return TG_OK;
 }
