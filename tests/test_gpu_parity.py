@@ -585,3 +585,37 @@ def test_learners_fall_back_to_autograd_for_non_relu_nets(tg, dev):
                    updates_per_iter=1, batch_size=1024)
     algo2.learn(buf)
     assert len(algo2.last_stats["total_loss"]) == -(-int(algo2.last_stats["n_valid"]) // 1024)
+
+
+# --------------------------------------------------------------------------------------------
+# published checkpoints of the reference (reports/*/001): load the reference's artefact formats and
+# reproduce the published learning-curve end points with a fresh GPU rollout
+# --------------------------------------------------------------------------------------------
+PUBLISHED = [
+    # name, env, actor-critic?, dims, published last avg_reward, reference-CPU re-evaluation (20 episodes), band
+    ("cartpole_nn_ppo", "CartPole", True, (5, 1, (128, 128, 128)), 800.79, 819.7, (650.0, 950.0)),
+    ("quadpole2d_nn_ppo", "QuadPole2D", True, (10, 2, (128, 128, 128)), 1047.64, 906.4, (750.0, 1100.0)),
+    ("cartpole_nn_grpo", "CartPole", False, (5, 1, (128, 128, 128, 128)), -62.20, -46.4, (-75.0, -30.0)),
+]
+
+
+@pytest.mark.parametrize("name,env_name,critic,dims,published,ref_eval,band", PUBLISHED)
+def test_published_checkpoints_reproduce_on_gpu(tg, dev, name, env_name, critic, dims, published, ref_eval, band):
+    import json
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "published", name)
+    meta = json.load(open(os.path.join(path, "metadata.json")))
+    assert meta["policy"]["hidden_dims"] == list(dims[2]) and meta["buffer"]["avg_reward"] == pytest.approx(published, abs=0.01)
+    cls = tg.GaussianActorCritic_NeuralNetwork if critic else tg.GaussianActor_NeuralNetwork
+    cov = [row[i] for i, row in enumerate(meta["policy"]["cov"])]
+    pol = cls(dims[0], dims[1], dims[2], cov=cov, device=dev)
+    pol.load(path)                                                       # reference `policy.pt` format
+    assert pol.metadata()["num_parameters"] == meta["policy"]["num_parameters"]
+    mk = lambda: tg.environments.ENV_CLASSES[env_name]()                 # default max_steps = 500, as published
+    mgr = tg.RolloutManager(mk, pol, num_workers=16, num_episodes_per_worker=256, seed=0)
+    buf = tg.Rollout_Buffer(mgr)
+    assert buf.load(path) == len(open(os.path.join(path, "reward.csv")).read().split())   # reward.csv resume
+    buf.sample()
+    avg = float(buf.avg_reward[-1])
+    assert band[0] < avg < band[1], f"{name}: avg return {avg:.1f}; published {published}, reference re-eval {ref_eval}"
