@@ -79,6 +79,40 @@ def cpu_baseline(T, updates, budget_workers=None, episodes=32):
             "rollout_value": steps / t_roll}
 
 
+def dynamics_kernel_probe(tg, dev, n, launches=64):
+    """The stand-alone dynamics kernel (tg_rollout_step, sampling mode) at `n` envs with nobody terminating:
+    `launches` consecutive time steps bracketed by one HIP event pair on the launch stream.  HBM roofline:
+    SURVEY 8(d) algorithmic bytes (189 B / QuadPole env-step) / time per launch (launch-to-launch, so it
+    includes the ~1.5 us kernel boundary)."""
+    import ctypes as C
+    import torch
+    N_ = tg._native
+    env = tg.QuadPole(max_steps=launches + 1)
+    env.spatial_bounds = tuple((-1e9, 1e9) for _ in env.spatial_bounds)
+    pol = tg.GaussianActor_NeuralNetwork(20, 4, (8,), cov=0.3, device=dev)
+    eng = tg.DeviceRollout(env, pol, n // 256, 256, seed=1)
+    eng._seed_host, eng._stream_host = 1, 0
+    lib, tr, st, p = N_.load(), eng.traj.native(), N_.stream_ptr(dev), C.byref(eng.params)
+    mean = torch.zeros(n, 8, device=dev)
+    best = None
+    for _ in range(3):
+        eng._enqueue_prepare(None)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for t in range(launches):
+            N_.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), 8, eng._sigma, eng.rng.data_ptr(), 0, st))
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / launches
+        best = us if best is None else min(best, us)
+    gbs = ALGO_BYTES["QuadPole"] * n / best / 1e3
+    return {"kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>", "bound": "hbm", "n_envs": n,
+            "us_per_launch": best, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+            "bytes_per_env_step": ALGO_BYTES["QuadPole"],
+            "traffic": 14334976 if n == 65536 else None,
+            "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per launch)"}
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -91,6 +125,8 @@ def main():
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="per-step launches (actor GEMMs + tg_rollout_step) instead of the fused persistent rollout kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing the multi-rank path on a single GPU (ranks share the device)")
     args = ap.parse_args()
@@ -132,7 +168,7 @@ def main():
     policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
     mk = lambda: tg.QuadPole(max_steps=T)
     mgr = tg.RolloutManager(mk, policy, num_workers=G_global, num_episodes_per_worker=E, dtype=torch.float32,
-                            seed=1234, compute_dtype=cdt, use_graph=args.graph)
+                            seed=1234, compute_dtype=cdt, use_graph=args.graph, fused=False if args.no_fused else None)
     buf = tg.Rollout_Buffer(mgr)
     algo = tg.PPO(epsilon=0.2, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4), ref_model=None,
                   updates_per_iter=args.updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,
@@ -161,6 +197,7 @@ def main():
     env_steps = 0
     t_roll = 0.0
     launches = []            # (duration ms, env-steps in that launch)
+    launch_units = []
     if not args.graph:
         mgr.engine.step_events = []
     barrier()
@@ -171,13 +208,18 @@ def main():
         t_roll += time.perf_counter() - r0
         env_steps += buf.device_traj.env_steps()
         if mgr.engine.step_events:
-            alive = buf.device_traj.mask.sum(1, dtype=torch.int64).tolist()
-            launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
+            if mgr.engine.fused:
+                launches += [(a.elapsed_time(b), buf.device_traj.env_steps()) for _, a, b in mgr.engine.step_events]
+                launch_units.append(buf.device_traj.env_steps())
+            else:
+                alive = buf.device_traj.mask.sum(1, dtype=torch.int64).tolist()
+                launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
             mgr.engine.step_events = []
         algo.learn(buf)
     barrier()
     dt = time.perf_counter() - t0
 
+    dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     tot = torch.tensor([float(env_steps), dt, t_roll], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
@@ -202,13 +244,25 @@ def main():
             "rollout_ms": 1e3 * t_roll / args.steps,
             "env_steps_per_step": total_steps / args.steps,
         }
-        if launches:
+        fused = mgr.engine.fused
+        out["rollout_path"] = "fused persistent kernel (tg_fused_rollout)" if fused else "per-step launches (GEMMs + tg_rollout_step)"
+        if launches and fused:
+            # one launch per rollout: actor MLP on the matrix cores + sampling + dynamics + recording.
+            # algorithmic flops = 2 * actor parameters per valid env-step (539 kflop for 20-256x5-4)
+            n_par = sum(p.numel() for p in policy.actor.parameters())
+            dur = sum(d for d, _ in launches) * 1e-3
+            ach = 2.0 * n_par * sum(launch_units) / dur / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                               "traffic": None, "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256>",
+                               "flops_per_env_step": 2 * n_par, "launches": len(launches),
+                               "avg_launch_ms": 1e3 * dur / len(launches),
+                               "note": "valid env-steps only (natural termination: ended envs idle their lanes); "
+                                       "all-alive figure in profiles/ and DESIGN.md"}
+        elif launches:
             dur = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in launches) * 1e-3
             units = sum(u for _, u in launches)
             full = [(d, u) for d, u in launches if u == args.envs]
             ach = ALGO_BYTES["QuadPole"] * units / dur / 1e9
-            # HBM bytes of one all-alive launch at 65,536 envs from the PMC passes committed under profiles/
-            # (r01_step_kernel_65536_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction); not re-measured live
             traffic = 14334976 if args.envs == 65536 else None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -221,6 +275,7 @@ def main():
                 d_full = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in full) * 1e-3 / len(full)
                 out["roofline"]["full_launch_us"] = 1e6 * d_full
                 out["roofline"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
+        out["dynamics_kernel"] = dyn
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

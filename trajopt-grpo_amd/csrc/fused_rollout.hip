@@ -1,0 +1,346 @@
+// Fused GPU-resident rollout: the whole T-step loop of a rollout in ONE persistent launch.
+//
+// Reference path replaced: rollout/rollout_worker.py:19-84 -- per step one policy forward
+// (policies/actor_critic.py:107-138 -> models/neural_network.py:67-77), one sample, one Env.step.
+// The unfused path (rollout.py) launches ~9 kernels per time step and streams every activation through
+// HBM; here a workgroup owns 256 environments for the whole rollout:
+//   * the env state lives in registers (one lane per env, 64 envs per wavefront) and is never re-read;
+//   * the actor MLP runs on the matrix cores in TRANSPOSED form, Y^T = W . X^T, with
+//     v_mfma_f32_32x32x16_bf16: the 32 lanes of a tile are 32 envs, so an env's activations never leave
+//     its wave, and a layer's accumulator tile IS the next layer's B operand (bias-init, ReLU, bf16
+//     pack -- no LDS transpose; the k-order permutation this implies is folded into the weight stream);
+//   * the weights (bf16, pre-arranged on the host in MFMA A-fragment order, 1 KiB per wave-instruction)
+//     stream L2 -> LDS once per workgroup per step and are shared by its 4 waves (and 2 env tiles each);
+//   * sampling (Philox keyed by global env index and t, identical to rollout_step_kernel), dynamics,
+//     trajectory recording and episode termination follow in the same launch; a wave whose 64 envs have
+//     all ended skips its MFMA work, a workgroup whose envs have all ended leaves the time loop.
+// HBM traffic per env-step is the trajectory record only (S*4 + A*4 + 4 + 1 B written, nothing read).
+#include "env_dynamics.hpp"
+
+#include <string.h>
+
+namespace tg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SigmaF { float v[8]; };
+
+constexpr int kRing = 2;          // LDS slots (each one weight block = H/16 KiB)
+
+// One weight block = the A fragments of one 32-row output tile for all k-steps (hidden layers and head),
+// or of all MT output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB.  The block
+// stream is the same every time step (L2-resident, n_blocks even) and is software-pipelined through two
+// register sets: block b+3 is requested from L2 while block b is being multiplied, block b+1 is parked in
+// the other LDS slot.  One barrier per block.
+// (plain named uint4 registers: an array-of-struct staging object ends up in scratch memory)
+#define TG_STG_LOAD(S, g)                                                            \
+    do {                                                                             \
+        const uint4* g__ = (g);                                                      \
+        S##0 = g__[threadIdx.x];                                                     \
+        S##1 = g__[256 + threadIdx.x];                                               \
+        if constexpr (KS / 4 > 2) { S##2 = g__[512 + threadIdx.x]; S##3 = g__[768 + threadIdx.x]; } \
+    } while (0)
+#define TG_STG_STORE(S, slot)                                                        \
+    do {                                                                             \
+        uint4* s__ = (slot);                                                         \
+        s__[threadIdx.x] = S##0;                                                     \
+        s__[256 + threadIdx.x] = S##1;                                               \
+        if constexpr (KS / 4 > 2) { s__[512 + threadIdx.x] = S##2; s__[768 + threadIdx.x] = S##3; } \
+    } while (0)
+
+// consume an even block (slot 0): publish the odd block parked in set B to slot 1, request block +3 into B;
+// consume an odd block (slot 1): the same with set A / slot 0.
+#define TG_STAGE_ADVANCE_EVEN                                                        \
+    __syncthreads();                                                                 \
+    TG_STG_STORE(sb, ring + KS * 64);                                                \
+    TG_STG_LOAD(sb, wfrag + (int64_t)pre * KS * 64);                                 \
+    pre = (pre + 1 == n_blocks) ? 0 : pre + 1;                                       \
+    const uint4* cur = ring;
+#define TG_STAGE_ADVANCE_ODD                                                         \
+    __syncthreads();                                                                 \
+    TG_STG_STORE(sa, ring);                                                          \
+    TG_STG_LOAD(sa, wfrag + (int64_t)pre * KS * 64);                                 \
+    pre = (pre + 1 == n_blocks) ? 0 : pre + 1;                                       \
+    const uint4* cur = ring + KS * 64;
+
+template <typename Env, int H>
+__global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
+    typename Env::C c, float* __restrict__ obs, float* __restrict__ act, float* __restrict__ rew,
+    uint8_t* __restrict__ mask, int32_t* __restrict__ len, int64_t n, int32_t T, int32_t t0, int32_t t1,
+    const uint4* __restrict__ wfrag, const float* __restrict__ bias, int32_t n_hh, SigmaF sigma,
+    const uint64_t* __restrict__ rng, int64_t env_offset) {
+    constexpr int S = Env::S, A = Env::A, MT = H / 32, KS = H / 16;
+    static_assert(S <= 32 && A <= 4, "state must fit one padded 32-feature tile; actions the first 4 head rows");
+    extern __shared__ uint4 lds[];
+    uint4* ring = lds;                                                  // kRing * KS * 64 uint4
+    float* bias_s = reinterpret_cast<float*>(lds + kRing * KS * 64);    // (n_hh + 2) * H floats
+    unsigned short* xs = reinterpret_cast<unsigned short*>(bias_s + (n_hh + 2) * H);   // 4 waves * 64 envs * 32 bf16
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = i < n;
+    const int64_t ic = in_range ? i : n - 1;
+    const int64_t T1 = (int64_t)T + 1;
+
+    for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 256) bias_s[q] = bias[q];
+
+    float s[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = obs[(k * T1 + t0) * n + ic];
+    bool alive = in_range && (len[ic] == 0);
+    unsigned short* my_x = xs + (wave * 64 + lane) * 32;
+    // zero the padding features once (columns S..31 never change)
+#pragma unroll
+    for (int k = S; k < 32; ++k) my_x[k] = 0;
+    const int n_blocks = n_hh * MT + 2;               // even (MT is even): block parity is static per code site
+    static_assert(KS / 4 == 2 || KS / 4 == 4, "staging macros cover 2 or 4 uint4 per thread and block");
+    uint4 sa0, sa1, sa2 = {}, sa3 = {}, sb0, sb1, sb2 = {}, sb3 = {};   // staging sets: even / odd blocks
+    TG_STG_LOAD(sa, wfrag);                           // block 0 -> slot 0 now; blocks 1, 2 in flight
+    TG_STG_STORE(sa, ring);
+    TG_STG_LOAD(sb, wfrag + (int64_t)1 * KS * 64);
+    TG_STG_LOAD(sa, wfrag + (int64_t)(2 % n_blocks) * KS * 64);
+    int pre = 3 % n_blocks;                           // next stream position to request
+    __syncthreads();
+
+    for (int32_t t = t0; t < t1; ++t) {
+        if (!__syncthreads_or(alive ? 1 : 0)) break;          // every env of this workgroup has ended
+        const bool wave_alive = __ballot(alive) != 0ull;
+
+        // ---- layer-1 input: this wave's 64 states as bf16 rows in LDS, read back in B-fragment order ----
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const __bf16 b = (__bf16)s[k];
+            my_x[k] = __builtin_bit_cast(unsigned short, b);
+        }
+        bf16x8 xin[2][KS], xout[2][KS];
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            const unsigned short* row = xs + (wave * 64 + tile * 32 + col) * 32;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // element j of lane half h is feature 16*ks + 8*(j>>2) + 4*h + (j&3)
+                const uint2 lo = *reinterpret_cast<const uint2*>(row + 16 * ks + 4 * h);
+                const uint2 hi = *reinterpret_cast<const uint2*>(row + 16 * ks + 8 + 4 * h);
+                const uint4 v = {lo.x, lo.y, hi.x, hi.y};
+                xin[tile][ks] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+
+        // ---- layer 1: [H x 32] . [32 x 64 envs]; one block holds all MT output tiles (2 k-steps each) ----
+        {
+            TG_STAGE_ADVANCE_EVEN
+            if (wave_alive) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int tile = 0; tile < 2; ++tile) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + 32 * mt + 8 * q + 4 * h);
+                            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[tile][ks], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int sh = 0; sh < 2; ++sh) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(acc[8 * sh + j], 0.0f);
+                            xout[tile][2 * mt + sh] = o;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xin[tile][ks] = xout[tile][ks];
+        }
+        // ---- hidden H x H layers: blocks alternate odd (slot 1) / even (slot 0) ----
+        for (int l = 0; l < n_hh; ++l) {
+            const float* bl = bias_s + (l + 1) * H;
+            auto tile_gemm = [&](const uint4* __restrict__ cur, const int mt) {
+                if (wave_alive) {
+#pragma unroll
+                    for (int tile = 0; tile < 2; ++tile) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * mt + 8 * q + 4 * h);
+                            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[tile][ks], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int sh = 0; sh < 2; ++sh) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(acc[8 * sh + j], 0.0f);
+                            xout[tile][2 * mt + sh] = o;
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int mp = 0; mp < MT / 2; ++mp) {
+                {
+                    TG_STAGE_ADVANCE_ODD
+                    tile_gemm(cur, 2 * mp);
+                }
+                {
+                    TG_STAGE_ADVANCE_EVEN
+                    tile_gemm(cur, 2 * mp + 1);
+                }
+            }
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xin[tile][ks] = xout[tile][ks];
+        }
+        // ---- head: 32 padded output rows (the first A are the action means), no activation ----
+        float mu[A];
+        {
+            TG_STAGE_ADVANCE_ODD
+            const float* bl = bias_s + (n_hh + 1) * H;
+            f32x16 acc2[2];
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bl + 8 * q + 4 * h);
+                    acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+                }
+                if (wave_alive) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[tile][ks], acc, 0, 0, 0);
+                    }
+                }
+                acc2[tile] = acc;
+            }
+            // rows 0..3 of the head tile sit in registers 0..3 of the h == 0 lanes; env (32*tile + col) is lane
+            // 32*tile + col, so tile 1's means cross from lane col to lane col + 32
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const float other = __shfl(acc2[1][k], col, 64);
+                mu[k] = (lane < 32) ? acc2[0][k] : other;
+            }
+        }
+
+        // ---- sample, step, record (same arithmetic and RNG keys as rollout_step_kernel) ----
+        float a[A];
+        {
+            uint32_t rnd[4];
+            Philox::draw(rng[0], (uint64_t)(env_offset + ic), (uint32_t)t, (uint32_t)rng[1], rnd);
+            float eps[4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (2 * hh < A) {
+                    const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(Philox::u01(rnd[2 * hh])));
+                    const float rev = Philox::u01(rnd[2 * hh + 1]);
+                    eps[2 * hh] = rad * __builtin_amdgcn_cosf(rev);
+                    eps[2 * hh + 1] = rad * __builtin_amdgcn_sinf(rev);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < A; ++k) a[k] = rn_add(mu[k], rn_mul(sigma.v[k], eps[k]));
+        }
+        float o[S], r;
+        const StepOut out = Env::step(s, a, c, t + 1, o, r);
+        const bool done = out.truncated || (t + 1 >= T);
+        const bool carry = alive && !done;
+        if (in_range) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) act[((int64_t)k * T + t) * n + i] = alive ? a[k] : 0.0f;
+            rew[(int64_t)t * n + i] = alive ? r : 0.0f;
+            mask[(int64_t)t * n + i] = alive ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = carry ? o[k] : 0.0f;
+            if (alive && done) len[i] = t + 1;
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = carry ? o[k] : 0.0f;
+        alive = carry;
+    }
+}
+
+template <template <typename> class EnvT, int H>
+static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* wfrag, const float* bias, int n_hh,
+                        const float* sigma, const uint64_t* rng, int64_t env_offset, int t0, int t1, hipStream_t st) {
+    using Env = EnvT<float>;
+    constexpr int KS = H / 16;
+    auto c = Env::C::make(*p);
+    SigmaF sg;
+    memset(&sg, 0, sizeof(sg));
+    for (int k = 0; k < Env::A; ++k) sg.v[k] = sigma[k];
+    const size_t shmem = (size_t)kRing * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + 4 * 64 * 32 * 2;
+    auto kern = fused_rollout_kernel<Env, H>;
+    if (shmem > 160 * 1024) return set_error(TG_ERR_ARG, "tg_fused_rollout: %zu B of LDS needed (> 160 KiB)", shmem);
+    static size_t attr_bytes = 0;
+    if (shmem > 64 * 1024 && shmem > attr_bytes) {
+        // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            int dev = 0, maxb = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&maxb, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+            return set_error(TG_ERR_HIP, "tg_fused_rollout: cannot reserve %zu B of LDS (%s; device max per block %d)", shmem,
+                             hipGetErrorString(e), maxb);
+        }
+        attr_bytes = shmem;
+    }
+    const dim3 grid((unsigned)ceil_div(tr->n, 256));
+    hipLaunchKernelGGL(kern, grid, dim3(256), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
+                       tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset);
+    TG_LAUNCH_CHECK("tg_fused_rollout");
+    return TG_OK;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wfrag, const float* d_bias, int32_t hidden,
+                     int32_t n_hidden_layers, const float* sigma, const uint64_t* d_rng, int64_t env_offset, int32_t t_begin,
+                     int32_t t_end, void* stream) {
+    TG_REQUIRE(p && tr && d_wfrag && d_bias && sigma && d_rng, "tg_fused_rollout: null pointer");
+    TG_REQUIRE(tr->d_obs && tr->d_act && tr->d_rew && tr->d_mask && tr->d_len, "tg_fused_rollout: null trajectory pointer");
+    TG_REQUIRE(tr->dtype == TG_F32, "tg_fused_rollout: float32 trajectories only");
+    TG_REQUIRE(tr->n > 0 && tr->horizon == p->max_steps, "tg_fused_rollout: horizon %d != env.max_steps %d", tr->horizon,
+               p->max_steps);
+    TG_REQUIRE(0 <= t_begin && t_begin <= t_end && t_end <= tr->horizon, "tg_fused_rollout: bad step range [%d, %d)", t_begin,
+               t_end);
+    TG_REQUIRE(n_hidden_layers >= 1 && n_hidden_layers <= 16, "tg_fused_rollout: %d hidden layers unsupported", n_hidden_layers);
+    if (t_begin == t_end) return TG_OK;
+    const int n_hh = n_hidden_layers - 1;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(E, HH) fused_launch<E, HH>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st)
+    switch (p->env_id * 1000 + hidden) {
+        case TG_ENV_CARTPOLE * 1000 + 128: return CALL(CartPoleEnv, 128);
+        case TG_ENV_CARTPOLE * 1000 + 256: return CALL(CartPoleEnv, 256);
+        case TG_ENV_QUADPOLE2D * 1000 + 128: return CALL(QuadPole2DEnv, 128);
+        case TG_ENV_QUADPOLE2D * 1000 + 256: return CALL(QuadPole2DEnv, 256);
+        case TG_ENV_QUADPOLE * 1000 + 128: return CALL(QuadPoleEnv, 128);
+        case TG_ENV_QUADPOLE * 1000 + 256: return CALL(QuadPoleEnv, 256);
+        default:
+            return set_error(TG_ERR_UNSUPPORTED, "tg_fused_rollout: env %d with hidden width %d is not instantiated "
+                             "(widths 128 and 256)", p->env_id, hidden);
+    }
+#undef CALL
+}
+
+}  // extern "C"

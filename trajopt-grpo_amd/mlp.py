@@ -138,3 +138,47 @@ class GemmMLP:
             if i > 0:
                 da = da @ self.w[i]
         self._acts = None
+
+
+# ---------------------------------------------------------------------------------------------
+# weight stream of the fused rollout kernel (csrc/fused_rollout.hip)
+# ---------------------------------------------------------------------------------------------
+def fused_rollout_supported(net, obs_dim: int, act_dim: int) -> int:
+    """Hidden width H if `net` is Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {128,256}, else 0."""
+    if not supports(net) or obs_dim > 32 or act_dim > 4:
+        return 0
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
+    if H not in (128, 256) or any(l.out_features != H for l in lin[:-1]) or any(l.in_features != H for l in lin[1:]):
+        return 0
+    return H
+
+
+def _fragment_index(k_pad: int, device):
+    """[k_pad/16][64 lanes][8]: column of W that element j of lane (r, h) holds at k-step ks:
+    16*ks + 8*(j>>2) + 4*h + (j&3)  (the order in which an MFMA accumulator tile hands its rows over)."""
+    ks = torch.arange(k_pad // 16, device=device).view(-1, 1, 1)
+    lane = torch.arange(64, device=device).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    return 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+
+
+def fragment_stream(net, H: int):
+    """(bf16 weight stream, f32 bias table) in the layout tg_fused_rollout consumes."""
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    dev = lin[0].weight.device
+    row = (torch.arange(64, device=dev) & 31).view(1, -1, 1)
+    blocks = []
+    with torch.no_grad():
+        for li, l in enumerate(lin):
+            m_pad = _round_up(l.out_features, 32)
+            k_pad = _round_up(l.in_features, 32)
+            wp = torch.zeros(m_pad, k_pad, dtype=torch.bfloat16, device=dev)
+            wp[:l.out_features, :l.in_features].copy_(l.weight)
+            kidx = _fragment_index(k_pad, dev)                               # [KSl][64][8]
+            for mo in range(m_pad // 32):
+                blocks.append(wp[(32 * mo + row).expand_as(kidx), kidx].reshape(-1))   # [KSl*64*8]
+        bias = torch.zeros(len(lin), H, dtype=torch.float32, device=dev)
+        for li, l in enumerate(lin):
+            bias[li, :l.out_features].copy_(l.bias)
+    return torch.cat(blocks).contiguous(), bias.contiguous()

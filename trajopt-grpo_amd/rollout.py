@@ -78,7 +78,7 @@ class DeviceRollout:
 
     def __init__(self, env, policy, num_groups: int, episodes_per_group: int, restart: bool = False,
                  dtype=torch.float32, device=None, seed: int = 0, group_offset: int = 0,
-                 compute_dtype: Optional[torch.dtype] = None, use_graph: bool = False):
+                 compute_dtype: Optional[torch.dtype] = None, use_graph: bool = False, fused: Optional[bool] = None):
         self.lib = N.load()
         self.env, self.policy = env, policy
         self.G, self.E = int(num_groups), int(episodes_per_group)
@@ -107,6 +107,15 @@ class DeviceRollout:
                           for l in self._linears]
         self.use_graph = use_graph
         self._graph = None
+        # fused persistent rollout kernel (csrc/fused_rollout.hip): whole T-step loop in one launch, actor MLP on
+        # the matrix cores.  Auto-selected for bf16 policies whose shape it supports; `fused=True` insists.
+        H = M.fused_rollout_supported(policy.actor, self.S, self.A)
+        can_fuse = bool(H) and dtype == torch.float32 and compute_dtype == torch.bfloat16
+        if fused and not can_fuse:
+            raise ValueError("fused rollout needs a float32 trajectory, compute_dtype=bfloat16 and an actor "
+                             "Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {128,256}, S<=32, A<=4")
+        self.fused = can_fuse if fused is None else bool(fused)
+        self._fused_H = H
         # when set to a list, every tg_rollout_step launch is bracketed by HIP events on the launch
         # stream (bench.py reads them back for the dynamics kernel's roofline)
         self.step_events = None
@@ -157,7 +166,11 @@ class DeviceRollout:
         if not hasattr(self, "_stream_host"):
             self._seed_host, self._stream_host = int(self.rng[0].item()), 0
         sample = forced_actions is None
-        if self.use_graph and sample and initial_states is None:
+        if self.fused and sample:
+            with torch.cuda.device(self.device):
+                self._enqueue_prepare(initial_states)
+                self._enqueue_fused(0, self.T)
+        elif self.use_graph and sample and initial_states is None:
             self._run_graph()
         else:
             with torch.cuda.device(self.device):
@@ -180,6 +193,24 @@ class DeviceRollout:
         else:
             init = torch.as_tensor(np.asarray(initial_states), dtype=self.dtype).reshape(self.n, self.S)
             self.traj.obs[:, 0, :].copy_(init.t().to(self.device))
+
+    def _enqueue_fused(self, t_begin: int, t_end: int):
+        """All steps [t_begin, t_end) in one persistent launch (tg_fused_rollout)."""
+        lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
+        self._wfrag, self._bias_tab = M.fragment_stream(self.policy.actor, self._fused_H)   # weights change every learn()
+        n_hidden = len(self._linears) - 1
+        ev = None
+        if self.step_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(lib.tg_fused_rollout(C.byref(self.params), C.byref(tr), self._wfrag.data_ptr(), self._bias_tab.data_ptr(),
+                                     self._fused_H, n_hidden, self._sigma, self.rng.data_ptr(),
+                                     self.group_offset * self.E, t_begin, t_end, st), "tg_fused_rollout")
+        if ev is not None:
+            ev[1].record()
+            self.step_events.append((None, ev[0], ev[1]))
+        N.check(lib.tg_rollout_finish(C.byref(tr), st), "tg_rollout_finish")
+        N.check(lib.tg_rng_advance(self.rng.data_ptr(), st), "tg_rng_advance")
 
     def _enqueue_steps(self, sample: bool):
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
@@ -267,7 +298,8 @@ class RolloutManager:
 
     def __init__(self, env_fn, policy, worker_class=RolloutWorker, restart=False, num_workers: int = 4,
                  num_episodes_per_worker: int = 5, use_multiprocessing: bool = True, *, dtype=torch.float32,
-                 device=None, seed: int = 0, compute_dtype=None, use_graph: bool = False, process_group=None):
+                 device=None, seed: int = 0, compute_dtype=None, use_graph: bool = False, process_group=None,
+                 fused=None):
         self.env_fn, self.worker_class, self.policy = env_fn, worker_class, policy
         self.restart = restart
         self.num_workers = num_workers
@@ -282,7 +314,8 @@ class RolloutManager:
         self.group_lo, self.group_hi = D.shard_groups(num_workers, self.rank, self.world_size)
         self.local_groups = self.group_hi - self.group_lo
         self.episodes_completed = [0 for _ in range(num_workers)]
-        self._engine_kw = dict(dtype=dtype, device=device, seed=seed, compute_dtype=compute_dtype, use_graph=use_graph)
+        self._engine_kw = dict(dtype=dtype, device=device, seed=seed, compute_dtype=compute_dtype, use_graph=use_graph,
+                               fused=fused)
         self._engine = None
 
     @property
