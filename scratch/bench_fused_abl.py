@@ -1,5 +1,5 @@
 import sys, time, os, shutil, torch
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import trajopt_grpo_amd as tg
 N_ = tg._native
 lib = os.environ.get('ABL')

@@ -17,6 +17,7 @@
 // HBM traffic per env-step is the trajectory record only (S*4 + A*4 + 4 + 1 B written, nothing read).
 #include "env_dynamics.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace tg {
@@ -64,8 +65,12 @@ constexpr int kRing = 2;          // LDS slots (each one weight block = H/16 KiB
     pre = (pre + 1 == n_blocks) ? 0 : pre + 1;                                       \
     const uint4* cur = ring + KS * 64;
 
-template <typename Env, int H>
-__global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
+// NT = env tiles (of 32) per wave.  NT = 2: 64 envs per wave, one lane per env, one wave per SIMD (the X
+// fragments of two tiles fill the register file).  NT = 1: 32 envs per wave (lanes 32..63 only carry the upper
+// k-halves of the MFMA operands), half the registers, two workgroups per CU: finer termination granularity
+// (a wave stops doing MFMA work when its 32 envs have ended) and more workgroups for small env counts.
+template <typename Env, int H, int NT>
+__global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
     typename Env::C c, float* __restrict__ obs, float* __restrict__ act, float* __restrict__ rew,
     uint8_t* __restrict__ mask, int32_t* __restrict__ len, int64_t n, int32_t T, int32_t t0, int32_t t1,
     const uint4* __restrict__ wfrag, const float* __restrict__ bias, int32_t n_hh, SigmaF sigma,
@@ -79,9 +84,11 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = i < n;
-    const int64_t ic = in_range ? i : n - 1;
+    // NT = 2: lane == env.  NT = 1: lanes 0..31 own the wave's 32 envs, lanes 32..63 shadow them (never recorded).
+    const int64_t i = (NT == 2) ? (int64_t)blockIdx.x * 256 + threadIdx.x
+                                : (int64_t)blockIdx.x * 128 + wave * 32 + col;
+    const bool in_range = (i < n) && (NT == 2 || h == 0);
+    const int64_t ic = (i < n) ? i : n - 1;
     const int64_t T1 = (int64_t)T + 1;
 
     for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 256) bias_s[q] = bias[q];
@@ -114,9 +121,9 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
             const __bf16 b = (__bf16)s[k];
             my_x[k] = __builtin_bit_cast(unsigned short, b);
         }
-        bf16x8 xin[2][KS], xout[2][KS];
+        bf16x8 xin[NT][KS], xout[NT][KS];
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
+        for (int tile = 0; tile < NT; ++tile) {
             const unsigned short* row = xs + (wave * 64 + tile * 32 + col) * 32;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                    for (int tile = 0; tile < 2; ++tile) {
+                    for (int tile = 0; tile < NT; ++tile) {
                         f32x16 acc;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -151,14 +158,14 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
                         for (int sh = 0; sh < 2; ++sh) {
                             bf16x8 o;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(acc[8 * sh + j], 0.0f);
+                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
                             xout[tile][2 * mt + sh] = o;
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile)
+            for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xin[tile][ks] = xout[tile][ks];
         }
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
             auto tile_gemm = [&](const uint4* __restrict__ cur, const int mt) {
                 if (wave_alive) {
 #pragma unroll
-                    for (int tile = 0; tile < 2; ++tile) {
+                    for (int tile = 0; tile < NT; ++tile) {
                         f32x16 acc;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
                         for (int sh = 0; sh < 2; ++sh) {
                             bf16x8 o;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaxf(acc[8 * sh + j], 0.0f);
+                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
                             xout[tile][2 * mt + sh] = o;
                         }
                     }
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
                 }
             }
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile)
+            for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xin[tile][ks] = xout[tile][ks];
         }
@@ -211,9 +218,9 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
         {
             TG_STAGE_ADVANCE_ODD
             const float* bl = bias_s + (n_hh + 1) * H;
-            f32x16 acc2[2];
+            f32x16 acc2[NT];
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile) {
+            for (int tile = 0; tile < NT; ++tile) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -233,8 +240,12 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
             // 32*tile + col, so tile 1's means cross from lane col to lane col + 32
 #pragma unroll
             for (int k = 0; k < A; ++k) {
-                const float other = __shfl(acc2[1][k], col, 64);
-                mu[k] = (lane < 32) ? acc2[0][k] : other;
+                if constexpr (NT == 2) {
+                    const float other = __shfl(acc2[1][k], col, 64);
+                    mu[k] = (lane < 32) ? acc2[0][k] : other;
+                } else {
+                    mu[k] = acc2[0][k];            // lanes 0..31; the shadow lanes' values are never recorded
+                }
             }
         }
 
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void fused_rollout_kernel(
     }
 }
 
-template <template <typename> class EnvT, int H>
+template <template <typename> class EnvT, int H, int NT>
 static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* wfrag, const float* bias, int n_hh,
                         const float* sigma, const uint64_t* rng, int64_t env_offset, int t0, int t1, hipStream_t st) {
     using Env = EnvT<float>;
@@ -285,7 +296,7 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
     memset(&sg, 0, sizeof(sg));
     for (int k = 0; k < Env::A; ++k) sg.v[k] = sigma[k];
     const size_t shmem = (size_t)kRing * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + 4 * 64 * 32 * 2;
-    auto kern = fused_rollout_kernel<Env, H>;
+    auto kern = fused_rollout_kernel<Env, H, NT>;
     if (shmem > 160 * 1024) return set_error(TG_ERR_ARG, "tg_fused_rollout: %zu B of LDS needed (> 160 KiB)", shmem);
     static size_t attr_bytes = 0;
     if (shmem > 64 * 1024 && shmem > attr_bytes) {
@@ -301,7 +312,7 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
         }
         attr_bytes = shmem;
     }
-    const dim3 grid((unsigned)ceil_div(tr->n, 256));
+    const dim3 grid((unsigned)ceil_div(tr->n, 128 * NT));
     hipLaunchKernelGGL(kern, grid, dim3(256), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
                        tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset);
     TG_LAUNCH_CHECK("tg_fused_rollout");
@@ -328,7 +339,13 @@ int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wf
     if (t_begin == t_end) return TG_OK;
     const int n_hh = n_hidden_layers - 1;
     hipStream_t st = (hipStream_t)stream;
-#define CALL(E, HH) fused_launch<E, HH>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st)
+    // tiles per wave: 1 (32-env waves, two workgroups per CU) measured faster whenever episodes end early and for
+    // small env counts; 2 (64-env waves) marginally faster when every env runs the full horizon.  TG_FUSED_NT overrides.
+    static const int nt_env = [] { const char* e = getenv("TG_FUSED_NT"); return e ? atoi(e) : 0; }();
+    const int nt = nt_env == 1 || nt_env == 2 ? nt_env : 1;
+#define CALL(E, HH)                                                                                                   \
+    (nt == 1 ? fused_launch<E, HH, 1>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st)      \
+             : fused_launch<E, HH, 2>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st))
     switch (p->env_id * 1000 + hidden) {
         case TG_ENV_CARTPOLE * 1000 + 128: return CALL(CartPoleEnv, 128);
         case TG_ENV_CARTPOLE * 1000 + 256: return CALL(CartPoleEnv, 256);
