@@ -220,6 +220,24 @@ def main():
     dt = time.perf_counter() - t0
 
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
+    fused_all_alive = None
+    if rank == 0 and mgr.engine.fused:
+        # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
+        env_open = tg.QuadPole(max_steps=T)
+        env_open.spatial_bounds = tuple((-1e9, 1e9) for _ in env_open.spatial_bounds)
+        eng = tg.DeviceRollout(env_open, policy, G_local, E, seed=7, compute_dtype=cdt, fused=True)
+        eng.run()
+        eng.step_events = []
+        eng.run()
+        torch.cuda.synchronize()
+        _, a, b = eng.step_events[0]
+        ms = a.elapsed_time(b)
+        n_par = sum(p.numel() for p in policy.actor.parameters())
+        fused_all_alive = {"ms_per_rollout": ms, "env_steps": eng.traj.env_steps(),
+                           "env_steps_per_s": eng.traj.env_steps() / ms * 1e3,
+                           "achieved_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9,
+                           "frac_of_2500_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9 / 2500.0}
+        del eng
     tot = torch.tensor([float(env_steps), dt, t_roll], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
@@ -256,8 +274,8 @@ def main():
                                "traffic": None, "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256>",
                                "flops_per_env_step": 2 * n_par, "launches": len(launches),
                                "avg_launch_ms": 1e3 * dur / len(launches),
-                               "note": "valid env-steps only (natural termination: ended envs idle their lanes); "
-                                       "all-alive figure in profiles/ and DESIGN.md"}
+                               "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
+                               "all_alive": fused_all_alive}
         elif launches:
             dur = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in launches) * 1e-3
             units = sum(u for _, u in launches)

@@ -48,6 +48,10 @@ enum { TG_F32 = 0, TG_F64 = 1 };
  *                                         p9 bound
  *  QUADROTOR12(quadrotor_env.py:9-16):   p0 mass, p1 arm_length, p2 Ixx, p3 Iyy, p4 Izz,
  *                                         p5 torque_constant, p6 gravity
+ * agents: rollout kernels only.  With agents = k > 1, every k consecutive env slots form ONE environment of k
+ *  bodies that share the policy and terminate together: when any body truncates, all k stop at that step
+ *  (segmented wavefront ballot).  The reference's QuadrotorSwarm is an empty subclass (quadrotor_env.py:185-186),
+ *  so this semantics is defined by this build and has no oracle beyond k = 1 == the plain env.
  * time_trunc_step: CartPole only -- first step count at which the reference's
  *  float-accumulated `_time > max_time` fires (cartpole_env.py:168); filled by
  *  tg_env_default_params / tg_env_finalize_params. */
@@ -55,7 +59,7 @@ typedef struct tg_env_params {
     int32_t env_id;
     int32_t max_steps;
     int32_t time_trunc_step;
-    int32_t reserved;
+    int32_t agents;          /* swarm: agents per env (power of two <= 64), 0/1 = single-body env */
     double  timestep;
     double  p[12];
 } tg_env_params;

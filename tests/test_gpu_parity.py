@@ -677,3 +677,57 @@ def test_fused_rollout_auto_selection_and_manager(tg, dev):
     b = mgr.rollout()                      # second rollout: new Philox stream id, new initial states
     assert a[0].shape == (2, 128, 24, 20) and not torch.equal(a[1], b[1])
     assert torch.equal(a[4].sum(2), a[3])
+
+
+# --------------------------------------------------------------------------------------------
+# swarm (BASELINE config 5; build-defined semantics, no reference oracle beyond n_agents = 1)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True])
+def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused):
+    T, G, Eps, K = 48, 2, 16, 8
+    torch.manual_seed(8)
+    pol = tg.GaussianActor_NeuralNetwork(20, 4, (128, 128), cov=0.3, device=dev)
+    kw = dict(seed=5, compute_dtype=torch.bfloat16, fused=fused)
+    swarm = tg.DeviceRollout(tg.QuadPoleSwarm(n_agents=K, max_steps=T), pol, G, Eps, **kw).run()
+    s_len, s_act, s_obs = swarm.len.clone(), swarm.act.clone(), swarm.obs.clone()
+    assert swarm.n == G * Eps * K and swarm.E == Eps * K
+    # the same env slots stepped as independent QuadPole bodies: same Philox keys, same initial states
+    indep = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps * K, **kw).run()
+    assert torch.equal(indep.obs[:, 0, :], s_obs[:, 0, :])
+    # every body of an env stops with the env, at the first step any of its bodies would have stopped alone
+    per_env = s_len.view(-1, K)
+    assert torch.equal(per_env, per_env[:, :1].expand_as(per_env))
+    assert torch.equal(per_env[:, 0], indep.len.view(-1, K).min(dim=1).values)
+    # until then the bodies evolve exactly as the independent ones
+    t_keep = (torch.arange(T, device=dev)[:, None] < s_len[None, :])
+    assert torch.equal(s_act[:, t_keep], indep.act[:, t_keep])
+    assert (per_env[:, 0] < T).any() and (per_env[:, 0] > 1).all()
+    # n_agents = 1 is the plain env, bit for bit
+    one = tg.DeviceRollout(tg.QuadPoleSwarm(n_agents=1, max_steps=T), pol, G, Eps * K, **kw).run()
+    for a, b in ((one.obs, indep.obs), (one.act, indep.act), (one.rew, indep.rew), (one.len, indep.len)):
+        assert torch.equal(a, b)
+
+
+def test_grpo_on_a_swarm_buffer_uses_group_statistics_across_bodies(tg, dev):
+    T, G, Eps, K = 32, 4, 8, 8
+    torch.manual_seed(9)
+    pol = tg.GaussianActor_NeuralNetwork(20, 4, (128, 128), cov=0.3, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.QuadPoleSwarm(n_agents=K, max_steps=T), pol, restart=True, num_workers=G,
+                            num_episodes_per_worker=Eps, compute_dtype=torch.bfloat16, seed=2)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    assert buf.group_observations.shape == (G, Eps * K, T, 20)
+    tr = buf.device_traj
+    rtg = tg.hip_ops.rtg_scan(tr.rew, tr.mask, 0.9)
+    adv = tg.hip_ops.group_normalize(rtg, tr.mask, tg.hip_ops.masked_moments(rtg, tr.mask, tr.E), 0, tr.E)
+    a = adv.t().reshape(G, -1)
+    m = tr.mask.t().reshape(G, -1).bool()
+    for g in range(G):                      # one mean / std per group, across all bodies of its episodes
+        v = a[g][m[g]]
+        assert abs(float(v.mean())) < 1e-4 and abs(float(v.std()) - 1) < 1e-3
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.9, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4),
+                   updates_per_iter=1, autocast_dtype=torch.bfloat16)
+    before = [p.detach().clone() for p in pol.parameters()]
+    algo.learn(buf)
+    assert np.isfinite(algo.last_stats["J"]).all()
+    assert any(not torch.equal(x, y) for x, y in zip(before, pol.parameters()))

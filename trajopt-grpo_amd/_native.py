@@ -27,7 +27,7 @@ class NativeLibraryError(RuntimeError):
 
 class EnvParams(C.Structure):
     _fields_ = [("env_id", C.c_int32), ("max_steps", C.c_int32), ("time_trunc_step", C.c_int32),
-                ("reserved", C.c_int32), ("timestep", C.c_double), ("p", C.c_double * 12)]
+                ("agents", C.c_int32), ("timestep", C.c_double), ("p", C.c_double * 12)]
 
 
 class Traj(C.Structure):

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ len,
                                                            int64_t n, int32_t T, int32_t t,
                                                            const float* __restrict__ mean, int64_t mean_rs, Sigma sigma,
-                                                           const uint64_t* __restrict__ rng, int64_t env_offset) {
+                                                           const uint64_t* __restrict__ rng, int64_t env_offset,
+                                                           int32_t agents) {
     constexpr int S = Env::S, A = Env::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < n;
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
 
     R r;
     const StepOut out = Env::step(s, a, c, t + 1, o, r);
-    // the worker also stops at t == max_steps (rollout_worker.py:51)
-    const bool done = out.truncated || (t + 1 >= T);
+    // the worker also stops at t == max_steps (rollout_worker.py:51); a swarm stops when any of its bodies does
+    const bool done = any_in_segment(alive && out.truncated, agents) || (t + 1 >= T);
     const bool carry = alive && !done;
     if (in_range) {
         // every lane of a live wave stores (zeros for ended envs, which is what the padding must hold):
@@ -251,7 +252,7 @@ static int rollout_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t
 #define TG_RS(SAMPLE, SPEC)                                                                                            \
     hipLaunchKernelGGL((rollout_step_kernel<EnvT<R>, R, SAMPLE, SPEC>), grid, dim3(block), 0, st, c, (R*)tr->d_obs,      \
                        tr->d_act, (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t, mean, mean_rs, sg, rng, \
-                       env_offset)
+                       env_offset, p->agents)
     if (mean != nullptr) {
         for (int k = 0; k < EnvT<R>::A; ++k) sg.v[k] = sigma[k];
         if (spec) TG_RS(true, true); else TG_RS(true, false);
@@ -418,6 +419,8 @@ int tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const 
                tr->horizon);
     TG_REQUIRE(tr->horizon == p->max_steps, "tg_rollout_step: trajectory horizon %d != env.max_steps %d", tr->horizon,
                p->max_steps);
+    TG_REQUIRE(p->agents <= 1 || (p->agents <= 64 && (p->agents & (p->agents - 1)) == 0 && tr->n % p->agents == 0),
+               "tg_rollout_step: agents=%d must be a power of two <= 64 dividing n", p->agents);
     if (d_mean != nullptr) {
         int S, A;
         tg_env_dims(p->env_id, &S, &A);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
     typename Env::C c, float* __restrict__ obs, float* __restrict__ act, float* __restrict__ rew,
     uint8_t* __restrict__ mask, int32_t* __restrict__ len, int64_t n, int32_t T, int32_t t0, int32_t t1,
     const uint4* __restrict__ wfrag, const float* __restrict__ bias, int32_t n_hh, SigmaF sigma,
-    const uint64_t* __restrict__ rng, int64_t env_offset) {
+    const uint64_t* __restrict__ rng, int64_t env_offset, int32_t agents) {
     constexpr int S = Env::S, A = Env::A, MT = H / 32, KS = H / 16;
     static_assert(S <= 32 && A <= 4, "state must fit one padded 32-feature tile; actions the first 4 head rows");
     extern __shared__ uint4 lds[];
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
         }
         float o[S], r;
         const StepOut out = Env::step(s, a, c, t + 1, o, r);
-        const bool done = out.truncated || (t + 1 >= T);
+        const bool done = any_in_segment(alive && out.truncated, agents) || (t + 1 >= T);
         const bool carry = alive && !done;
         if (in_range) {
 #pragma unroll
@@ -314,7 +314,7 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
     }
     const dim3 grid((unsigned)ceil_div(tr->n, 128 * NT));
     hipLaunchKernelGGL(kern, grid, dim3(256), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
-                       tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset);
+                       tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset, p->agents);
     TG_LAUNCH_CHECK("tg_fused_rollout");
     return TG_OK;
 }
@@ -336,6 +336,8 @@ int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wf
     TG_REQUIRE(0 <= t_begin && t_begin <= t_end && t_end <= tr->horizon, "tg_fused_rollout: bad step range [%d, %d)", t_begin,
                t_end);
     TG_REQUIRE(n_hidden_layers >= 1 && n_hidden_layers <= 16, "tg_fused_rollout: %d hidden layers unsupported", n_hidden_layers);
+    TG_REQUIRE(p->agents <= 1 || (p->agents <= 32 && (p->agents & (p->agents - 1)) == 0 && tr->n % p->agents == 0),
+               "tg_fused_rollout: agents=%d must be a power of two <= 32 dividing n", p->agents);
     if (t_begin == t_end) return TG_OK;
     const int n_hh = n_hidden_layers - 1;
     hipStream_t st = (hipStream_t)stream;

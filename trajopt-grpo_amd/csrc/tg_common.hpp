@@ -48,6 +48,16 @@ __device__ static inline float rn_div(float a, float b) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Swarm termination: lanes [k*agents, (k+1)*agents) of a wavefront are the bodies of one environment; the env
+// truncates when any of them does.  One 64-bit ballot, then each lane tests its own segment of the mask.
+__device__ static inline bool any_in_segment(bool flag, int agents) {
+    if (agents <= 1) return flag;
+    const unsigned long long b = __ballot(flag);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long seg = (agents >= 64 ? ~0ull : ((1ull << agents) - 1ull)) << (lane & ~(agents - 1));
+    return (b & seg) != 0ull;
+}
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011): counter-based, so the draw for (env, t) does
 // not depend on launch geometry or on how envs are sharded across GPUs.

@@ -242,6 +242,29 @@ class QuadPole(Env):
             p.p[i] = v
 
 
+class QuadPoleSwarm(QuadPole):
+    """N-body swarm for BASELINE config 5 (build-defined: the reference's `QuadrotorSwarm` is an empty subclass,
+    quadrotor_env.py:185-186, so there is nothing to mirror -- SURVEY F3 / 8f.3).
+
+    One environment = `n_agents` independent QuadPole bodies driven by ONE shared policy (each body observes its
+    own 20-dim state and receives its own 4 rotor commands and its own reward).  The bodies are coupled only
+    through termination: the env truncates for everybody when any body leaves the bounds (or at max_steps).
+    In a rollout the bodies of an env occupy `n_agents` consecutive env slots, so the returned tensors are
+    `(G, E*n_agents, T, .)` and a GRPO group spans the `E*n_agents` bodies of its E episodes (group-relative
+    advantage across the swarm).  `n_agents = 1` is exactly `QuadPole`.  The scalar reset/step API steps a single
+    body (no coupling)."""
+
+    def __init__(self, env_name="QuadPoleSwarm", n_agents: int = 8, max_steps=500, device=None, dtype=torch.float64):
+        super().__init__(env_name, max_steps, device, dtype)
+        if n_agents < 1 or n_agents > 32 or (n_agents & (n_agents - 1)):
+            raise ValueError("n_agents must be a power of two <= 32")
+        self.n_agents = n_agents
+
+    def _fill_params(self, p):
+        super()._fill_params(p)
+        p.agents = self.n_agents
+
+
 class Quadrotor:
     """The reference's `Quadrotor` is a stub whose only usable member is `_dynamics`
     (environments/quadrotor_env.py:6-182); this mirrors that pure function, batched."""
@@ -275,4 +298,4 @@ class QuadrotorSwarm(Quadrotor):
     pass
 
 
-ENV_CLASSES = {"CartPole": CartPole, "QuadPole2D": QuadPole2D, "QuadPole": QuadPole}
+ENV_CLASSES = {"CartPole": CartPole, "QuadPole2D": QuadPole2D, "QuadPole": QuadPole, "QuadPoleSwarm": QuadPoleSwarm}

@@ -81,7 +81,9 @@ class DeviceRollout:
                  compute_dtype: Optional[torch.dtype] = None, use_graph: bool = False, fused: Optional[bool] = None):
         self.lib = N.load()
         self.env, self.policy = env, policy
-        self.G, self.E = int(num_groups), int(episodes_per_group)
+        # a swarm env contributes n_agents bodies per episode, laid out as consecutive env slots of the group
+        self.agents = int(getattr(env, "n_agents", 1))
+        self.G, self.E = int(num_groups), int(episodes_per_group) * self.agents
         self.n = self.G * self.E
         self.restart = bool(restart)
         self.device = torch.device(device) if device is not None else policy.device
