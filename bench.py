@@ -220,6 +220,31 @@ def main():
     dt = time.perf_counter() - t0
 
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
+    relu_probe = None
+    if rank == 0 and cdt is not None:
+        # the hand-written kernel with the most GPU time in the update (28 %): ReLU-backward + bias gradient,
+        # one pass over dA (r/w) and A (r): 3 x 512 B per row at 256 bf16 features
+        import ctypes as C
+        N_ = tg._native
+        rows, cols = 1 << 20, 256
+        dA = torch.randn(rows, cols, device=dev).to(cdt)
+        A_ = torch.relu(torch.randn(rows, cols, device=dev)).to(cdt)
+        part = torch.empty(N_.load().tg_relu_bwd_bias_blocks(), cols, dtype=torch.float32, device=dev)
+        st = N_.stream_ptr(dev)
+        for _ in range(3):
+            N_.check(N_.load().tg_relu_bwd_bias(dA.data_ptr(), A_.data_ptr(), rows, cols, 1, part.data_ptr(), st))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            N_.check(N_.load().tg_relu_bwd_bias(dA.data_ptr(), A_.data_ptr(), rows, cols, 1, part.data_ptr(), st))
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / 20
+        gbs = 3.0 * rows * cols * 2 / us / 1e3
+        relu_probe = {"kernel": "tg::relu_bwd_bias_bf16_kernel", "bound": "hbm", "rows": rows, "cols": cols,
+                      "us_per_launch": us, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                      "bytes_per_row": 3 * cols * 2}
+        del dA, A_, part
     fused_all_alive = None
     if rank == 0 and mgr.engine.fused:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
@@ -294,6 +319,7 @@ def main():
                 out["roofline"]["full_launch_us"] = 1e6 * d_full
                 out["roofline"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
         out["dynamics_kernel"] = dyn
+        out["learner_kernel"] = relu_probe
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
