@@ -731,3 +731,54 @@ def test_grpo_on_a_swarm_buffer_uses_group_statistics_across_bodies(tg, dev):
     algo.learn(buf)
     assert np.isfinite(algo.last_stats["J"]).all()
     assert any(not torch.equal(x, y) for x, y in zip(before, pol.parameters()))
+
+
+# --------------------------------------------------------------------------------------------
+# edge shapes
+# --------------------------------------------------------------------------------------------
+def test_degenerate_shapes(tg, dev):
+    """1 env x 1 step; horizon 1; empty launches through the C ABI."""
+    K, Nn = tg.hip_ops, tg._native
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (8,), cov=0.5, device=dev)
+    tr = tg.DeviceRollout(tg.CartPole(max_steps=1), pol, 1, 1, seed=1).run()
+    assert tr.len.tolist() == [1] and tr.mask.tolist() == [[1]] and tr.env_steps() == 1
+    obs, act, rew, ln, mask = tr.to_reference()
+    assert obs.shape == (1, 1, 1, 5) and ln.shape == (1, 1) and float(ln) == 1.0
+    # a single valid step per episode: RTG == reward; GRPO's unbiased std over one sample is NaN, exactly like torch
+    r = K.rtg_scan(tr.rew, tr.mask, 0.9)
+    assert torch.equal(r, tr.rew)
+    adv = K.group_normalize(r, tr.mask, K.masked_moments(r, tr.mask, 1), 0, 1)
+    assert torch.isnan(adv).all() and torch.isnan(torch.std(r.reshape(-1) + 1e-8))
+    # n == 0 is a no-op, not an error
+    lib = Nn.load()
+    z = torch.empty(0, device=dev)
+    assert lib.tg_rtg_scan(z.data_ptr() or 1, z.data_ptr() or 1, 0.5, z.data_ptr() or 1, 0, 4, Nn.stream_ptr(dev)) == 0
+    p = tg.CartPole(max_steps=4).native_params()
+    assert lib.tg_env_reset(C.byref(p), 0, 1, 0, 0, 1, 1, 0, 1, Nn.stream_ptr(dev)) == 0
+    # argument validation happens on the host
+    assert lib.tg_rollout_step(C.byref(p), C.byref(tr.native()), 7, None, 0, None, None, 0, Nn.stream_ptr(dev)) == -1
+    assert b"outside horizon" in lib.tg_last_error()
+
+
+def test_reference_learner_can_consume_the_device_buffer(tg, dev):
+    """Mixing components across the seam: the buffer serves the reference-layout CPU tensors, so a CPU learner written
+    against the reference's attribute names (here: the oracle's restatement of GRPO.learn) runs on a GPU rollout."""
+    torch.manual_seed(10)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (16, 16), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=24), pol, num_workers=2, num_episodes_per_worker=8, seed=4)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    cpu_pol = L.OraclePolicy(5, 1, (16, 16), cov=0.5)
+    cpu_pol.load_state_dict({k: v.cpu() for k, v in pol.state_dict().items()})
+    old = L.OraclePolicy(5, 1, (16, 16), cov=0.5)
+    old.load_state_dict(cpu_pol.state_dict())
+    opt = torch.optim.Adam(cpu_pol.parameters(), lr=3e-4)
+    Js = L.grpo_learn(cpu_pol, old, opt, buf.group_observations, buf.group_actions, buf.group_rewards, buf.group_masks,
+                      epsilon=0.15, gamma=0.5, updates_per_iter=1)
+    # ... and the GPU learner on the same buffer and weights reaches the same J and the same step
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4),
+                   updates_per_iter=1)
+    algo.learn(buf)
+    np.testing.assert_allclose(algo.last_stats["J"], Js, rtol=1e-3, atol=1e-5)
+    for (k, p), q in zip(pol.actor.named_parameters(), cpu_pol.actor.parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=0, atol=5e-5)

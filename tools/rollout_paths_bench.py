@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Rollout-only timing of the three rollout paths (fused persistent kernel, hipGraph replay of the per-step
+launches, eager per-step launches) at 16k / 65k / 262k QuadPole envs x 256 steps, bf16 20-256x5-4 actor."""
 import sys, time, torch
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import trajopt_grpo_amd as tg
 dev=torch.device('cuda',0)
 torch.manual_seed(0)
