@@ -168,7 +168,7 @@ def main():
     policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
     mk = lambda: tg.QuadPole(max_steps=T)
     mgr = tg.RolloutManager(mk, policy, num_workers=G_global, num_episodes_per_worker=E, dtype=torch.float32,
-                            seed=1234, compute_dtype=cdt, use_graph=args.graph, fused=False if args.no_fused else None)
+                            seed=1234, compute_dtype=cdt, use_graph=bool(args.graph), fused=False if args.no_fused else None)
     buf = tg.Rollout_Buffer(mgr)
     algo = tg.PPO(epsilon=0.2, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4), ref_model=None,
                   updates_per_iter=args.updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,

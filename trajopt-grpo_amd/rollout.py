@@ -78,7 +78,8 @@ class DeviceRollout:
 
     def __init__(self, env, policy, num_groups: int, episodes_per_group: int, restart: bool = False,
                  dtype=torch.float32, device=None, seed: int = 0, group_offset: int = 0,
-                 compute_dtype: Optional[torch.dtype] = None, use_graph: bool = False, fused: Optional[bool] = None):
+                 compute_dtype: Optional[torch.dtype] = None, use_graph: Optional[bool] = False,
+                 fused: Optional[bool] = None):
         self.lib = N.load()
         self.env, self.policy = env, policy
         # a swarm env contributes n_agents bodies per episode, laid out as consecutive env slots of the group
@@ -118,6 +119,8 @@ class DeviceRollout:
                              "Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {128,256}, S<=32, A<=4")
         self.fused = can_fuse if fused is None else bool(fused)
         self._fused_H = H
+        if use_graph is None:          # auto: the per-step launch path is launch-bound, replay it as one hipGraph
+            self.use_graph = not self.fused
         # when set to a list, every tg_rollout_step launch is bracketed by HIP events on the launch
         # stream (bench.py reads them back for the dynamics kernel's roofline)
         self.step_events = None
@@ -300,7 +303,7 @@ class RolloutManager:
 
     def __init__(self, env_fn, policy, worker_class=RolloutWorker, restart=False, num_workers: int = 4,
                  num_episodes_per_worker: int = 5, use_multiprocessing: bool = True, *, dtype=torch.float32,
-                 device=None, seed: int = 0, compute_dtype=None, use_graph: bool = False, process_group=None,
+                 device=None, seed: int = 0, compute_dtype=None, use_graph: Optional[bool] = None, process_group=None,
                  fused=None):
         self.env_fn, self.worker_class, self.policy = env_fn, worker_class, policy
         self.restart = restart
