@@ -113,7 +113,8 @@ int  tg_quadrotor12_dynamics(const tg_env_params* p, int dtype, const void* d_st
 /* ---- GPU-resident rollout (replaces RolloutManager.rollout / RolloutWorker.run_episodes,
  *      rollout/rollout_manager.py:85-125, rollout/rollout_worker.py:19-84) ---- */
 
-/* zero the trajectory + counters (padding must be zero: rollout_worker.py:37-41) */
+/* zero the trajectory + counters (padding must be zero: rollout_worker.py:37-41).  Clears ALL of obs, slot 0
+ * included: write the initial states (tg_env_reset into slot 0, or a copy) after this call. */
 int  tg_rollout_begin(const tg_traj* tr, int obs_dim, int act_dim, void* stream);
 
 /* fused time step t for all n envs:

@@ -400,9 +400,9 @@ int tg_rollout_begin(const tg_traj* tr, int obs_dim, int act_dim, void* stream) 
     const size_t n = (size_t)tr->n, T = (size_t)tr->horizon;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    // slot 0 of obs holds the initial states (written by tg_env_reset before or after this call):
-    // clear slots 1..T of every component with one strided 2-D memset
-    e = hipMemset2DAsync((char*)tr->d_obs + n * rs, (T + 1) * n * rs, 0, T * n * rs, (size_t)obs_dim, st);
+    // the whole obs buffer in ONE linear fill (a strided 2-D memset that spares slot 0 runs at ~0.5 TB/s, 10x slower);
+    // the caller writes the initial states into slot 0 AFTER this call (tg_env_reset or a copy)
+    e = hipMemsetAsync(tr->d_obs, 0, (size_t)obs_dim * (T + 1) * n * rs, st);
     if (e == hipSuccess) e = hipMemsetAsync(tr->d_act, 0, (size_t)act_dim * T * n * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(tr->d_rew, 0, T * n * rs, st);
     if (e == hipSuccess) e = hipMemsetAsync(tr->d_mask, 0, T * n, st);

@@ -163,22 +163,39 @@ def _fragment_index(k_pad: int, device):
     return 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
 
 
-def fragment_stream(net, H: int):
-    """(bf16 weight stream, f32 bias table) in the layout tg_fused_rollout consumes."""
-    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
-    dev = lin[0].weight.device
-    row = (torch.arange(64, device=dev) & 31).view(1, -1, 1)
-    blocks = []
-    with torch.no_grad():
-        for li, l in enumerate(lin):
-            m_pad = _round_up(l.out_features, 32)
-            k_pad = _round_up(l.in_features, 32)
-            wp = torch.zeros(m_pad, k_pad, dtype=torch.bfloat16, device=dev)
-            wp[:l.out_features, :l.in_features].copy_(l.weight)
+class FragmentStream:
+    """bf16 weight stream + f32 bias table in the layout tg_fused_rollout consumes, refreshed from the fp32
+    master weights with one gather (the permutation is built once)."""
+
+    def __init__(self, net, H: int):
+        self.lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        dev = self.lin[0].weight.device
+        self.H = H
+        row = (torch.arange(64, device=dev) & 31).view(1, -1, 1)
+        flat_idx, self._slices, off = [], [], 0
+        for l in self.lin:
+            m_pad, k_pad = _round_up(l.out_features, 32), _round_up(l.in_features, 32)
             kidx = _fragment_index(k_pad, dev)                               # [KSl][64][8]
             for mo in range(m_pad // 32):
-                blocks.append(wp[(32 * mo + row).expand_as(kidx), kidx].reshape(-1))   # [KSl*64*8]
-        bias = torch.zeros(len(lin), H, dtype=torch.float32, device=dev)
-        for li, l in enumerate(lin):
-            bias[li, :l.out_features].copy_(l.bias)
-    return torch.cat(blocks).contiguous(), bias.contiguous()
+                flat_idx.append((off + (32 * mo + row).expand_as(kidx) * k_pad + kidx).reshape(-1))
+            self._slices.append((off, m_pad, k_pad))
+            off += m_pad * k_pad
+        self._idx = torch.cat(flat_idx)
+        self._wflat = torch.zeros(off, dtype=torch.bfloat16, device=dev)     # padded weights, layer after layer
+        self.stream = torch.empty(self._idx.numel(), dtype=torch.bfloat16, device=dev)
+        self.bias = torch.zeros(len(self.lin), H, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        for l, (off, m_pad, k_pad) in zip(self.lin, self._slices):
+            self._wflat[off:off + m_pad * k_pad].view(m_pad, k_pad)[:l.out_features, :l.in_features].copy_(l.weight)
+        torch.index_select(self._wflat, 0, self._idx, out=self.stream)
+        for li, l in enumerate(self.lin):
+            self.bias[li, :l.out_features].copy_(l.bias)
+
+
+def fragment_stream(net, H: int):
+    """(bf16 weight stream, f32 bias table) in the layout tg_fused_rollout consumes (one-shot form of FragmentStream)."""
+    fs = FragmentStream(net, H)
+    return fs.stream, fs.bias

@@ -119,6 +119,7 @@ class DeviceRollout:
                              "Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {128,256}, S<=32, A<=4")
         self.fused = can_fuse if fused is None else bool(fused)
         self._fused_H = H
+        self._frag = None
         if use_graph is None:          # auto: the per-step launch path is launch-bound, replay it as one hipGraph
             self.use_graph = not self.fused
         # when set to a list, every tg_rollout_step launch is bracketed by HIP events on the launch
@@ -202,7 +203,11 @@ class DeviceRollout:
     def _enqueue_fused(self, t_begin: int, t_end: int):
         """All steps [t_begin, t_end) in one persistent launch (tg_fused_rollout)."""
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
-        self._wfrag, self._bias_tab = M.fragment_stream(self.policy.actor, self._fused_H)   # weights change every learn()
+        if self._frag is None:
+            self._frag = M.FragmentStream(self.policy.actor, self._fused_H)
+        else:
+            self._frag.refresh()                                  # weights change every learn()
+        self._wfrag, self._bias_tab = self._frag.stream, self._frag.bias
         n_hidden = len(self._linears) - 1
         ev = None
         if self.step_events is not None:
