@@ -220,6 +220,13 @@ int  tg_relu_bwd_bias_blocks(void);
 int  tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, int32_t is_bf16,
                       float* d_partial, void* stream);
 
+/* The head's backward-data product fused into the top hidden layer's ReLU backward:
+ *   dZ[r][c] = (sum_{k<act_dim} dout[r][k] * Whead[k][c]) * (A[r][c] > 0),  d_partial as tg_relu_bwd_bias.
+ * d_dout f32 [rows][act_dim] (contiguous), d_whead f32 [act_dim][cols] (the head's master weights),
+ * d_act / d_dz [rows][cols] bf16 (is_bf16) or f32; cols % 8 == 0. */
+int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, void* d_dz,
+                           int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -561,7 +561,9 @@ def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
     for n, a, p in zip(names, got, net.parameters()):
         rel = float((a - p.grad).norm() / p.grad.norm())
         head = n.startswith(f"network.{2 * len(hidden)}.")
-        assert rel <= (5e-3 if bf else (5e-6 if head else 3e-3)), (n, rel)
+        # bf16: the head's backward uses the fp32 master weights (tg_head_bwd_relu_bias) where autocast rounds them to
+        # bf16 (2^-9 relative), so the two bf16 pipelines differ by a few 1e-3
+        assert rel <= (1e-2 if bf else (5e-6 if head else 3e-3)), (n, rel)
     pad = m.forward(m.prepare_input(X), keep=False, padded=True)
     assert pad.shape[1] % 8 == 0 and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
     assert not tg.mlp.supports(tg.NeuralNetwork(S, A, hidden, "Tanh"))

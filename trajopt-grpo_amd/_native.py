@@ -72,6 +72,7 @@ SIGNATURES = {
     "tg_surrogate_loss": (C.c_int, [_P(LossArgs), _VP]),
     "tg_relu_bwd_bias_blocks": (C.c_int, []),
     "tg_relu_bwd_bias": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "tg_head_bwd_relu_bias": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
 }
 
 _lib = None

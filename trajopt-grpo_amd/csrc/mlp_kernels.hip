@@ -81,6 +81,82 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_f32_kernel(float* __restric
     }
 }
 
+// Head backward fused with the top hidden layer's ReLU backward and bias gradient:
+//   dA[r][c] = sum_k dout[r][k] * Wh[k][c]   (k < A <= 8: a rank-A product, computed on the fly in fp32)
+//   dZ[r][c] = dA[r][c] * (Act[r][c] > 0)    written once (bf16 or f32);  partial[block][c] = column sums of dZ
+// replaces the [rows x 8] x [8 x cols] GEMM (which only writes 512 B/row) plus the read of dA in relu_bwd_bias.
+__device__ static inline uint16_t f32_to_bf16_rne(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+
+template <bool kBf16>
+__global__ __launch_bounds__(256) void head_bwd_relu_bias_kernel(const float* __restrict__ dout, int a_dim,
+                                                                 const float* __restrict__ Wh, const void* __restrict__ act,
+                                                                 void* __restrict__ dz, int64_t rows, int cols,
+                                                                 float* __restrict__ partial) {
+    extern __shared__ float sh[];
+    constexpr int PER = 8;
+    const int tpr = cols / PER;
+    const int rpp = blockDim.x / tpr;
+    const int rl = threadIdx.x / tpr, cl = (threadIdx.x % tpr) * PER;
+    float acc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+    if (rl < rpp) {
+        float w[8][PER];                                      // this thread's columns of the head weights
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < PER; ++j) w[k][j] = (k < a_dim) ? Wh[(int64_t)k * cols + cl + j] : 0.f;
+        for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < rows; r += (int64_t)gridDim.x * rpp) {
+            float d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = (k < a_dim) ? dout[r * a_dim + k] : 0.f;
+            float v[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += d[k] * w[k][j];
+                v[j] = s;
+            }
+            const int64_t off = r * cols + cl;
+            if constexpr (kBf16) {
+                const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(act) + off);
+                const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+                uint32_t ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint16_t a_lo = (uint16_t)(av[j] & 0xFFFFu), a_hi = (uint16_t)(av[j] >> 16);
+                    const bool p_lo = (a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u);
+                    const bool p_hi = (a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u);
+                    const uint16_t o_lo = p_lo ? f32_to_bf16_rne(v[2 * j]) : (uint16_t)0;
+                    const uint16_t o_hi = p_hi ? f32_to_bf16_rne(v[2 * j + 1]) : (uint16_t)0;
+                    acc[2 * j] += bf16_to_f32(o_lo);
+                    acc[2 * j + 1] += bf16_to_f32(o_hi);
+                    ov[j] = (uint32_t)o_lo | ((uint32_t)o_hi << 16);
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dz) + off) = uint4{ov[0], ov[1], ov[2], ov[3]};
+            } else {
+                const float* ap = reinterpret_cast<const float*>(act) + off;
+                float* zp = reinterpret_cast<float*>(dz) + off;
+                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                const float am[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int j = 0; j < PER; ++j) { v[j] = am[j] > 0.f ? v[j] : 0.f; acc[j] += v[j]; }
+                *reinterpret_cast<float4*>(zp) = float4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4*>(zp + 4) = float4{v[4], v[5], v[6], v[7]};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sh[rl * cols + cl + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += sh[r * cols + c];
+        partial[(int64_t)blockIdx.x * cols + c] = s;
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -106,6 +182,26 @@ int tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, in
                            rows, cols, d_partial);
     }
     TG_LAUNCH_CHECK("tg_relu_bwd_bias");
+    return TG_OK;
+}
+
+int tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, void* d_dz,
+                          int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream) {
+    TG_REQUIRE(d_dout && d_whead && d_act && d_dz && d_partial, "tg_head_bwd_relu_bias: null pointer");
+    TG_REQUIRE(act_dim >= 1 && act_dim <= 8, "tg_head_bwd_relu_bias: act_dim %d outside 1..8", act_dim);
+    TG_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols / 8 <= 256, "tg_head_bwd_relu_bias: cols=%d must be a multiple of 8 and <= 2048",
+               cols);
+    const int tpr = cols / 8, rpp = 256 / tpr;
+    const size_t shmem = (size_t)rpp * cols * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16) {
+        hipLaunchKernelGGL(head_bwd_relu_bias_kernel<true>, dim3(kReluBlocks), dim3(256), shmem, st, d_dout, act_dim, d_whead, d_act,
+                           d_dz, rows, cols, d_partial);
+    } else {
+        hipLaunchKernelGGL(head_bwd_relu_bias_kernel<false>, dim3(kReluBlocks), dim3(256), shmem, st, d_dout, act_dim, d_whead, d_act,
+                           d_dz, rows, cols, d_partial);
+    }
+    TG_LAUNCH_CHECK("tg_head_bwd_relu_bias");
     return TG_OK;
 }
 

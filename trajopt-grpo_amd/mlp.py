@@ -116,21 +116,31 @@ class GemmMLP:
         lib = N.load()
         rows = dout.shape[0]
         L = len(self.linears)
+        dout = dout.contiguous()
         dz = torch.zeros(rows, self.out_pad, dtype=self.cd, device=dout.device)
         dz[:, :self.out_dim].copy_(dout)
         lin = self.linears[-1]
         lin.bias.grad.add_(dout.sum(0))
         lin.weight.grad.add_(self._dw(dz, acts[L - 1])[:self.out_dim])
-        da = dz @ self.w[-1]
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0
         nblk = lib.tg_relu_bwd_bias_blocks()
+        fuse_head = self.out_dim <= 8
+        da = None if fuse_head else dz @ self.w[-1]
         for i in range(L - 2, -1, -1):
             a = acts[i + 1]
             cols = a.shape[1]
             if self._partial is None or self._partial.shape[1] != cols:
                 self._partial = torch.empty(nblk, cols, dtype=torch.float32, device=dout.device)
-            N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, self._partial.data_ptr(),
-                                         N.stream_ptr(dout.device)), "tg_relu_bwd_bias")
+            if i == L - 2 and fuse_head:
+                # top hidden layer: dA = dout . W_head is a rank-A product, formed inside the ReLU-backward kernel
+                da = torch.empty_like(a)
+                N.check(lib.tg_head_bwd_relu_bias(dout.data_ptr(), self.out_dim, self.linears[-1].weight.data_ptr(),
+                                                  a.data_ptr(), da.data_ptr(), rows, cols, is_bf16,
+                                                  self._partial.data_ptr(), N.stream_ptr(dout.device)),
+                        "tg_head_bwd_relu_bias")
+            else:
+                N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, self._partial.data_ptr(),
+                                             N.stream_ptr(dout.device)), "tg_relu_bwd_bias")
             lin = self.linears[i]
             lin.bias.grad.add_(self._partial.sum(0))
             dw = self._dw(da, acts[i])
