@@ -296,7 +296,10 @@ def main():
             dur = sum(d for d, _ in launches) * 1e-3
             ach = 2.0 * n_par * sum(launch_units) / dur / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                               "traffic": None, "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256>",
+                               "traffic": 1706642656 if args.envs == 65536 else None,
+                               "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
+                                                 "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
+                               "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1>",
                                "flops_per_env_step": 2 * n_par, "launches": len(launches),
                                "avg_launch_ms": 1e3 * dur / len(launches),
                                "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
