@@ -27,71 +27,70 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SigmaF { float v[8]; };
 
-constexpr int kRing = 2;          // LDS slots (each one weight block = H/16 KiB)
+typedef __attribute__((address_space(3))) void lds_void;
 
 // One weight block = the A fragments of one 32-row output tile for all k-steps (hidden layers and head),
-// or of all MT output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB.  The block
-// stream is the same every time step (L2-resident, n_blocks even) and is software-pipelined through two
-// register sets: block b+3 is requested from L2 while block b is being multiplied, block b+1 is parked in
-// the other LDS slot.  One barrier per block.
-// (plain named uint4 registers: an array-of-struct staging object ends up in scratch memory)
-#define TG_STG_LOAD(S, g)                                                            \
-    do {                                                                             \
-        const uint4* g__ = (g);                                                      \
-        S##0 = g__[threadIdx.x];                                                     \
-        S##1 = g__[256 + threadIdx.x];                                               \
-        if constexpr (KS / 4 > 2) { S##2 = g__[512 + threadIdx.x]; S##3 = g__[768 + threadIdx.x]; } \
-    } while (0)
-#define TG_STG_STORE(S, slot)                                                        \
-    do {                                                                             \
-        uint4* s__ = (slot);                                                         \
-        s__[threadIdx.x] = S##0;                                                     \
-        s__[256 + threadIdx.x] = S##1;                                               \
-        if constexpr (KS / 4 > 2) { s__[512 + threadIdx.x] = S##2; s__[768 + threadIdx.x] = S##3; } \
-    } while (0)
+// or of all MT output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB = KS pieces of
+// 1 KiB (one wave-instruction each).  The block stream is the same every time step (L2-resident) and flows
+// L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging) into a ring of D slots with P blocks
+// in flight: the stream needs ~15-30 GB/s per CU, far more bytes in flight than two register sets can hold
+// (the register-staged version spent 9 of 36 us per step waiting for it).  Per block: a COUNTED
+// `s_waitcnt vmcnt` (this wave's pieces of the block have landed; the P-1 younger blocks stay in flight),
+// a raw `s_barrier` (everyone's pieces have landed, and everyone has finished reading the slot that is
+// about to be refilled), then the DMA for block +P is issued.  `__syncthreads()` would drain the ring.
+template <int KS, int WPW>
+__device__ static inline void dma_block(const uint4* __restrict__ gblock, uint4* __restrict__ slot, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < KS / WPW; ++q) {
+        const int piece = q * WPW + wave;
+        __builtin_amdgcn_global_load_lds(gblock + piece * 64 + lane, (lds_void*)(slot + piece * 64), 16, 0, 0);
+    }
+}
 
-// consume an even block (slot 0): publish the odd block parked in set B to slot 1, request block +3 into B;
-// consume an odd block (slot 1): the same with set A / slot 0.
-#define TG_STAGE_ADVANCE_EVEN                                                        \
-    __syncthreads();                                                                 \
-    TG_STG_STORE(sb, ring + KS * 64);                                                \
-    TG_STG_LOAD(sb, wfrag + (int64_t)pre * KS * 64);                                 \
-    pre = (pre + 1 == n_blocks) ? 0 : pre + 1;                                       \
-    const uint4* cur = ring;
-#define TG_STAGE_ADVANCE_ODD                                                         \
-    __syncthreads();                                                                 \
-    TG_STG_STORE(sa, ring);                                                          \
-    TG_STG_LOAD(sa, wfrag + (int64_t)pre * KS * 64);                                 \
-    pre = (pre + 1 == n_blocks) ? 0 : pre + 1;                                       \
-    const uint4* cur = ring + KS * 64;
+#define TG_STAGE_ADVANCE                                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * (KS / WPW)) : "memory");               \
+    __builtin_amdgcn_s_barrier();                                                             \
+    asm volatile("" ::: "memory");                                                            \
+    dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane); \
+    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                    \
+    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                        \
+    const uint4* cur = ring + cur_slot * KS * 64;                                             \
+    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
 
-// NT = env tiles (of 32) per wave.  NT = 2: 64 envs per wave, one lane per env, one wave per SIMD (the X
-// fragments of two tiles fill the register file).  NT = 1: 32 envs per wave (lanes 32..63 only carry the upper
-// k-halves of the MFMA operands), half the registers, two workgroups per CU: finer termination granularity
-// (a wave stops doing MFMA work when its 32 envs have ended) and more workgroups for small env counts.
-template <typename Env, int H, int NT>
-__global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
+// NT = env tiles (of 32) per wave, WPW = waves per workgroup.
+//   NT = 2, WPW = 4: 64 envs per wave, one lane per env, one wave per SIMD (the X fragments of two tiles fill
+//                    the register file), 256 envs per workgroup.
+//   NT = 1, WPW = 8: 32 envs per wave (lanes 32..63 only carry the upper k-halves of the MFMA operands), half the
+//                    registers, so two waves share a SIMD and fill each other's barrier / LDS / epilogue gaps;
+//                    ONE weight ring feeds all 8 waves (256 envs per workgroup).  Measured fastest.
+//   NT = 1, WPW = 4: 128 envs per workgroup, two workgroups per CU (twice the weight stream per CU); more
+//                    workgroups for small env counts.
+template <typename Env, int H, int NT, int WPW>
+__global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_kernel(
     typename Env::C c, float* __restrict__ obs, float* __restrict__ act, float* __restrict__ rew,
     uint8_t* __restrict__ mask, int32_t* __restrict__ len, int64_t n, int32_t T, int32_t t0, int32_t t1,
     const uint4* __restrict__ wfrag, const float* __restrict__ bias, int32_t n_hh, SigmaF sigma,
     const uint64_t* __restrict__ rng, int64_t env_offset, int32_t agents) {
     constexpr int S = Env::S, A = Env::A, MT = H / 32, KS = H / 16;
+    constexpr int D = (NT == 1 && WPW == 4) ? 3 : 4, P = D - 1;   // ring slots, blocks in flight (LDS is shared by 2 workgroups at 4 x NT=1)
+    static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
     static_assert(S <= 32 && A <= 4, "state must fit one padded 32-feature tile; actions the first 4 head rows");
     extern __shared__ uint4 lds[];
-    uint4* ring = lds;                                                  // kRing * KS * 64 uint4
-    float* bias_s = reinterpret_cast<float*>(lds + kRing * KS * 64);    // (n_hh + 2) * H floats
-    unsigned short* xs = reinterpret_cast<unsigned short*>(bias_s + (n_hh + 2) * H);   // 4 waves * 64 envs * 32 bf16
+    uint4* ring = lds;                                                  // D * KS * 64 uint4
+    float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
+    unsigned short* xs = reinterpret_cast<unsigned short*>(bias_s + (n_hh + 2) * H);   // WPW waves * 64 rows * 32 bf16
+    int* flags = reinterpret_cast<int*>(xs + WPW * 64 * 32);            // WPW ints: per-wave "some env alive"
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
     // NT = 2: lane == env.  NT = 1: lanes 0..31 own the wave's 32 envs, lanes 32..63 shadow them (never recorded).
-    const int64_t i = (NT == 2) ? (int64_t)blockIdx.x * 256 + threadIdx.x
-                                : (int64_t)blockIdx.x * 128 + wave * 32 + col;
+    const int64_t i = (NT == 2) ? (int64_t)blockIdx.x * (64 * WPW) + threadIdx.x
+                                : (int64_t)blockIdx.x * (32 * WPW) + wave * 32 + col;
     const bool in_range = (i < n) && (NT == 2 || h == 0);
     const int64_t ic = (i < n) ? i : n - 1;
     const int64_t T1 = (int64_t)T + 1;
 
-    for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 256) bias_s[q] = bias[q];
+    for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
 
     float s[S];
 #pragma unroll
@@ -101,19 +100,26 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
     // zero the padding features once (columns S..31 never change)
 #pragma unroll
     for (int k = S; k < 32; ++k) my_x[k] = 0;
-    const int n_blocks = n_hh * MT + 2;               // even (MT is even): block parity is static per code site
-    static_assert(KS / 4 == 2 || KS / 4 == 4, "staging macros cover 2 or 4 uint4 per thread and block");
-    uint4 sa0, sa1, sa2 = {}, sa3 = {}, sb0, sb1, sb2 = {}, sb3 = {};   // staging sets: even / odd blocks
-    TG_STG_LOAD(sa, wfrag);                           // block 0 -> slot 0 now; blocks 1, 2 in flight
-    TG_STG_STORE(sa, ring);
-    TG_STG_LOAD(sb, wfrag + (int64_t)1 * KS * 64);
-    TG_STG_LOAD(sa, wfrag + (int64_t)(2 % n_blocks) * KS * 64);
-    int pre = 3 % n_blocks;                           // next stream position to request
-    __syncthreads();
+    const int n_blocks = n_hh * MT + 2;
+    __syncthreads();                                  // bias table and padding are in place; no DMA outstanding yet
+    int pre_pos = 0, pre_slot = 0, cur_slot = 0;
+    for (int b0 = 0; b0 < P; ++b0) {                  // blocks 0..P-1 in flight before the first step
+        dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
+        pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
+    }
 
     for (int32_t t = t0; t < t1; ++t) {
-        if (!__syncthreads_or(alive ? 1 : 0)) break;          // every env of this workgroup has ended
         const bool wave_alive = __ballot(alive) != 0ull;
+        // leave the time loop when every env of this workgroup has ended (raw barrier: keeps the DMA ring in flight)
+        if (lane == 0) flags[wave] = wave_alive ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int any_alive = 0;
+#pragma unroll
+        for (int w = 0; w < WPW; ++w) any_alive |= flags[w];
+        if (any_alive == 0) break;
 
         // ---- layer-1 input: this wave's 64 states as bf16 rows in LDS, read back in B-fragment order ----
 #pragma unroll
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
 
         // ---- layer 1: [H x 32] . [32 x 64 envs]; one block holds all MT output tiles (2 k-steps each) ----
         {
-            TG_STAGE_ADVANCE_EVEN
+            TG_STAGE_ADVANCE
             if (wave_alive) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -200,11 +206,11 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
 #pragma unroll
             for (int mp = 0; mp < MT / 2; ++mp) {
                 {
-                    TG_STAGE_ADVANCE_ODD
+                    TG_STAGE_ADVANCE
                     tile_gemm(cur, 2 * mp);
                 }
                 {
-                    TG_STAGE_ADVANCE_EVEN
+                    TG_STAGE_ADVANCE
                     tile_gemm(cur, 2 * mp + 1);
                 }
             }
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
         // ---- head: 32 padded output rows (the first A are the action means), no activation ----
         float mu[A];
         {
-            TG_STAGE_ADVANCE_ODD
+            TG_STAGE_ADVANCE
             const float* bl = bias_s + (n_hh + 1) * H;
             f32x16 acc2[NT];
 #pragma unroll
@@ -284,9 +290,10 @@ __global__ __launch_bounds__(256, 3 - NT) void fused_rollout_kernel(
         for (int k = 0; k < S; ++k) s[k] = carry ? o[k] : 0.0f;
         alive = carry;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <template <typename> class EnvT, int H, int NT>
+template <template <typename> class EnvT, int H, int NT, int WPW>
 static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* wfrag, const float* bias, int n_hh,
                         const float* sigma, const uint64_t* rng, int64_t env_offset, int t0, int t1, hipStream_t st) {
     using Env = EnvT<float>;
@@ -295,8 +302,9 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
     SigmaF sg;
     memset(&sg, 0, sizeof(sg));
     for (int k = 0; k < Env::A; ++k) sg.v[k] = sigma[k];
-    const size_t shmem = (size_t)kRing * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + 4 * 64 * 32 * 2;
-    auto kern = fused_rollout_kernel<Env, H, NT>;
+    const size_t shmem = (size_t)((NT == 1 && WPW == 4) ? 3 : 4) * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) +
+                         (size_t)WPW * 64 * 32 * 2 + 4 * WPW;
+    auto kern = fused_rollout_kernel<Env, H, NT, WPW>;
     if (shmem > 160 * 1024) return set_error(TG_ERR_ARG, "tg_fused_rollout: %zu B of LDS needed (> 160 KiB)", shmem);
     static size_t attr_bytes = 0;
     if (shmem > 64 * 1024 && shmem > attr_bytes) {
@@ -312,8 +320,8 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
         }
         attr_bytes = shmem;
     }
-    const dim3 grid((unsigned)ceil_div(tr->n, 128 * NT));
-    hipLaunchKernelGGL(kern, grid, dim3(256), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
+    const dim3 grid((unsigned)ceil_div(tr->n, 32 * NT * WPW));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WPW), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
                        tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset, p->agents);
     TG_LAUNCH_CHECK("tg_fused_rollout");
     return TG_OK;
@@ -341,13 +349,14 @@ int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wf
     if (t_begin == t_end) return TG_OK;
     const int n_hh = n_hidden_layers - 1;
     hipStream_t st = (hipStream_t)stream;
-    // tiles per wave: 1 (32-env waves, two workgroups per CU) measured faster whenever episodes end early and for
-    // small env counts; 2 (64-env waves) marginally faster when every env runs the full horizon.  TG_FUSED_NT overrides.
-    static const int nt_env = [] { const char* e = getenv("TG_FUSED_NT"); return e ? atoi(e) : 0; }();
-    const int nt = nt_env == 1 || nt_env == 2 ? nt_env : 1;
-#define CALL(E, HH)                                                                                                   \
-    (nt == 1 ? fused_launch<E, HH, 1>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st)      \
-             : fused_launch<E, HH, 2>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st))
+    // variant: 0 = NT 1 x 8 waves (default), 1 = NT 1 x 4 waves (two workgroups per CU; default below 32,768 envs, where
+    // it gives twice as many workgroups), 2 = NT 2 x 4 waves.  TG_FUSED_VARIANT overrides.
+    static const int var_env = [] { const char* e = getenv("TG_FUSED_VARIANT"); return e ? atoi(e) : -1; }();
+    const int variant = (var_env >= 0 && var_env <= 2) ? var_env : (tr->n < 32768 ? 1 : 0);
+#define CALL(E, HH)                                                                                                       \
+    (variant == 0   ? fused_launch<E, HH, 1, 8>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st) \
+     : variant == 1 ? fused_launch<E, HH, 1, 4>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st) \
+                    : fused_launch<E, HH, 2, 4>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st))
     switch (p->env_id * 1000 + hidden) {
         case TG_ENV_CARTPOLE * 1000 + 128: return CALL(CartPoleEnv, 128);
         case TG_ENV_CARTPOLE * 1000 + 256: return CALL(CartPoleEnv, 256);
