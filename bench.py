@@ -299,7 +299,7 @@ def main():
                                "traffic": 1706642656 if args.envs == 65536 else None,
                                "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
                                                  "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
-                               "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1>",
+                               "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
                                "flops_per_env_step": 2 * n_par, "launches": len(launches),
                                "avg_launch_ms": 1e3 * dur / len(launches),
                                "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
