@@ -115,3 +115,48 @@ def test_policy_surface_and_checkpoint_formats(tmp_path):
     import copy
     c = copy.deepcopy(ac)                                                 # grpo.py:48 / ppo.py:62 deep-copy the policy
     assert all(torch.equal(x, y) for x, y in zip(c.parameters(), ac.parameters()))
+
+
+def test_fragment_stream_layout_is_the_mfma_a_fragment_order():
+    """Host logic of the fused rollout kernel's weight stream (mlp.FragmentStream), checked on CPU: block b of a
+    layer holds, for every k-step, the 64 lanes' 8-element A fragments of one 32-row output tile, with the k order
+    in which an MFMA accumulator tile hands its rows to the next layer: 16*ks + 8*(j>>2) + 4*h + (j&3)."""
+    torch.manual_seed(0)
+    net = tg.NeuralNetwork(20, 4, (128, 128), "ReLU")
+    assert tg.mlp.fused_rollout_supported(net, 20, 4) == 128
+    assert tg.mlp.fused_rollout_supported(net, 40, 4) == 0 and tg.mlp.fused_rollout_supported(net, 20, 5) == 0
+    assert tg.mlp.fused_rollout_supported(tg.NeuralNetwork(20, 4, (128, 256), "ReLU"), 20, 4) == 0
+    fs = tg.mlp.FragmentStream(net, 128)
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    KS = 128 // 16
+    n_blocks = 1 + 4 + 1                       # layer 1 (all tiles), 4 output tiles of the 128x128 layer, the head
+    assert fs.stream.numel() == n_blocks * KS * 64 * 8 and fs.bias.shape == (3, 128)
+    st = fs.stream.float().view(-1, 64, 8)     # [fragment][lane][j]
+
+    def expect(W, m_pad, k_pad, mo, ks, lane, j):
+        r, c = 32 * mo + (lane & 31), 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+        if r >= W.shape[0] or c >= W.shape[1]:
+            return 0.0
+        return float(W[r, c].to(torch.bfloat16))
+
+    rng = np.random.default_rng(0)
+    # layer 1: K padded 20 -> 32 (2 k-steps), 4 output tiles packed into ONE block: fragment index = mo*2 + ks
+    for _ in range(200):
+        mo, ks, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(st[mo * 2 + ks, lane, j]) == expect(lin[0].weight, 128, 32, mo, ks, lane, j)
+    # hidden layer: block (1 + mo), fragment ks
+    base = KS
+    for _ in range(200):
+        mo, ks, lane, j = rng.integers(4), rng.integers(KS), rng.integers(64), rng.integers(8)
+        assert float(st[base + mo * KS + ks, lane, j]) == expect(lin[1].weight, 128, 128, mo, ks, lane, j)
+    # head: 4 rows padded to 32
+    base = KS + 4 * KS
+    for _ in range(200):
+        ks, lane, j = rng.integers(KS), rng.integers(64), rng.integers(8)
+        assert float(st[base + ks, lane, j]) == expect(lin[2].weight, 32, 128, 0, ks, lane, j)
+    assert torch.equal(fs.bias[2, :4], lin[2].bias.detach()) and torch.all(fs.bias[2, 4:] == 0)
+    # refresh follows the master weights
+    with torch.no_grad():
+        lin[1].weight.add_(1.0)
+    fs.refresh()
+    assert float(fs.stream.float().view(-1, 64, 8)[KS + 3, 5, 2]) == expect(lin[1].weight, 128, 128, 0, 3, 5, 2)
