@@ -29,6 +29,8 @@ struct SigmaF { float v[8]; };
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+constexpr int kCompactEvery = 8;   // time steps between compactions of a workgroup's running envs
+
 // One weight block = the A fragments of one 32-row output tile for all k-steps (hidden layers and head),
 // or of all MT output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB = KS pieces of
 // 1 KiB (one wave-instruction each).  The block stream is the same every time step (L2-resident) and flows
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
     // NT = 2: lane == env.  NT = 1: lanes 0..31 own the wave's 32 envs, lanes 32..63 shadow them (never recorded).
-    const int64_t i = (NT == 2) ? (int64_t)blockIdx.x * (64 * WPW) + threadIdx.x
-                                : (int64_t)blockIdx.x * (32 * WPW) + wave * 32 + col;
-    const bool in_range = (i < n) && (NT == 2 || h == 0);
-    const int64_t ic = (i < n) ? i : n - 1;
+    const int64_t wg_base = (int64_t)blockIdx.x * (32 * NT * WPW);
+    int64_t i = (NT == 2) ? wg_base + threadIdx.x : wg_base + wave * 32 + col;
+    bool in_range = (i < n) && (NT == 2 || h == 0);
+    int64_t ic = (i < n) ? i : n - 1;
     const int64_t T1 = (int64_t)T + 1;
 
     for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
@@ -110,16 +112,68 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
     }
 
     for (int32_t t = t0; t < t1; ++t) {
-        const bool wave_alive = __ballot(alive) != 0ull;
-        // leave the time loop when every env of this workgroup has ended (raw barrier: keeps the DMA ring in flight)
-        if (lane == 0) flags[wave] = wave_alive ? 1 : 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        int any_alive = 0;
+        bool wave_alive;
+        if (NT == 1 && agents <= 1 && t > t0 && ((t - t0) % kCompactEvery) == 0) {
+            // ---- compaction: the workgroup's running envs move to its lowest lanes, so the waves that hold only
+            // ended envs (and, between compactions, fill up with them) stop doing MFMA work.  An env keeps its
+            // identity `i`: recording and the Philox key follow the env, not the lane.
+            const bool own = alive && (h == 0);
+            const unsigned long long ball = __ballot(own);
+            const int cnt = __popcll(ball);
+            const int rank = __popcll(ball & ((1ull << lane) - 1ull));
+            if (lane == 0) flags[wave] = cnt;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int offset = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < WPW; ++w) any_alive |= flags[w];
-        if (any_alive == 0) break;
+            for (int w = 0; w < WPW; ++w) {
+                const int cw = flags[w];
+                offset += (w < wave) ? cw : 0;
+                total += cw;
+            }
+            if (total == 0) break;                            // every env of this workgroup has ended
+            float* stage = reinterpret_cast<float*>(xs);      // [32*WPW][S+1] floats; xs is rewritten every step anyway
+            if (own) {
+                float* d = stage + (offset + rank) * (S + 1);
+#pragma unroll
+                for (int k = 0; k < S; ++k) d[k] = s[k];
+                d[S] = __int_as_float((int)(i - wg_base));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int slot = wave * 32 + col;
+            if (slot < total) {
+                const float* d = stage + slot * (S + 1);
+#pragma unroll
+                for (int k = 0; k < S; ++k) s[k] = d[k];
+                i = wg_base + __float_as_int(d[S]);
+                alive = true;
+                in_range = (h == 0);
+                ic = i;
+            } else {
+                alive = false;
+                in_range = false;                             // an empty slot records nothing
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // staging reads are done before xs is rewritten
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = S; k < 32; ++k) my_x[k] = 0;         // the staging overwrote the zero padding of the feature rows
+            wave_alive = __ballot(alive) != 0ull;
+        } else {
+            wave_alive = __ballot(alive) != 0ull;
+            // leave the time loop when every env of this workgroup has ended (raw barrier: keeps the DMA ring in flight)
+            if (lane == 0) flags[wave] = wave_alive ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int any_alive = 0;
+#pragma unroll
+            for (int w = 0; w < WPW; ++w) any_alive |= flags[w];
+            if (any_alive == 0) break;
+        }
 
         // ---- layer-1 input: this wave's 64 states as bf16 rows in LDS, read back in B-fragment order ----
 #pragma unroll
