@@ -72,7 +72,7 @@ def device_trajectory(buffer, device) -> DeviceTrajectory:
 
 
 class _GpuLearner(Algorithm):
-    chunk_rows = 1 << 20
+    chunk_rows = 1 << 22          # rows per forward/backward chunk (activations: ~5 KiB per row and net at 256x5 bf16)
 
     def _setup(self, policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp=True):
         self.policy, self.optimizer = policy, optimizer
