@@ -150,6 +150,31 @@ def gen_env_steps(rng):
                             truncated=trunc, time_balanced_after=tb_after, info_time_balanced=info_tb)
         print(name, "single-step: truncated", int(trunc.sum()), "reward range", rew.min(), rew.max())
 
+    # non-default constructor arguments (the physical parameters are live attributes in the reference)
+    rng2 = np.random.default_rng(777)   # own stream: the fixtures generated after this keep their values
+    envs = {
+        "cartpole_custom": (CartPole(masscart=2.0, masspole=0.3, length=0.8, gravity=9.0, timestep=0.01, max_steps=MAXS),
+                            "CartPole", 5, 1, dict(masscart=2.0, masspole=0.3, length=0.8, gravity=9.0, timestep=0.01)),
+        "quadpole2d_custom": (QuadPole2D(max_steps=MAXS, timestep=0.01), "QuadPole2D", 10, 2, dict(timestep=0.01)),
+    }
+    for tag, (env, name, S, A, kw) in envs.items():
+        n = 96
+        st = rng2.normal(size=(n, S)) * 0.5
+        for i0 in ((2,) if name == "CartPole" else (4, 7)):
+            ang = rng2.uniform(-np.pi, np.pi, size=n)
+            st[:, i0], st[:, i0 + 1] = np.sin(ang), np.cos(ang)
+        act = (rng2.normal(size=(n, A)) * 0.9).astype(np.float32)
+        steps = rng2.integers(0, MAXS - 1, size=n)
+        tb = np.zeros(n)
+        nxt, rew, trunc = np.zeros((n, S)), np.zeros(n), np.zeros(n, dtype=bool)
+        for i in range(n):
+            set_env_state(env, name, st[i], steps[i], tb[i])
+            o, r, term, tr, info = env.step(act[i])
+            nxt[i], rew[i], trunc[i] = np.asarray(o, dtype=np.float64), float(r), bool(tr)
+        np.savez_compressed(os.path.join(OUT, f"env_step_{tag}.npz"), state=st, action=act, steps=steps, time_balanced=tb,
+                            max_steps=MAXS, next_state=nxt, reward=rew, truncated=trunc,
+                            **{f"param_{k}": v for k, v in kw.items()})
+
     # Quadrotor._dynamics pure function (class is a stub)
     q = Quadrotor()
     st = rng.normal(size=(64, 12)) * 0.5
@@ -359,6 +384,32 @@ def gen_learner(rng):
         print("PPO total", out["total_loss"])
 
 
+def gen_ppo_gae_step():
+    G, Eps, T, S, A = 3, 4, 16, 10, 2
+    rs = np.random.default_rng(300)
+    buf = ragged_buffer(rs, G, Eps, T, S, A)
+    torch.manual_seed(23)
+    pol = GaussianActorCritic_NeuralNetwork(S, A, (32, 32), cov=[0.5, 0.2])
+    init = sd_to_np(pol.state_dict())
+    opt = torch.optim.Adam(pol.parameters(), lr=2e-4)
+    ppo = PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=0.5, kl_coeff=0.5, gamma=0.97,
+              lam=0.9, entropy=0.01, batch_size=None, monte_carlo=False)
+    sink = []
+    hook_frame_locals(opt, "zero_grad", ["total_loss", "actor_loss", "critic_loss", "kl_div"], sink)
+    ppo.learn(buf)
+    out = dict(obs=buf.group_observations.numpy(), act=buf.group_actions.numpy(), rew=buf.group_rewards.numpy(),
+               mask=buf.group_masks.numpy(), lr=2e-4, epsilon=0.2, gamma=0.97, lam=0.9, cov=np.array([0.5, 0.2]), c1=0.5,
+               kl_coeff=0.5, entropy_coeff=0.01)
+    for name in ("total_loss", "actor_loss", "critic_loss", "kl_div"):
+        out[name] = np.array([float(r[name]) for r in sink])
+    for k, v in init.items():
+        out[f"init.{k}"] = v
+    for k, v in sd_to_np(pol.state_dict()).items():
+        out[f"final.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "ppo_gae_step_u2.npz"), **out)
+    print("PPO GAE total", out["total_loss"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20250613)
@@ -366,6 +417,7 @@ def main():
     gen_rollouts()
     gen_policy()
     gen_learner(rng)
+    gen_ppo_gae_step()
     print("fixtures written to", OUT)
 
 

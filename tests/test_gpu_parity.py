@@ -31,10 +31,10 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def native_step(tg, name, state, action, steps, tb, max_steps, dtype, dev):
+def native_step(tg, name, state, action, steps, tb, max_steps, dtype, dev, **ctor):
     """tg_env_step through the C ABI on SoA device arrays."""
     Nn = tg._native
-    env = tg.environments.ENV_CLASSES[name](max_steps=max_steps)
+    env = tg.environments.ENV_CLASSES[name](max_steps=max_steps, **ctor)
     p = env.native_params()
     n = state.shape[0]
     st = torch.as_tensor(np.ascontiguousarray(state.T), dtype=dtype, device=dev)
@@ -65,6 +65,17 @@ def test_step_fp64_matches_reference_golden(tg, dev, name):
     assert np.array_equal(sp, g["steps"] + 1)
     if name != "QuadPole":
         np.testing.assert_allclose(tb, g["time_balanced_after"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,name", [("cartpole_custom", "CartPole"), ("quadpole2d_custom", "QuadPole2D")])
+def test_step_with_non_default_constructor_arguments(tg, dev, tag, name):
+    g = load_golden(f"env_step_{tag}.npz")
+    kw = {k[len("param_"):]: float(g[k]) for k in g if k.startswith("param_")}
+    nx, rw, tr, sp, _ = native_step(tg, name, g["state"], g["action"], g["steps"], g["time_balanced"],
+                                    int(g["max_steps"]), torch.float64, dev, **kw)
+    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(rw, g["reward"], rtol=1e-11, atol=1e-11)
+    assert np.array_equal(tr, g["truncated"])
 
 
 @pytest.mark.parametrize("name", ENVS)
@@ -491,6 +502,25 @@ def test_ppo_learn_matches_reference(tg, dev, n_upd):
     for net in ("actor", "critic"):
         for k, p in getattr(pol, net).named_parameters():
             np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"lastgrad.{net}.{k}"], rtol=2e-3, atol=2e-6)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-5)
+
+
+def test_ppo_learn_with_gae_and_per_dimension_covariance(tg, dev):
+    g = load_golden("ppo_gae_step_u2.npz")
+    pol = tg.GaussianActorCritic_NeuralNetwork(10, 2, (32, 32), cov=[float(c) for c in g["cov"]], device=dev)
+    sd = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    pol.load_state_dict({"actor": {k[6:]: v for k, v in sd.items() if k.startswith("actor.")},
+                         "critic": {k[7:]: v for k, v in sd.items() if k.startswith("critic.")}})
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    algo = tg.PPO(epsilon=float(g["epsilon"]), policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2,
+                  c1=float(g["c1"]), kl_coeff=float(g["kl_coeff"]), gamma=float(g["gamma"]), lam=float(g["lam"]),
+                  entropy=float(g["entropy_coeff"]), batch_size=None, monte_carlo=False)
+    algo.learn(_buffer_from_golden(g))
+    st = algo.last_stats
+    np.testing.assert_allclose(st["total_loss"], g["total_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(st["critic_loss"], g["critic_loss"], rtol=2e-5, atol=2e-6)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
             np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-5)
 
 

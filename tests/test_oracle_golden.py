@@ -24,6 +24,17 @@ def test_single_step_matches_reference(name):
     assert trunc.sum() > 8 and (~trunc).sum() > 100
 
 
+@pytest.mark.parametrize("tag,name", [("cartpole_custom", "CartPole"), ("quadpole2d_custom", "QuadPole2D")])
+def test_single_step_with_non_default_constructor_arguments(tag, name):
+    g = load_golden(f"env_step_{tag}.npz")
+    kw = {k[len("param_"):]: float(g[k]) for k in g if k.startswith("param_")}
+    nxt, rew, trunc, _, _ = E.ENV_SPECS[name]["step"](
+        g["state"], g["action"], g["steps"], g["time_balanced"], max_steps=int(g["max_steps"]), **kw)
+    np.testing.assert_allclose(nxt, g["next_state"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(rew, g["reward"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(trunc, g["truncated"])
+
+
 def test_cartpole_upright_known_answer():
     # reference tests/test_cartpole.py:91-104: upright, zero action -> 0 < r < 5 (closed form 2.8)
     nxt, rew, trunc, _, tb = E.cartpole_step(np.array([[0, 0, 0, 1, 0.0]]), np.zeros((1, 1), np.float32), [0], [0.0])
@@ -162,3 +173,18 @@ def test_ppo_step(n_upd):
         for k, p in getattr(pol, net).named_parameters():
             np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)
             np.testing.assert_allclose(p.grad.numpy(), g[f"lastgrad.{net}.{k}"], rtol=1e-3, atol=1e-6)
+
+
+def test_ppo_step_with_gae_and_per_dimension_covariance():
+    g = load_golden("ppo_gae_step_u2.npz")
+    pol = _policy_from_golden(g, "init.", 10, 2, (32, 32), [float(c) for c in g["cov"]], True)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    t = lambda k: torch.from_numpy(g[k])
+    logs = L.ppo_learn(pol, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=float(g["epsilon"]),
+                       gamma=float(g["gamma"]), lam=float(g["lam"]), c1=float(g["c1"]), kl_coeff=float(g["kl_coeff"]),
+                       entropy_coeff=float(g["entropy_coeff"]), updates_per_iter=2, monte_carlo=False)
+    np.testing.assert_allclose([l["total"] for l in logs], g["total_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([l["critic"] for l in logs], g["critic_loss"], rtol=1e-5, atol=1e-6)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
+            np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)
