@@ -222,29 +222,36 @@ def main():
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     relu_probe = None
     if rank == 0 and cdt is not None:
-        # the hand-written kernel with the most GPU time in the update (28 %): ReLU-backward + bias gradient,
-        # one pass over dA (r/w) and A (r): 3 x 512 B per row at 256 bf16 features
-        import ctypes as C
+        # the hand-written kernel with the most GPU time in the update: a hidden layer's backward-data product fused
+        # with the ReLU backward + bias gradient below it (tg_dx_relu_bias).  Algorithmic traffic: read dZ and A,
+        # write dZ_below = 3 x 512 B per row at 256 bf16 features; timed at the learner's chunk size.
         N_ = tg._native
-        rows, cols = 1 << 20, 256
-        dA = torch.randn(rows, cols, device=dev).to(cdt)
+        lib_ = N_.load()
+        rows, cols = 1 << 22, 256
+        dZ = (torch.randn(rows, cols, device=dev) * 0.5).to(cdt)
         A_ = torch.relu(torch.randn(rows, cols, device=dev)).to(cdt)
-        part = torch.empty(N_.load().tg_relu_bwd_bias_blocks(), cols, dtype=torch.float32, device=dev)
+        W_ = (torch.randn(cols, cols, device=dev) / 16).to(cdt)
+        frag = torch.empty(cols * cols, dtype=cdt, device=dev)
+        out_ = torch.empty_like(A_)
+        part = torch.empty(lib_.tg_dx_relu_bias_blocks(), cols, dtype=torch.float32, device=dev)
         st = N_.stream_ptr(dev)
+        N_.check(lib_.tg_dx_pack_weights(W_.data_ptr(), frag.data_ptr(), cols, cols, st))
+        run = lambda: N_.check(lib_.tg_dx_relu_bias(dZ.data_ptr(), frag.data_ptr(), A_.data_ptr(), out_.data_ptr(), rows, cols,
+                                                    cols, part.data_ptr(), st))
         for _ in range(3):
-            N_.check(N_.load().tg_relu_bwd_bias(dA.data_ptr(), A_.data_ptr(), rows, cols, 1, part.data_ptr(), st))
+            run()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(20):
-            N_.check(N_.load().tg_relu_bwd_bias(dA.data_ptr(), A_.data_ptr(), rows, cols, 1, part.data_ptr(), st))
+        for _ in range(10):
+            run()
         b.record()
         torch.cuda.synchronize()
-        us = a.elapsed_time(b) * 1e3 / 20
+        us = a.elapsed_time(b) * 1e3 / 10
         gbs = 3.0 * rows * cols * 2 / us / 1e3
-        relu_probe = {"kernel": "tg::relu_bwd_bias_bf16_kernel", "bound": "hbm", "rows": rows, "cols": cols,
+        relu_probe = {"kernel": "tg::dx_relu_bias_kernel<256,256,1,8>", "bound": "hbm", "rows": rows, "cols": cols,
                       "us_per_launch": us, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                      "bytes_per_row": 3 * cols * 2}
-        del dA, A_, part
+                      "bytes_per_row": 3 * cols * 2, "TFLOPs": 2.0 * rows * cols * cols / us / 1e6}
+        del dZ, A_, W_, frag, out_, part
     fused_all_alive = None
     if rank == 0 and mgr.engine.fused:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes

@@ -227,6 +227,20 @@ int  tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, i
 int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, void* d_dz,
                            int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream);
 
+/* A hidden layer's backward-data product on the matrix cores, fused with the ReLU backward and the bias gradient
+ * of the layer below (bf16 operands, fp32 accumulate; replaces `dA = dZ @ W` + tg_relu_bwd_bias):
+ *   dZ_below[r][m] = (sum_{k<k_dim} dZ[r][k] * W[k][m]) * (A[r][m] > 0)
+ *   d_partial f32 [tg_dx_relu_bias_blocks()][m_dim]: per-workgroup column sums of dZ_below (caller sums axis 0).
+ * d_dz_in bf16 [rows][k_dim], d_act / d_dz_out bf16 [rows][m_dim] (row-major, contiguous, distinct buffers),
+ * W = Linear.weight bf16 [k_dim = out_features][m_dim = in_features].  d_wfrag is W re-ordered by
+ * tg_dx_pack_weights (k_dim*m_dim bf16, MFMA A-fragment order; rebuild it whenever W changes).
+ * tg_dx_relu_bias_supported(k_dim, m_dim) != 0 for the shapes that have a kernel (square 64 / 128 / 256). */
+int  tg_dx_relu_bias_supported(int32_t k_dim, int32_t m_dim);
+int  tg_dx_relu_bias_blocks(void);
+int  tg_dx_pack_weights(const void* d_w, void* d_wfrag, int32_t k_dim, int32_t m_dim, void* stream);
+int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, void* d_dz_out, int64_t rows,
+                     int32_t k_dim, int32_t m_dim, float* d_partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

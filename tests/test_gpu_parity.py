@@ -599,6 +599,36 @@ def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
     assert not tg.mlp.supports(tg.NeuralNetwork(S, A, hidden, "Tanh"))
 
 
+@pytest.mark.parametrize("width", [64, 128, 256])
+@pytest.mark.parametrize("rows", [1, 1000, 70001])
+def test_fused_backward_data_relu_bias_kernel(tg, dev, width, rows):
+    """tg_dx_relu_bias against the two-pass formulation it replaces (dA = dZ @ W; dZ_below = dA * (A > 0); column sums)."""
+    Nn = tg._native
+    lib = Nn.load()
+    assert lib.tg_dx_relu_bias_supported(width, width) and not lib.tg_dx_relu_bias_supported(width, 2 * width)
+    gen = torch.Generator(device="cpu").manual_seed(width + rows)
+    dz = (torch.randn(rows, width, generator=gen) * 0.5).to(torch.bfloat16).to(dev)
+    W = (torch.randn(width, width, generator=gen) / width ** 0.5).to(torch.bfloat16).to(dev)
+    act = torch.relu(torch.randn(rows, width, generator=gen)).to(torch.bfloat16).to(dev)
+    act[0, :5] = torch.tensor([0.0, -0.0, 1e-30, 1.0, 0.0], dtype=torch.bfloat16)      # signed zero, tiny positive
+    frag = torch.empty(width * width, dtype=torch.bfloat16, device=dev)
+    Nn.check(lib.tg_dx_pack_weights(W.data_ptr(), frag.data_ptr(), width, width, Nn.stream_ptr(dev)))
+    out = torch.full((rows, width), float("nan"), dtype=torch.bfloat16, device=dev)
+    partial = torch.full((lib.tg_dx_relu_bias_blocks(), width), float("nan"), dtype=torch.float32, device=dev)
+    Nn.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), act.data_ptr(), out.data_ptr(), rows, width, width,
+                                 partial.data_ptr(), Nn.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    exact = (dz.double() @ W.double()) * (act > 0)
+    got = out.double()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got == 0, exact.to(torch.bfloat16) == 0) or ((got == 0) == (exact == 0)).float().mean() > 0.9999
+    # one bf16 rounding of an fp32-accumulated sum: <= 2^-8 relative (+ accumulation noise far below that)
+    assert torch.all((got - exact).abs() <= 2.0 ** -8 * exact.abs() + 1e-6)
+    assert torch.all(got[act <= 0] == 0)
+    # the bias-gradient partials add up to the column sums of what was written
+    np.testing.assert_allclose(partial.sum(0).cpu().numpy(), got.sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4 * rows ** 0.5)
+
+
 def test_learners_fall_back_to_autograd_for_non_relu_nets(tg, dev):
     """A Tanh policy cannot use the GEMM chain; learn() must still run (torch autograd path) and move the weights."""
     torch.manual_seed(5)

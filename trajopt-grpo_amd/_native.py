@@ -73,6 +73,10 @@ SIGNATURES = {
     "tg_relu_bwd_bias_blocks": (C.c_int, []),
     "tg_relu_bwd_bias": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "tg_head_bwd_relu_bias": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "tg_dx_relu_bias_supported": (C.c_int, [_I32, _I32]),
+    "tg_dx_relu_bias_blocks": (C.c_int, []),
+    "tg_dx_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
+    "tg_dx_relu_bias": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
 }
 
 _lib = None

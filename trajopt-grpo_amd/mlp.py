@@ -57,6 +57,15 @@ class GemmMLP:
             self.b.append(torch.zeros(o, dtype=compute_dtype, device=dev))
         self._acts = None
         self._partial = None
+        # hidden layers whose backward-data product runs fused with the ReLU backward below it (tg_dx_relu_bias)
+        self._dxfrag = [None] * len(self.linears)
+        if compute_dtype == torch.bfloat16:
+            lib = N.load()
+            for i in range(1, len(self.linears) - 1):
+                o, k = self.w[i].shape
+                if lib.tg_dx_relu_bias_supported(o, k):
+                    self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
+        self._dx_partial = None
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
         self.refresh()
 
@@ -67,6 +76,10 @@ class GemmMLP:
                 w[:l.out_features, :l.in_features].copy_(l.weight)
                 b[:l.out_features].copy_(l.bias)
             self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
+            for w, frag in zip(self.w, self._dxfrag):
+                if frag is not None:
+                    N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
+                                                        N.stream_ptr(w.device)), "tg_dx_pack_weights")
 
     def prepare_input(self, X: torch.Tensor) -> torch.Tensor:
         """[M][in_dim] (any float dtype, any strides) -> contiguous [M][in_pad] compute dtype, zero padded."""
@@ -125,28 +138,39 @@ class GemmMLP:
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0
         nblk = lib.tg_relu_bwd_bias_blocks()
         fuse_head = self.out_dim <= 8
-        da = None if fuse_head else dz @ self.w[-1]
+        st = N.stream_ptr(dout.device)
         for i in range(L - 2, -1, -1):
-            a = acts[i + 1]
+            a = acts[i + 1]                                    # post-ReLU output of hidden layer i
             cols = a.shape[1]
-            if self._partial is None or self._partial.shape[1] != cols:
-                self._partial = torch.empty(nblk, cols, dtype=torch.float32, device=dout.device)
-            if i == L - 2 and fuse_head:
-                # top hidden layer: dA = dout . W_head is a rank-A product, formed inside the ReLU-backward kernel
-                da = torch.empty_like(a)
-                N.check(lib.tg_head_bwd_relu_bias(dout.data_ptr(), self.out_dim, self.linears[-1].weight.data_ptr(),
-                                                  a.data_ptr(), da.data_ptr(), rows, cols, is_bf16,
-                                                  self._partial.data_ptr(), N.stream_ptr(dout.device)),
-                        "tg_head_bwd_relu_bias")
+            frag = self._dxfrag[i + 1] if i < L - 2 else None
+            if frag is not None:
+                # dZ_i = (dZ_{i+1} W_{i+1}) * (a > 0) and its column sums in one pass on the matrix cores
+                if self._dx_partial is None or self._dx_partial.shape[1] != cols:
+                    self._dx_partial = torch.empty(lib.tg_dx_relu_bias_blocks(), cols, dtype=torch.float32, device=dout.device)
+                partial = self._dx_partial
+                dz_below = torch.empty_like(a)
+                N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), a.data_ptr(), dz_below.data_ptr(), rows,
+                                            dz.shape[1], cols, partial.data_ptr(), st), "tg_dx_relu_bias")
+                dz = dz_below
             else:
-                N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, self._partial.data_ptr(),
-                                             N.stream_ptr(dout.device)), "tg_relu_bwd_bias")
+                if self._partial is None or self._partial.shape[1] != cols:
+                    self._partial = torch.empty(nblk, cols, dtype=torch.float32, device=dout.device)
+                partial = self._partial
+                if i == L - 2 and fuse_head:
+                    # top hidden layer: dA = dout . W_head is a rank-A product, formed inside the ReLU-backward kernel
+                    da = torch.empty_like(a)
+                    N.check(lib.tg_head_bwd_relu_bias(dout.data_ptr(), self.out_dim, self.linears[-1].weight.data_ptr(),
+                                                      a.data_ptr(), da.data_ptr(), rows, cols, is_bf16, partial.data_ptr(), st),
+                            "tg_head_bwd_relu_bias")
+                else:
+                    da = dz @ self.w[i + 1]
+                    N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, partial.data_ptr(), st),
+                            "tg_relu_bwd_bias")
+                dz = da
             lin = self.linears[i]
-            lin.bias.grad.add_(self._partial.sum(0))
-            dw = self._dw(da, acts[i])
+            lin.bias.grad.add_(partial.sum(0))
+            dw = self._dw(dz, acts[i])
             lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
-            if i > 0:
-                da = da @ self.w[i]
         self._acts = None
 
 
