@@ -241,6 +241,20 @@ int  tg_dx_pack_weights(const void* d_w, void* d_wfrag, int32_t k_dim, int32_t m
 int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, void* d_dz_out, int64_t rows,
                      int32_t k_dim, int32_t m_dim, float* d_partial, void* stream);
 
+/* ---- MLP forward, all layers in one persistent launch (models/neural_network.py:67-77) ----
+ * Linear(in<=32, H) ReLU [Linear(H, H) ReLU]^(n_hidden_layers-1) Linear(H, out<=out_cols), H in {128, 256}, bf16
+ * operands, fp32 accumulate / bias / head output.  A row's activations stay on chip between layers and are only
+ * written (for the backward pass):
+ *   d_x      bf16 [rows][32]   input, features >= in zero-padded
+ *   d_wfrag  bf16 weight stream in MFMA fragment order (trajopt-grpo_amd/mlp.py `FragmentStream(layout="chain")`
+ *            documents and builds it), d_bias f32 [n_hidden_layers + 1][H] (natural order, head row zero-padded)
+ *   d_acts   HOST array of n_hidden_layers device pointers, bf16 [rows][H] each (post-ReLU outputs of the hidden
+ *            layers, row-major), or NULL to skip storing them
+ *   d_out    f32 [rows][out_cols], out_cols in {8, 16} (columns >= out hold the padded head rows: zeros + bias 0) */
+int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden,
+                          int32_t n_hidden_layers, int64_t rows, void* const* d_acts, float* d_out,
+                          int32_t out_cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Time tg_mlp_forward_chain (all layers, one launch) against the per-layer GEMM chain on the bench's actor shape."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import trajopt_grpo_amd as tg  # noqa: E402
+from trajopt_grpo_amd.mlp import GemmMLP  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, nargs="+", default=[1 << 20, 1 << 22])
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    net = tg.NeuralNetwork(20, 4, (a.hidden,) * a.layers, "ReLU").to(dev)
+    mlp = GemmMLP(net, torch.bfloat16)
+    H, L = a.hidden, a.layers
+    flop_row = 2.0 * (32 * H + (L - 1) * H * H + H * 32)
+    res = []
+    for rows in a.rows:
+        xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
+        out = {"rows": rows}
+        for keep in (True, False):
+            chain = mlp._chain
+            t_c = timed(lambda: mlp.forward(xp, keep=keep, padded=True), a.iters)
+            mlp._chain = None
+            t_l = timed(lambda: mlp.forward(xp, keep=keep, padded=True), a.iters)
+            mlp._chain = chain
+            k = "keep" if keep else "nokeep"
+            out[f"chain_{k}_us"], out[f"layers_{k}_us"] = t_c, t_l
+            out[f"chain_{k}_TFLOPs"] = flop_row * rows / t_c / 1e6
+            if keep:
+                out["chain_keep_write_GBps"] = rows * (L * H * 2 + 32) / t_c / 1e3
+        res.append(out)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

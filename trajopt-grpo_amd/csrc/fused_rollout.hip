@@ -49,6 +49,28 @@ __device__ static inline void dma_block(const uint4* __restrict__ gblock, uint4*
     }
 }
 
+// Accumulator start values: rows (r&3) + 8(r>>2) + 4h of a 32-row tile, `b` = tile base + 4h.  The `__restrict__`
+// parameter of this inlined function gives its LDS reads alias-scope metadata; without it hipcc makes an LDS read wait
+// for EVERY outstanding LDS-DMA (vmcnt(0)), draining the weight ring (it did, in the first-layer and head blocks).
+__device__ static inline f32x16 bias_rows(const float* __restrict__ b) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b + 8 * q);
+        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+    }
+    return acc;
+}
+
+// First-layer B fragment from a bf16 feature row in LDS: element j of lane half h is feature 16 ks + 8 (j>>2) + 4 h + (j&3);
+// `p` = row + 16 ks + 4 h.  (`__restrict__` for the same reason as bias_rows.)
+__device__ static inline bf16x8 x_fragment(const unsigned short* __restrict__ p) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(p);
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + 8);
+    const uint4 v = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 #define TG_STAGE_ADVANCE                                                                      \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * (KS / WPW)) : "memory");               \
     __builtin_amdgcn_s_barrier();                                                             \
@@ -186,13 +208,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
         for (int tile = 0; tile < NT; ++tile) {
             const unsigned short* row = xs + (wave * 64 + tile * 32 + col) * 32;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // element j of lane half h is feature 16*ks + 8*(j>>2) + 4*h + (j&3)
-                const uint2 lo = *reinterpret_cast<const uint2*>(row + 16 * ks + 4 * h);
-                const uint2 hi = *reinterpret_cast<const uint2*>(row + 16 * ks + 8 + 4 * h);
-                const uint4 v = {lo.x, lo.y, hi.x, hi.y};
-                xin[tile][ks] = __builtin_bit_cast(bf16x8, v);
-            }
+            for (int ks = 0; ks < 2; ++ks) xin[tile][ks] = x_fragment(row + 16 * ks + 4 * h);
         }
 
         // ---- layer 1: [H x 32] . [32 x 64 envs]; one block holds all MT output tiles (2 k-steps each) ----
@@ -203,12 +219,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int tile = 0; tile < NT; ++tile) {
-                        f32x16 acc;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + 32 * mt + 8 * q + 4 * h);
-                            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-                        }
+                        f32x16 acc = bias_rows(bias_s + 32 * mt + 4 * h);
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
@@ -236,12 +247,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
                 if (wave_alive) {
 #pragma unroll
                     for (int tile = 0; tile < NT; ++tile) {
-                        f32x16 acc;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * mt + 8 * q + 4 * h);
-                            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-                        }
+                        f32x16 acc = bias_rows(bl + 32 * mt + 4 * h);
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
                             const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
@@ -281,12 +287,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
             f32x16 acc2[NT];
 #pragma unroll
             for (int tile = 0; tile < NT; ++tile) {
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(bl + 8 * q + 4 * h);
-                    acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-                }
+                f32x16 acc = bias_rows(bl + 4 * h);
                 if (wave_alive) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {

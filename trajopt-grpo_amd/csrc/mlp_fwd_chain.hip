@@ -1,0 +1,278 @@
+// Forward pass of the reference's ReLU MLP (models/neural_network.py:48-77: Linear(S,H) ReLU [Linear(H,H) ReLU]*
+// Linear(H,A)) for 10^6..10^7 rows in ONE persistent launch that keeps a row's activations on chip from the input to
+// the head and only WRITES them (the backward pass needs them): 64 B read + (L-1)*2H + 4*out_cols B written per row
+// (2.6 KB at 20-256x5-4) against 5.2 KB for a chain of per-layer GEMMs, each of which re-reads what the previous
+// one wrote.  With the HBM traffic halved the pass is bound by the matrix cores (557 kflop/row).
+//
+// Same machinery as fused_rollout.hip: transposed product Y^T = W . X^T with v_mfma_f32_32x32x16_bf16, 32 rows per
+// wave (the MFMA columns), a layer's accumulator tile IS the next layer's B operand (bias-init, ReLU, bf16 pack), the
+// weights stream L2 -> LDS by LDS-DMA through a ring shared by the 8 waves of the workgroup.  What differs:
+//   * the fragment rows are permuted so that the 16 accumulator registers of lane (n, h) in output tile mt are the 16
+//     CONSECUTIVE features 32 mt + 16 h + 0..15 of row n: an activation store is 2 x 16 B per lane and tile, and the
+//     k-order of the next layer's A fragments is 8 contiguous weights per lane (mlp.ChainStream packs them);
+//   * the input tile (32 rows x 32 padded features, bf16) also arrives by LDS-DMA, one round ahead, so that no
+//     ordinary global load sits in the loop (hipcc would drain the ring with vmcnt(0) at its first use); for the
+//     same reason every LDS read in the loop carries alias-scope metadata or is opaque to the compiler (see
+//     bias_tile / lds_read_b128_opaque): a plain LDS read makes hipcc wait for ALL outstanding LDS-DMA;
+//   * vector-memory operations retire in issue order, stores included, so the counted wait of the ring must allow
+//     for the stores issued since the block it waits for: every block issues AT LEAST 2 stores per wave, always
+//     (rows past the end are clamped to the last row and rewrite it with identical bytes), hence
+//     vmcnt(2 P + (P-1) KS/WPW) is never too weak and at most a few stores too strict.
+#include "tg_common.hpp"
+
+namespace tg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int kChainMaxHidden = 8;
+struct ChainActs { uint16_t* p[kChainMaxHidden]; };
+
+template <int KS, int WPW>
+__device__ static inline void chain_dma_block(const uint4* __restrict__ gblock, uint4* __restrict__ slot, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < KS / WPW; ++q) {
+        const int piece = q * WPW + wave;
+        __builtin_amdgcn_global_load_lds(gblock + piece * 64 + lane, (lds_void_t*)(slot + piece * 64), 16, 0, 0);
+    }
+}
+
+// A lane (n, h) holds features 16 h + 0..15 of its row's 32-feature tile as two 16-B halves (lo, hi).  Stored as they
+// stand, one instruction would write two separate 16-B pieces per row; after swapping the upper lanes' lo with the
+// lower lanes' hi (v_permlane32_swap) each instruction writes 32 contiguous bytes per row: half the write requests.
+// `p` = row base + 32 mt + 8 h (elements).
+__device__ static inline void store_tile(uint16_t* p, bf16x8 lo, bf16x8 hi) {
+    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(a.z, b.z, false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(a.w, b.w, false, false);
+    *reinterpret_cast<uint4*>(p) = uint4{s0[0], s1[0], s2[0], s3[0]};          // features  0..15 of the tile: h = 0 | h = 1 halves
+    *reinterpret_cast<uint4*>(p + 16) = uint4{s0[1], s1[1], s2[1], s3[1]};     // features 16..31
+}
+
+// Accumulator start values = the tile's 32 biases (LDS table), 16 per lane half.  `__restrict__` on an inlined
+// function's pointer parameters is what gives its LDS reads alias-scope metadata; hipcc makes an LDS read WITHOUT it
+// wait for every outstanding LDS-DMA (vmcnt(0)), which would drain the weight ring at each block.
+__device__ static inline f32x16 bias_tile(const float* __restrict__ b16) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b16 + 4 * q);
+        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+    }
+    return acc;
+}
+
+// 16 B from LDS without telling the compiler it is an LDS read (same reason); waits for it itself.
+__device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint4*)p;
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+
+#define TG_CHAIN_ADVANCE                                                                           \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitN) : "memory");                                  \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    asm volatile("" ::: "memory");                                                                 \
+    chain_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane); \
+    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                         \
+    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                             \
+    const uint4* cur = ring + cur_slot * KS * 64;                                                  \
+    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+
+// x [rows][32] bf16 (features >= in_dim zero); acts.p[l] [rows][H] bf16 for hidden layer l (kStore); out f32
+// [rows][out_cols], out_cols in {8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
+template <int H, int WPW, bool kStore, int D>
+__global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                                                    const float* __restrict__ bias, int32_t n_hh, int64_t rows,
+                                                                    ChainActs acts, float* __restrict__ out, int32_t out_cols) {
+    constexpr int MT = H / 32, KS = H / 16;
+    constexpr int P = D - 1;
+    constexpr int kWaitN = (kStore ? 2 * P : 0) + (P - 1) * (KS / WPW);
+    static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
+    extern __shared__ uint4 lds[];
+    uint4* ring = lds;                                                  // D * KS * 64 uint4
+    float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
+    uint4* xs = reinterpret_cast<uint4*>(bias_s + (n_hh + 2) * H);      // WPW waves * 2 pieces * 64 uint4
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int64_t n_rounds = (rows + 32 * WPW - 1) / (32 * WPW);
+    const int n_blocks = n_hh * MT + 2;
+
+    for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
+    __syncthreads();                                  // bias table in place; no DMA outstanding yet
+
+    uint4* my_xs = xs + wave * 128;
+    auto dma_x = [&](int64_t round) {
+        // 32 rows x 64 B = two 1-KiB pieces; lane -> row 16 p + (lane >> 2), 16-B chunk lane & 3 (lands row-major)
+        const int64_t base = round * (32 * WPW) + wave * 32;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int64_t r = base + 16 * p + (lane >> 2);
+            r = r < rows ? r : rows - 1;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(x) + r * 4 + (lane & 3), (lds_void_t*)(my_xs + 64 * p), 16, 0,
+                                             0);
+        }
+    };
+
+    int pre_pos = 0, pre_slot = 0, cur_slot = 0;
+    dma_x(blockIdx.x);
+    for (int b0 = 0; b0 < P; ++b0) {                  // blocks 0..P-1 in flight before the first round
+        chain_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
+        pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
+    }
+    // the counted wait assumes the stores of three earlier blocks behind the block it waits for; before the first
+    // block there are none, so the prologue is drained once
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+        int64_t row = round * (32 * WPW) + wave * 32 + col;
+        row = row < rows ? row : rows - 1;            // clamped rows recompute and rewrite the last row (identical bytes)
+        bf16x8 xin[KS], xout[KS];
+
+        // ---- layer 0: [H x 32] . [32 x 32 rows]; one block holds all MT output tiles (2 k-steps each) ----
+        {
+            TG_CHAIN_ADVANCE
+            // the x tile was issued a full round ago (or in the prologue): it is older than everything the wait let pass
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xin[ks] = __builtin_bit_cast(bf16x8, lds_read_b128_opaque(my_xs + col * 4 + 2 * ks + h));
+            dma_x(round + gridDim.x);                 // next round's tile (clamped past the end)
+            uint16_t* ap = kStore ? acts.p[0] + row * H + 8 * h : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 acc = bias_tile(bias_s + 32 * mt + 16 * h);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
+                    xout[2 * mt + sh] = o;
+                }
+                if (kStore) store_tile(ap + 32 * mt, xout[2 * mt], xout[2 * mt + 1]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
+        }
+        // ---- hidden H x H layers: one block per 32-feature output tile ----
+        for (int l = 0; l < n_hh; ++l) {
+            const float* bl = bias_s + (l + 1) * H + 16 * h;
+            uint16_t* ap = kStore ? acts.p[l + 1] + row * H + 8 * h : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                TG_CHAIN_ADVANCE
+                f32x16 acc = bias_tile(bl + 32 * mt);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
+                    xout[2 * mt + sh] = o;
+                }
+                if (kStore) store_tile(ap + 32 * mt, xout[2 * mt], xout[2 * mt + 1]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
+        }
+        // ---- head: 32 padded output rows; features 0..15 are registers 0..15 of the h == 0 lanes ----
+        {
+            TG_CHAIN_ADVANCE
+            f32x16 acc = bias_tile(bias_s + (n_hh + 1) * H + 16 * h);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+            }
+            // the h == 1 lanes (features 16..31: padding) take their partner's values and write the same bytes again
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = __shfl(acc[r], col, 64);
+            float* op = out + row * out_cols;
+            *reinterpret_cast<float4*>(op) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(op + 4) = float4{v[4], v[5], v[6], v[7]};
+            if (out_cols == 16) {
+                *reinterpret_cast<float4*>(op + 8) = float4{v[8], v[9], v[10], v[11]};
+                *reinterpret_cast<float4*>(op + 12) = float4{v[12], v[13], v[14], v[15]};
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+template <int H, bool kStore, int D>
+static int chain_launch(const void* x, const void* wfrag, const float* bias, int n_hh, int64_t rows, const ChainActs& acts, float* out,
+                        int out_cols, hipStream_t st) {
+    constexpr int WPW = 8, KS = H / 16;
+    const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048;
+    auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D>;
+    static size_t attr_bytes = 0;
+    if (shmem > 64 * 1024 && shmem > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(TG_ERR_HIP, "tg_mlp_forward_chain: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
+        }
+        attr_bytes = shmem;
+    }
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+    }
+    const int64_t n_rounds = ceil_div(rows, (int64_t)32 * WPW);
+    const unsigned grid = (unsigned)(n_rounds < cus ? n_rounds : cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint16_t*)x, (const uint4*)wfrag, bias, n_hh, rows, acts, out,
+                       out_cols);
+    TG_LAUNCH_CHECK("tg_mlp_forward_chain");
+    return TG_OK;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
+                         int64_t rows, void* const* d_acts, float* d_out, int32_t out_cols, void* stream) {
+    TG_REQUIRE(d_x && d_wfrag && d_bias && d_out, "tg_mlp_forward_chain: null pointer");
+    TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_forward_chain: hidden width %d unsupported (128, 256)", hidden);
+    TG_REQUIRE(n_hidden_layers >= 1 && n_hidden_layers <= kChainMaxHidden, "tg_mlp_forward_chain: %d hidden layers outside 1..%d",
+               n_hidden_layers, kChainMaxHidden);
+    TG_REQUIRE(out_cols == 8 || out_cols == 16, "tg_mlp_forward_chain: out_cols %d must be 8 or 16", out_cols);
+    TG_REQUIRE(rows >= 0, "tg_mlp_forward_chain: negative row count");
+    if (rows == 0) return TG_OK;
+    ChainActs acts{};
+    if (d_acts)
+        for (int l = 0; l < n_hidden_layers; ++l) {
+            TG_REQUIRE(d_acts[l], "tg_mlp_forward_chain: activation buffer %d is null", l);
+            acts.p[l] = (uint16_t*)d_acts[l];
+        }
+    hipStream_t st = (hipStream_t)stream;
+    const int n_hh = n_hidden_layers - 1;
+#define TG_CHAIN_ARGS d_x, d_wfrag, d_bias, n_hh, rows, acts, d_out, out_cols, st
+    // ring of 4 slots, 3 blocks in flight (6 and 8 slots measured the same)
+    if (hidden == 256) return d_acts ? chain_launch<256, true, 4>(TG_CHAIN_ARGS) : chain_launch<256, false, 4>(TG_CHAIN_ARGS);
+    return d_acts ? chain_launch<128, true, 4>(TG_CHAIN_ARGS) : chain_launch<128, false, 4>(TG_CHAIN_ARGS);
+#undef TG_CHAIN_ARGS
+}
+
+}  // extern "C"

@@ -66,6 +66,11 @@ class GemmMLP:
                 if lib.tg_dx_relu_bias_supported(o, k):
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
+        # all layers of the forward pass in one launch (tg_mlp_forward_chain) when the shape allows
+        self._chain = None
+        H = fused_rollout_supported(net, min(self.in_dim, 32), 1) if compute_dtype == torch.bfloat16 else 0
+        if H and self.in_dim <= 32 and self.out_pad <= 16 and len(self.linears) - 1 <= 8:
+            self._chain = FragmentStream(net, H, layout="chain")
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
         self.refresh()
 
@@ -76,6 +81,8 @@ class GemmMLP:
                 w[:l.out_features, :l.in_features].copy_(l.weight)
                 b[:l.out_features].copy_(l.bias)
             self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
+            if self._chain is not None:
+                self._chain.refresh()
             for w, frag in zip(self.w, self._dxfrag):
                 if frag is not None:
                     N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
@@ -91,9 +98,19 @@ class GemmMLP:
     def forward(self, xp: torch.Tensor, keep: bool = True, padded: bool = False) -> torch.Tensor:
         """-> fp32 [rows][out_dim] (contiguous), or the [rows][out_pad] buffer itself with padded=True
         (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward()."""
+        L = len(self.linears)
+        if self._chain is not None and xp.shape[0] > 0:
+            rows, H = xp.shape[0], self._chain.H
+            hid = [torch.empty(rows, H, dtype=self.cd, device=xp.device) for _ in range(L - 1)] if keep else []
+            out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
+            ptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in hid]) if keep else None
+            N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
+                                                  L - 1, rows, ptrs, out.data_ptr(), self.out_pad, N.stream_ptr(xp.device)),
+                    "tg_mlp_forward_chain")
+            self._acts = [xp] + hid if keep else None
+            return out if padded else out[:, :self.out_dim].contiguous()
         acts = [xp]
         h = xp
-        L = len(self.linears)
         for i in range(L - 1):
             h = torch._addmm_activation(self.b[i], h, self.w[i].t())       # bias + ReLU in the GEMM epilogue
             acts.append(h)
@@ -197,19 +214,36 @@ def _fragment_index(k_pad: int, device):
     return 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
 
 
-class FragmentStream:
-    """bf16 weight stream + f32 bias table in the layout tg_fused_rollout consumes, refreshed from the fp32
-    master weights with one gather (the permutation is built once)."""
+def _chain_fragment_index(k_pad: int, device, first: bool):
+    """Same shape for tg_mlp_forward_chain: the first layer reads its input in natural order (16*ks + 8*h + j);
+    later layers take the previous accumulators, whose 16 registers per lane are CONSECUTIVE features there:
+    32*(ks>>1) + 16*h + 8*(ks&1) + j."""
+    ks = torch.arange(k_pad // 16, device=device).view(-1, 1, 1)
+    h = (torch.arange(64, device=device) >> 5).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    return 16 * ks + 8 * h + j if first else 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j
 
-    def __init__(self, net, H: int):
+
+class FragmentStream:
+    """bf16 weight stream + f32 bias table in the layout tg_fused_rollout (layout="rollout") or
+    tg_mlp_forward_chain (layout="chain") consumes, refreshed from the fp32 master weights with one gather (the
+    permutation is built once).  Blocks: the first layer's output tiles (2 k-steps each), then one block per
+    32-row output tile of every later layer; a block = its k-steps x 64 lanes x 8 bf16 (1 KiB per k-step).
+    Lane (m, h) of a fragment holds 8 weights of output row `32*tile + row(m)`: row(m) = m for the rollout kernel;
+    for the chain kernel row(m) = 16*((m>>2)&1) + 4*(m>>3) + (m&3), which makes a lane's 16 accumulator registers
+    16 consecutive output features."""
+
+    def __init__(self, net, H: int, layout: str = "rollout"):
+        assert layout in ("rollout", "chain")
         self.lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
         dev = self.lin[0].weight.device
         self.H = H
-        row = (torch.arange(64, device=dev) & 31).view(1, -1, 1)
+        m = torch.arange(64, device=dev) & 31
+        row = (m if layout == "rollout" else 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)).view(1, -1, 1)
         flat_idx, self._slices, off = [], [], 0
-        for l in self.lin:
+        for li, l in enumerate(self.lin):
             m_pad, k_pad = _round_up(l.out_features, 32), _round_up(l.in_features, 32)
-            kidx = _fragment_index(k_pad, dev)                               # [KSl][64][8]
+            kidx = _fragment_index(k_pad, dev) if layout == "rollout" else _chain_fragment_index(k_pad, dev, li == 0)
             for mo in range(m_pad // 32):
                 flat_idx.append((off + (32 * mo + row).expand_as(kidx) * k_pad + kidx).reshape(-1))
             self._slices.append((off, m_pad, k_pad))
