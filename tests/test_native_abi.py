@@ -160,3 +160,46 @@ def test_fragment_stream_layout_is_the_mfma_a_fragment_order():
         lin[1].weight.add_(1.0)
     fs.refresh()
     assert float(fs.stream.float().view(-1, 64, 8)[KS + 3, 5, 2]) == expect(lin[1].weight, 128, 128, 0, 3, 5, 2)
+
+
+def test_chain_fragment_stream_layout_gives_every_lane_consecutive_features():
+    """Host logic of tg_mlp_forward_chain's weight stream (mlp.FragmentStream(layout="chain")), checked on CPU.
+    Fragment row m of a 32-row output tile carries feature 16*((m>>2)&1) + 4*(m>>3) + (m&3): accumulator register r of
+    lane half h is row (r&3) + 8*(r>>2) + 4h of the MFMA tile, which is then feature 16h + r.  The k order of a later
+    layer follows: 32*(ks>>1) + 16h + 8*(ks&1) + j; the first layer reads its input in natural order."""
+    torch.manual_seed(1)
+    net = tg.NeuralNetwork(20, 4, (128, 128), "ReLU")
+    fs = tg.mlp.FragmentStream(net, 128, layout="chain")
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    KS = 128 // 16
+    st = fs.stream.float().view(-1, 64, 8)
+    assert st.shape[0] == (1 + 4 + 1) * KS
+
+    # the permutation is what the kernel assumes: D-layout row of (h, r)  ->  fragment row m  ->  feature 16h + r
+    for h in range(2):
+        for r in range(16):
+            m = (r & 3) + 8 * (r >> 2) + 4 * h
+            assert 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) == 16 * h + r
+
+    def expect(W, mo, ks, lane, j, first):
+        m, h = lane & 31, lane >> 5
+        r = 32 * mo + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)
+        c = 16 * ks + 8 * h + j if first else 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j
+        if r >= W.shape[0] or c >= W.shape[1]:
+            return 0.0
+        return float(W[r, c].to(torch.bfloat16))
+
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        mo, ks, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(st[mo * 2 + ks, lane, j]) == expect(lin[0].weight, mo, ks, lane, j, True)
+    for _ in range(300):
+        mo, ks, lane, j = rng.integers(4), rng.integers(KS), rng.integers(64), rng.integers(8)
+        assert float(st[KS + mo * KS + ks, lane, j]) == expect(lin[1].weight, mo, ks, lane, j, False)
+    for _ in range(300):
+        ks, lane, j = rng.integers(KS), rng.integers(64), rng.integers(8)
+        assert float(st[5 * KS + ks, lane, j]) == expect(lin[2].weight, 0, ks, lane, j, False)
+    # every weight appears exactly once per layer: the stream is a permutation of the zero-padded matrices
+    w1 = torch.zeros(128, 128)
+    w1.copy_(lin[1].weight.detach().to(torch.bfloat16).float())
+    assert torch.equal(torch.sort(st[KS:5 * KS].reshape(-1))[0], torch.sort(w1.reshape(-1))[0])
