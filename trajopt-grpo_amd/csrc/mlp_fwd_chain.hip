@@ -8,16 +8,17 @@
 // wave (the MFMA columns), a layer's accumulator tile IS the next layer's B operand (bias-init, ReLU, bf16 pack), the
 // weights stream L2 -> LDS by LDS-DMA through a ring shared by the 8 waves of the workgroup.  What differs:
 //   * the fragment rows are permuted so that the 16 accumulator registers of lane (n, h) in output tile mt are the 16
-//     CONSECUTIVE features 32 mt + 16 h + 0..15 of row n: an activation store is 2 x 16 B per lane and tile, and the
-//     k-order of the next layer's A fragments is 8 contiguous weights per lane (mlp.ChainStream packs them);
+//     CONSECUTIVE features 32 mt + 16 h + 0..15 of row n (32 B of its row), and the k-order of the next layer's A
+//     fragments is 8 contiguous weights per lane (mlp.FragmentStream(layout="chain") packs them); every second tile
+//     the wave transposes its 32 rows x 128 B through LDS and stores whole 128-B lines (store_pair);
 //   * the input tile (32 rows x 32 padded features, bf16) also arrives by LDS-DMA, one round ahead, so that no
 //     ordinary global load sits in the loop (hipcc would drain the ring with vmcnt(0) at its first use); for the
 //     same reason every LDS read in the loop carries alias-scope metadata or is opaque to the compiler (see
 //     bias_tile / lds_read_b128_opaque): a plain LDS read makes hipcc wait for ALL outstanding LDS-DMA;
 //   * vector-memory operations retire in issue order, stores included, so the counted wait of the ring must allow
-//     for the stores issued since the block it waits for: every block issues AT LEAST 2 stores per wave, always
-//     (rows past the end are clamped to the last row and rewrite it with identical bytes), hence
-//     vmcnt(2 P + (P-1) KS/WPW) is never too weak and at most a few stores too strict.
+//     for the stores issued since the block it waits for.  The stores are unconditional (rows past the end are
+//     clamped to the last row and rewrite it with identical bytes) and their number per block is a compile-time
+//     pattern (4 after every odd tile), so every wait site has its own exact count.
 #include "tg_common.hpp"
 
 namespace tg {
@@ -38,20 +39,6 @@ __device__ static inline void chain_dma_block(const uint4* __restrict__ gblock, 
     }
 }
 
-// A lane (n, h) holds features 16 h + 0..15 of its row's 32-feature tile as two 16-B halves (lo, hi).  Stored as they
-// stand, one instruction would write two separate 16-B pieces per row; after swapping the upper lanes' lo with the
-// lower lanes' hi (v_permlane32_swap) each instruction writes 32 contiguous bytes per row: half the write requests.
-// `p` = row base + 32 mt + 8 h (elements).
-__device__ static inline void store_tile(uint16_t* p, bf16x8 lo, bf16x8 hi) {
-    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
-    const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-    const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-    const auto s2 = __builtin_amdgcn_permlane32_swap(a.z, b.z, false, false);
-    const auto s3 = __builtin_amdgcn_permlane32_swap(a.w, b.w, false, false);
-    *reinterpret_cast<uint4*>(p) = uint4{s0[0], s1[0], s2[0], s3[0]};          // features  0..15 of the tile: h = 0 | h = 1 halves
-    *reinterpret_cast<uint4*>(p + 16) = uint4{s0[1], s1[1], s2[1], s3[1]};     // features 16..31
-}
-
 // Accumulator start values = the tile's 32 biases (LDS table), 16 per lane half.  `__restrict__` on an inlined
 // function's pointer parameters is what gives its LDS reads alias-scope metadata; hipcc makes an LDS read WITHOUT it
 // wait for every outstanding LDS-DMA (vmcnt(0)), which would drain the weight ring at each block.
@@ -65,6 +52,46 @@ __device__ static inline f32x16 bias_tile(const float* __restrict__ b16) {
     return acc;
 }
 
+// Activation stores.  After two output tiles a lane (n, h) holds 4 x 16 B of row n's 128-B line (tile t, half h, 16-B
+// piece sh at byte 64 t + 32 h + 16 sh).  Stored as they stand an instruction would write 32 rows x 32 B, and that
+// pattern alone caps at 4.1 TB/s on this chip; so the wave transposes the 32 x 128 B through its LDS staging area
+// (pitch 144 B: conflict-free b128 writes, 2-way reads) and each of its 4 store instructions writes 8 WHOLE 128-B lines
+// (5.1 TB/s for the same bytes).  `__restrict__`: see bias_tile.  Rows past the end are clamped: the lanes that
+// computed them worked on the last row's input, so they rewrite the last row with identical bytes.
+__device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
+                                         int lane, bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi) {
+    uint4* w = st + (lane & 31) * 9 + 2 * (lane >> 5);
+    w[0] = __builtin_bit_cast(uint4, a_lo);
+    w[1] = __builtin_bit_cast(uint4, a_hi);
+    w[4] = __builtin_bit_cast(uint4, b_lo);
+    w[5] = __builtin_bit_cast(uint4, b_hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), c = lane & 7;
+        const uint4 v = st[r * 9 + c];
+        int64_t row = row0 + r;
+        row = row < rows ? row : rows - 1;
+        *reinterpret_cast<uint4*>(g + row * ld + 8 * c) = v;
+    }
+}
+
+// One 32-feature output tile of a hidden layer: bias-init, K/16 MFMAs against the block's fragments, ReLU, bf16 pack.
+template <int KS>
+__device__ static inline void chain_tile(const uint4* __restrict__ cur, const float* __restrict__ b16, const bf16x8 (&xin)[KS],
+                                         bf16x8& lo, bf16x8& hi, int lane) {
+    f32x16 acc = bias_tile(b16);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[j], 0.0f, __builtin_inff());
+        hi[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 + j], 0.0f, __builtin_inff());
+    }
+}
+
 // 16 B from LDS without telling the compiler it is an LDS read (same reason); waits for it itself.
 __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint4*)p;
@@ -73,8 +100,10 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
     return v;
 }
 
-#define TG_CHAIN_ADVANCE                                                                           \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitN) : "memory");                                  \
+__device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
+
+#define TG_CHAIN_ADVANCE(WAITN)                                                                    \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                                   \
     __builtin_amdgcn_s_barrier();                                                                  \
     asm volatile("" ::: "memory");                                                                 \
     chain_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane); \
@@ -91,12 +120,19 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                                                                     ChainActs acts, float* __restrict__ out, int32_t out_cols) {
     constexpr int MT = H / 32, KS = H / 16;
     constexpr int P = D - 1;
-    constexpr int kWaitN = (kStore ? 2 * P : 0) + (P - 1) * (KS / WPW);
+    // counted wait for block c: all but the youngest N vector-memory operations have retired.  Behind DMA(c) there are
+    // always the DMAs of the P-1 later blocks, plus the activation stores of the last P blocks: 4 per ODD output tile
+    // (store_pair), none per even one -- two odd tiles lie behind an even site, one behind an odd site.  (At the layer
+    // boundaries, the first-layer block with its 2 MT stores and the head with its 2-4 only ever add to that.)
+    static_assert(P == 3, "the store counts below are for a window of three blocks");
+    constexpr int kWaitEven = (P - 1) * (KS / WPW) + (kStore ? 8 : 0);
+    constexpr int kWaitOdd = (P - 1) * (KS / WPW) + (kStore ? 4 : 0);
     static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
     extern __shared__ uint4 lds[];
     uint4* ring = lds;                                                  // D * KS * 64 uint4
     float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
     uint4* xs = reinterpret_cast<uint4*>(bias_s + (n_hh + 2) * H);      // WPW waves * 2 pieces * 64 uint4
+    uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 9);    // per wave: 32 rows x 144 B (store_pair)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
@@ -131,18 +167,18 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
-        int64_t row = round * (32 * WPW) + wave * 32 + col;
+        const int64_t row0 = round * (32 * WPW) + wave * 32;
+        int64_t row = row0 + col;
         row = row < rows ? row : rows - 1;            // clamped rows recompute and rewrite the last row (identical bytes)
         bf16x8 xin[KS], xout[KS];
 
         // ---- layer 0: [H x 32] . [32 x 32 rows]; one block holds all MT output tiles (2 k-steps each) ----
         {
-            TG_CHAIN_ADVANCE
+            TG_CHAIN_ADVANCE(kWaitOdd)
             // the x tile was issued a full round ago (or in the prologue): it is older than everything the wait let pass
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) xin[ks] = __builtin_bit_cast(bf16x8, lds_read_b128_opaque(my_xs + col * 4 + 2 * ks + h));
             dma_x(round + gridDim.x);                 // next round's tile (clamped past the end)
-            uint16_t* ap = kStore ? acts.p[0] + row * H + 8 * h : nullptr;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 f32x16 acc = bias_tile(bias_s + 32 * mt + 16 * h);
@@ -158,7 +194,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                     for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
                     xout[2 * mt + sh] = o;
                 }
-                if (kStore) store_tile(ap + 32 * mt, xout[2 * mt], xout[2 * mt + 1]);
+                if (kStore && (mt & 1))
+                    store_pair(stage, acts.p[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
+                               xout[2 * mt + 1]);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
@@ -166,31 +204,25 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         // ---- hidden H x H layers: one block per 32-feature output tile ----
         for (int l = 0; l < n_hh; ++l) {
             const float* bl = bias_s + (l + 1) * H + 16 * h;
-            uint16_t* ap = kStore ? acts.p[l + 1] + row * H + 8 * h : nullptr;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                TG_CHAIN_ADVANCE
-                f32x16 acc = bias_tile(bl + 32 * mt);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+                if (mt & 1) {
+                    TG_CHAIN_ADVANCE(kWaitOdd)
+                    chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
+                    if (kStore)
+                        store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1],
+                                   xout[2 * mt], xout[2 * mt + 1]);
+                } else {
+                    TG_CHAIN_ADVANCE(kWaitEven)
+                    chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
                 }
-#pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
-                    xout[2 * mt + sh] = o;
-                }
-                if (kStore) store_tile(ap + 32 * mt, xout[2 * mt], xout[2 * mt + 1]);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
         }
         // ---- head: 32 padded output rows; features 0..15 are registers 0..15 of the h == 0 lanes ----
         {
-            TG_CHAIN_ADVANCE
+            TG_CHAIN_ADVANCE(kWaitEven)
             f32x16 acc = bias_tile(bias_s + (n_hh + 1) * H + 16 * h);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -217,7 +249,8 @@ template <int H, bool kStore, int D>
 static int chain_launch(const void* x, const void* wfrag, const float* bias, int n_hh, int64_t rows, const ChainActs& acts, float* out,
                         int out_cols, hipStream_t st) {
     constexpr int WPW = 8, KS = H / 16;
-    const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048;
+    const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048 +
+                         (size_t)WPW * 32 * 144;
     auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D>;
     static size_t attr_bytes = 0;
     if (shmem > 64 * 1024 && shmem > attr_bytes) {
