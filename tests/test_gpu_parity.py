@@ -677,6 +677,20 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     assert float((out_c - out_l).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
 
 
+def test_weight_gradient_split_k_paths_agree(tg, dev):
+    """GemmMLP._dw: the fixed-batch-count split (>= 2^19 rows) and the fixed-block split below it against one fp32 GEMM."""
+    from trajopt_grpo_amd.mlp import GemmMLP
+    net = tg.NeuralNetwork(20, 4, (64, 64), "ReLU").to(dev)
+    m = GemmMLP(net, torch.bfloat16)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for rows in (128 * 4096 + 1777, 3 * 8192 + 5, 100):
+        dz = torch.randn(rows, 64, generator=gen).to(torch.bfloat16).to(dev)
+        a = torch.randn(rows, 32, generator=gen).to(torch.bfloat16).to(dev)
+        ref = dz.double().t() @ a.double()
+        got = m._dw(dz, a).double()
+        assert float((got - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_learners_fall_back_to_autograd_for_non_relu_nets(tg, dev):
     """A Tanh policy cannot use the GEMM chain; learn() must still run (torch autograd path) and move the weights."""
     torch.manual_seed(5)

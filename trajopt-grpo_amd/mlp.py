@@ -21,6 +21,7 @@ import torch
 from . import _native as N
 
 _ROW_BLOCK = 8192
+_SPLIT_BATCHES = 128
 
 
 def supports(net) -> bool:
@@ -125,16 +126,20 @@ class GemmMLP:
     def _dw(self, dz: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         """dz^T a in fp32 via a batched GEMM over row blocks (split-K with fp32 partials)."""
         rows = dz.shape[0]
-        nb = rows // _ROW_BLOCK
+        if rows >= _SPLIT_BATCHES * 4096:
+            # big batches: a fixed number of row blocks (2 output tiles each: every CU busy) keeps the fp32 partials --
+            # written once, read once by the reduction -- at 128 x 256 KB whatever the row count (3 % at 4 M rows)
+            nb, bs = _SPLIT_BATCHES, (rows // _SPLIT_BATCHES) // 64 * 64
+        else:
+            nb, bs = rows // _ROW_BLOCK, _ROW_BLOCK
         out = None
+        main = nb * bs
         if nb > 0:
-            main = nb * _ROW_BLOCK
-            p = torch.bmm(dz[:main].view(nb, _ROW_BLOCK, dz.shape[1]).transpose(1, 2),
-                          a[:main].view(nb, _ROW_BLOCK, a.shape[1]), out_dtype=torch.float32)
+            p = torch.bmm(dz[:main].view(nb, bs, dz.shape[1]).transpose(1, 2), a[:main].view(nb, bs, a.shape[1]),
+                          out_dtype=torch.float32)
             out = p.sum(0)
-        if rows - nb * _ROW_BLOCK > 0:
-            tail = torch.mm(dz[nb * _ROW_BLOCK:].t(), a[nb * _ROW_BLOCK:], out_dtype=torch.float32) \
-                if self.cd != torch.float32 else dz[nb * _ROW_BLOCK:].t() @ a[nb * _ROW_BLOCK:]
+        if rows - main > 0:
+            tail = torch.mm(dz[main:].t(), a[main:], out_dtype=torch.float32) if self.cd != torch.float32 else dz[main:].t() @ a[main:]
             out = tail if out is None else out + tail
         return out
 
