@@ -35,7 +35,7 @@ extern "C" {
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
 /* environments (environments/cartpole_env.py, environments/quadrotor_env.py) */
-enum { TG_ENV_CARTPOLE = 0, TG_ENV_QUADPOLE2D = 1, TG_ENV_QUADPOLE = 2, TG_ENV_QUADROTOR12 = 3 };
+enum { TG_ENV_CARTPOLE = 0, TG_ENV_QUADPOLE2D = 1, TG_ENV_QUADPOLE = 2, TG_ENV_QUADROTOR12 = 3, TG_ENV_PENDULUM = 4 };
 /* arithmetic type of the environment state / trajectory */
 enum { TG_F32 = 0, TG_F64 = 1 };
 
@@ -48,12 +48,17 @@ enum { TG_F32 = 0, TG_F64 = 1 };
  *                                         p9 bound
  *  QUADROTOR12(quadrotor_env.py:9-16):   p0 mass, p1 arm_length, p2 Ixx, p3 Iyy, p4 Izz,
  *                                         p5 torque_constant, p6 gravity
+ *  PENDULUM   (pendulum_env.py:8-16):    p0 mass, p1 length, p2 gravity, p3 swingup (0 / 1); p4 is filled by
+ *                                         tg_env_finalize_params: the number of CONSECUTIVE balanced steps after which
+ *                                         the float-accumulated `_time_balanced` first exceeds 5 s (:135, :151).
+ *                                         Pendulum is the one env whose episodes TERMINATE (balanced for > 5 s); in a
+ *                                         rollout the running count lives in d_len as a negative number.
  * agents: rollout kernels only.  With agents = k > 1, every k consecutive env slots form ONE environment of k
  *  bodies that share the policy and terminate together: when any body truncates, all k stop at that step
  *  (segmented wavefront ballot).  The reference's QuadrotorSwarm is an empty subclass (quadrotor_env.py:185-186),
  *  so this semantics is defined by this build and has no oracle beyond k = 1 == the plain env.
- * time_trunc_step: CartPole only -- first step count at which the reference's
- *  float-accumulated `_time > max_time` fires (cartpole_env.py:168); filled by
+ * time_trunc_step: CartPole and Pendulum -- first step count at which the reference's
+ *  float-accumulated `_time > max_time` fires (cartpole_env.py:168, pendulum_env.py:150); filled by
  *  tg_env_default_params / tg_env_finalize_params. */
 typedef struct tg_env_params {
     int32_t env_id;
@@ -70,7 +75,7 @@ typedef struct tg_traj {
     float*    d_act;      /* f32  [A][T][n]   (policies emit float32: actor_critic.py:138) */
     void*     d_rew;      /* real [T][n] */
     uint8_t*  d_mask;     /* u8   [T][n] */
-    int32_t*  d_len;      /* i32  [n]; 0 while the episode is running */
+    int32_t*  d_len;      /* i32  [n]; <= 0 while the episode is running (0; Pendulum: -balanced steps), else its length */
     uint64_t* d_counters; /* u64  [4]: [0] env-steps executed (= sum of mask), [1] episodes ended */
     int64_t   n;
     int32_t   horizon;    /* T = env.max_steps */

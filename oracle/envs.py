@@ -344,12 +344,73 @@ def quadrotor_dynamics(state, control, dtype=np.float64):
 
 
 # ---------------------------------------------------------------------------
+# Pendulum  (environments/pendulum_env.py) -- the one env whose episode can TERMINATE:
+# `terminated = _time_balanced > 5` (:151).  It returns (obs, reward, truncated, terminated,
+# info) in that order (:158), which the worker unpacks as (.., terminated, truncated, ..)
+# (rollout_worker.py:56) -- harmless, `done` is their disjunction.
+# ---------------------------------------------------------------------------
+PENDULUM_DEFAULTS = dict(mass=1.0, length=0.5, gravity=9.80665, timestep=0.05)   # pendulum_env.py:12-15
+PENDULUM_BALANCE_TIME = 5.0                                                         # :151
+
+
+def pendulum_balance_term_steps(timestep: float = 0.05, limit: float = PENDULUM_BALANCE_TIME) -> int:
+    """Smallest number k of CONSECUTIVE balanced steps after which `_time_balanced > 5` holds
+    (`_time_balanced = _time_balanced + timestep if cos_theta <= -0.99 else 0`, :135, fp64-accumulated)."""
+    tb, k = 0, 0
+    while True:
+        k += 1
+        tb = tb + timestep
+        if tb > limit:
+            return k
+
+
+def pendulum_step(state, action, steps, time_balanced, *, max_steps=200, mass=1.0, length=0.5,
+                  gravity=9.80665, timestep=0.05, dtype=np.float64):
+    """One Pendulum.step for N envs.  pendulum_env.py:45-46 (_wrap_action), :48-74 (_dynamics), :124-158 (step).
+
+    Returns (next_state (N,3), reward, truncated (time only, :150), steps_next, time_balanced_next);
+    the episode also ends when time_balanced_next > 5 (:151, ENV_SPECS['Pendulum']['balance_terminates'])."""
+    R = dtype
+    state = np.asarray(state, dtype=R)
+    a32 = np.clip(np.asarray(action, dtype=F32).reshape(len(state), 1), F32(-1), F32(1))   # :46 float32
+    u = a32[:, 0].astype(R)               # float32 array - np.float64 scalar promotes to float64 (:63)
+    s, c, thd = (state[:, i] for i in range(3))                                  # :56
+    thd = np.clip(thd, R(-10), R(10))                                            # :57
+    theta = np.arctan2(s, c)                                                     # :59
+    g_term = R(mass * gravity * length) * np.sin(theta)                          # python-float product first (:61)
+    alpha = R(1 / (mass * length ** 2)) * (u - g_term)                           # :61
+    dt = R(timestep)
+    thd_n = thd + alpha * dt                                                     # :63
+    theta_n = theta + thd_n * dt                                                 # :64
+    s_n, c_n = np.sin(theta_n), np.cos(theta_n)
+    nxt = np.stack([s_n, c_n, thd_n], axis=1)                                    # :68-72
+
+    steps_n = np.asarray(steps).astype(np.int64) + 1                             # :133
+    balanced = c_n <= R(-0.99)                                                   # :135
+    tb = np.where(balanced, np.asarray(time_balanced, dtype=R) + dt, R(0))
+    energy32 = F32(-0.001) * (a32 ** 2).sum(axis=1, dtype=F32)                   # float32 (weak python scalar), :145
+    e1 = R(-10) * np.abs(R(-1) - c_n) ** R(0.5)                                  # :143
+    e2 = R(-0.1) * thd_n ** 2                                                    # :144
+    reward = dt * ((e1 + e2) + energy32.astype(R))                               # np.sum of a 3-list, :142
+    reward = np.where(tb > 0, reward + R(1), reward)                             # :148-149
+    truncated = steps_n >= cartpole_time_trunc_step(max_steps, timestep)         # :150, float-accumulated time
+    return nxt, reward, truncated, steps_n, tb
+
+
+def pendulum_reset(theta0, dtype=np.float64):
+    """pendulum_env.py:86-106: [sin t0, cos t0, 0]; t0 ~ U(pi-0.05, pi+0.05), or U(-pi, pi) with swingup=True."""
+    theta0 = np.asarray(theta0, dtype=dtype)
+    return np.stack([np.sin(theta0), np.cos(theta0), np.zeros_like(theta0)], axis=1)
+
+
+# ---------------------------------------------------------------------------
 # registry used by tests / the port worker
 # ---------------------------------------------------------------------------
 ENV_SPECS = {
     "CartPole": dict(obs_dim=5, act_dim=1, step=cartpole_step, timestep=0.02),
     "QuadPole2D": dict(obs_dim=10, act_dim=2, step=quadpole2d_step, timestep=0.02),
     "QuadPole": dict(obs_dim=20, act_dim=4, step=quadpole_step, timestep=0.02),
+    "Pendulum": dict(obs_dim=3, act_dim=1, step=pendulum_step, timestep=0.05, balance_terminates=PENDULUM_BALANCE_TIME),
 }
 
 
@@ -363,4 +424,6 @@ def sample_initial_states(env_name, n, rng, dtype=np.float64):
     if env_name == "QuadPole":
         ab = rng.uniform(-1.0, 1.0, size=(n, 2))
         return quadpole_reset(ab[:, 0], ab[:, 1], dtype)
+    if env_name == "Pendulum":
+        return pendulum_reset(rng.uniform(np.pi - 0.05, np.pi + 0.05, size=n), dtype)
     raise KeyError(env_name)

@@ -113,10 +113,11 @@ class OraclePolicy:
 class OracleEnv:
     """One environment instance stepping through oracle.envs with N=1."""
 
-    def __init__(self, env_name, max_steps=500, rng=None):
+    def __init__(self, env_name, max_steps=500, rng=None, **params):
         self.env_name = env_name
         self.spec = E.ENV_SPECS[env_name]
         self.max_steps = max_steps
+        self.params = params                                  # constructor arguments of the reference env (masses, timestep, ...)
         self.obs_dim, self.act_dim = self.spec["obs_dim"], self.spec["act_dim"]
         self.rng = rng if rng is not None else np.random.default_rng()
         self.state = None
@@ -141,9 +142,10 @@ class OracleEnv:
     def step(self, action):
         nxt, rew, trunc, steps, tb = self.spec["step"](
             self.state, np.asarray(action, dtype=np.float32).reshape(1, -1),
-            np.array([self._steps]), np.array([self._tb]), max_steps=self.max_steps)
+            np.array([self._steps]), np.array([self._tb]), max_steps=self.max_steps, **self.params)
         self.state, self._steps, self._tb = nxt, int(steps[0]), float(tb[0])
-        return nxt[0], float(rew[0]), False, bool(trunc[0]), {}
+        limit = self.spec.get("balance_terminates")           # only Pendulum ever terminates (pendulum_env.py:151)
+        return nxt[0], float(rew[0]), bool(limit is not None and self._tb > limit), bool(trunc[0]), {}
 
 
 def run_episodes(env, policy, num_episodes, restart=False, initial_states=None,

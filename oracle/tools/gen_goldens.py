@@ -410,6 +410,91 @@ def gen_ppo_gae_step():
     print("PPO GAE total", out["total_loss"])
 
 
+# ---------------------------------------------------------------------------
+# 6. Pendulum: single steps incl. the balance-time termination, and in-process rollouts
+# ---------------------------------------------------------------------------
+def gen_pendulum():
+    from environments.pendulum_env import Pendulum  # noqa: E402  (reference)
+    rs = np.random.default_rng(424242)
+    variants = {
+        "default": dict(),
+        "custom": dict(mass=2.0, length=0.7, gravity=3.0, timestep=0.02),
+    }
+    for tag, kw in variants.items():
+        MAXS = 120
+        env = Pendulum(max_steps=MAXS, **kw)
+        dt = env.timestep
+        n = 192
+        ang = rs.uniform(-np.pi, np.pi, size=n)
+        ang[:64] = np.pi + rs.uniform(-0.2, 0.2, size=64)          # around the balance threshold cos <= -0.99 (0.1415 rad)
+        st = np.stack([np.sin(ang), np.cos(ang), rs.normal(size=n) * 3], axis=1)
+        st[:64, 2] = rs.normal(size=64) * 0.3
+        st[64:72, 2] = rs.choice([-14.0, 12.5, 10.0, -10.0], size=8)                # thetadot clamp
+        st[72:80, :2] *= rs.uniform(0.5, 1.5, size=(8, 1))                        # un-normalised (sin, cos)
+        act = (rs.normal(size=(n, 1)) * 0.9).astype(np.float32)
+        act[80:88] = np.where(rs.random((8, 1)) < 0.5, -3.0, 2.5)                  # |a| > 1 clipping
+        steps = rs.integers(0, MAXS - 1, size=n)
+        # `_time > max_time` with float-accumulated time: first true after k_tr steps (k_tr is MAXS or MAXS + 1)
+        t_acc, k_tr = 0, 0
+        while not t_acc > env.max_time:
+            t_acc += env.timestep
+            k_tr += 1
+        steps[88:96] = k_tr - 1 + rs.choice([-1, 0, 0, 1], size=8)              # the step lands on k_tr - 1, k_tr, k_tr + 1
+        # time_balanced as the reference accumulates it: k consecutive balanced steps, k around the 5 s limit
+        ks = rs.integers(0, 20, size=n)
+        k_lim = int(round(5.0 / dt))
+        ks[:64] = rs.choice([0, 1, k_lim - 2, k_lim - 1, k_lim, k_lim + 1], size=64)
+        tb = np.zeros(n)
+        for i in range(n):
+            t = 0
+            for _ in range(int(ks[i])):
+                t = t + dt
+            tb[i] = t
+        nxt, rew = np.zeros((n, 3)), np.zeros(n)
+        trunc, term = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)
+        tb_after, info_tb = np.zeros(n), np.zeros(n)
+        for i in range(n):
+            env.reset()
+            env.state_dict["pendulum"] = st[i].copy()
+            env._steps = int(steps[i])
+            env._time = 0
+            for _ in range(int(steps[i])):
+                env._time += env.timestep
+            env._time_balanced = tb[i] if ks[i] > 0 else 0
+            o, r, tr, te, info = env.step(act[i])                    # NOTE the order: truncated before terminated
+            nxt[i], rew[i], trunc[i], term[i] = np.asarray(o, dtype=np.float64), float(np.asarray(r).reshape(-1)[0]), bool(tr), bool(te)
+            tb_after[i], info_tb[i] = env._time_balanced, info["time_balanced"]
+        print("   sums", int(term.sum()), int(trunc.sum()), int((~term).sum()))
+        assert term.sum() > 4 and trunc.sum() > 3 and (~term).sum() > 100
+        np.savez_compressed(os.path.join(OUT, f"env_step_pendulum_{tag}.npz"), state=st, action=act, steps=steps,
+                            time_balanced=tb, max_steps=MAXS, next_state=nxt, reward=rew, truncated=trunc, terminated=term,
+                            time_balanced_after=tb_after, info_time_balanced=info_tb,
+                            **{f"param_{k}": v for k, v in kw.items()})
+        print("Pendulum", tag, "single-step: terminated", int(term.sum()), "truncated", int(trunc.sum()))
+
+    # rollouts through the reference RolloutManager: 'fall' = default physics (episodes run to the horizon),
+    # 'hold' = no gravity and a near-silent policy (the pendulum stays within the band: terminated at step 101)
+    out = {}
+    for tag, env_kw, cov, T in (("fall", dict(), 0.5, 64), ("hold", dict(gravity=0.0), 1e-4, 140)):
+        np.random.seed(21)
+        torch.manual_seed(21)
+        policy = GaussianActor_NeuralNetwork(3, 1, (32, 32), cov=cov)
+        if tag == "hold":
+            with torch.no_grad():
+                for prm in policy.actor.network[-1].parameters():
+                    prm.mul_(1e-3)
+        mgr = RolloutManager(env_fn=lambda: Pendulum(max_steps=T, **env_kw), policy=policy, restart=False, num_workers=2,
+                             num_episodes_per_worker=3, use_multiprocessing=False)
+        obs, act, rew, ln, mask = mgr.rollout()
+        out.update({f"{tag}_obs": obs.numpy(), f"{tag}_act": act.numpy(), f"{tag}_rew": rew.numpy(), f"{tag}_len": ln.numpy(),
+                    f"{tag}_mask": mask.numpy(), f"{tag}_cov": np.diag(policy.cov.numpy()), f"{tag}_max_steps": T,
+                    f"{tag}_gravity": env_kw.get("gravity", 9.80665)})
+        for k, v in sd_to_np(policy.state_dict()).items():
+            out[f"{tag}_policy.{k}"] = v
+        print("Pendulum rollout", tag, "lengths", ln.numpy().astype(int).tolist())
+    np.savez_compressed(os.path.join(OUT, "rollout_pendulum.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20250613)
@@ -418,6 +503,7 @@ def main():
     gen_policy()
     gen_learner(rng)
     gen_ppo_gae_step()
+    gen_pendulum()
     print("fixtures written to", OUT)
 
 

@@ -906,3 +906,123 @@ def test_reference_learner_can_consume_the_device_buffer(tg, dev):
     np.testing.assert_allclose(algo.last_stats["J"], Js, rtol=1e-3, atol=1e-5)
     for (k, p), q in zip(pol.actor.named_parameters(), cpu_pol.actor.parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=0, atol=5e-5)
+
+
+# --------------------------------------------------------------------------------------------
+# Pendulum: the env whose episodes terminate (time_balanced > 5)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["default", "custom"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+def test_pendulum_step_matches_reference_golden(tg, dev, tag, dtype, tol):
+    g = load_golden(f"env_step_pendulum_{tag}.npz")
+    kw = {k[len("param_"):]: float(g[k]) for k in g if k.startswith("param_")}
+    nx, rw, tr, sp, tb = native_step(tg, "Pendulum", g["state"], g["action"], g["steps"], g["time_balanced"],
+                                     int(g["max_steps"]), dtype, dev, **kw)
+    scale = 1.0 if dtype == torch.float64 else 20.0          # |thetadot| <= 10 + one step
+    np.testing.assert_allclose(nx, g["next_state"], rtol=tol, atol=tol * scale)
+    assert np.all(np.abs(rw - g["reward"]) <= tol * 50 * np.maximum(1.0, np.abs(g["reward"])))
+    assert np.array_equal(tr, g["truncated"]) and np.array_equal(sp, g["steps"] + 1)
+    if dtype == torch.float64:
+        np.testing.assert_allclose(tb, g["time_balanced_after"], rtol=0, atol=1e-12)
+        assert np.array_equal(tb > 5.0, g["terminated"])
+
+
+def test_pendulum_scalar_api_returns_truncated_before_terminated(tg, dev):
+    g = load_golden("env_step_pendulum_default.npz")
+    env = tg.Pendulum(max_steps=int(g["max_steps"]))
+    assert env.observation_space.shape == (3,) and env.action_space.shape == (1,)
+    i = int(np.flatnonzero(g["terminated"])[0])
+    k = int(round(g["time_balanced"][i] / 0.05))
+    env.set_state(g["state"][i])
+    env._steps = int(g["steps"][i])
+    env._steps_t.fill_(int(g["steps"][i]))
+    tbv = 0
+    for _ in range(k):
+        tbv = tbv + 0.05
+    env._tb_t.fill_(tbv)
+    obs, rew, truncated, terminated, info = env.step(g["action"][i])
+    np.testing.assert_allclose(obs, g["next_state"][i], rtol=1e-11, atol=1e-12)
+    assert rew == pytest.approx(float(g["reward"][i]), abs=1e-10)
+    assert (truncated, terminated) == (bool(g["truncated"][i]), True)
+    assert info["time_balanced"] == pytest.approx(float(g["info_time_balanced"][i]), abs=1e-12) and info["time_balanced"] > 5
+    o0, _ = env.reset()
+    assert abs(np.arctan2(o0[0], o0[1])) > np.pi - 0.0501 and o0[2] == 0          # near upright unless swingup
+
+
+@pytest.mark.parametrize("tag,T,ends", [("fall", 64, 64), ("hold", 140, 101)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_pendulum_rollout_matches_reference(tg, dev, tag, T, ends, fused):
+    """Teacher-forced (per-step kernels) and sampled fused rollouts.  'hold' (no gravity, near-silent policy) ends by
+    TERMINATION after 101 consecutive balanced steps; the count lives in len as a negative number while running."""
+    g = load_golden("rollout_pendulum.npz")
+    obs, act, rew, ln, mask = (g[f"{tag}_{k}"] for k in ("obs", "act", "rew", "len", "mask"))
+    G, Eps = ln.shape
+    env = tg.Pendulum(max_steps=T, gravity=float(g[f"{tag}_gravity"]))
+    pol = tg.GaussianActor_NeuralNetwork(3, 1, (32, 32), cov=float(g[f"{tag}_cov"][0]), device=dev)
+    pol.load_state_dict({k[len(f"{tag}_policy."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"{tag}_policy.")})
+    init = obs[:, :, 0, :].reshape(G * Eps, 3).astype(np.float64)
+    if not fused:
+        eng = tg.DeviceRollout(env, pol, G, Eps, dtype=torch.float64, seed=0)
+        tr = eng.run(initial_states=init, forced_actions=act.reshape(G * Eps, T, 1))
+        o2, a2, r2, l2, m2 = tr.to_reference()
+        assert np.array_equal(l2.numpy(), ln) and np.array_equal(m2.numpy(), mask) and np.all(ln == ends)
+        np.testing.assert_allclose(o2.numpy(), obs, rtol=0, atol=5e-4)
+        np.testing.assert_allclose(r2.numpy(), rew, rtol=2e-4, atol=2e-4)
+    else:
+        # sampled actions on the fused kernel (128-wide policy so that it is supported): same dynamics, own noise
+        pol = tg.GaussianActor_NeuralNetwork(3, 1, (128, 128), cov=float(g[f"{tag}_cov"][0]), device=dev)
+        with torch.no_grad():
+            for prm in pol.actor.network[-1].parameters():
+                prm.mul_(1e-3)
+        runs = []
+        for use_fused in (True, False):
+            eng = tg.DeviceRollout(env, pol, 4, 96, seed=3, compute_dtype=torch.bfloat16, fused=use_fused)
+            tr = eng.run(initial_states=np.tile(init, (64, 1)))
+            torch.cuda.synchronize()
+            runs.append(tr)
+            lens = tr.len.cpu().numpy()
+            assert np.all(lens > 0)
+            if tag == "hold":
+                # terminated by balance on both paths (a few envs may drift out of the band under their own noise and
+                # run on: then they end later, never earlier)
+                assert np.mean(lens == 101) > 0.9 and np.all(lens >= 101)
+            else:
+                assert np.all(lens == T)
+        # the two paths draw the same noise but round the policy differently (bf16 MFMA chain vs bf16 GEMMs)
+        assert float((runs[0].len == runs[1].len).float().mean()) > 0.97
+        same = (runs[0].len == runs[1].len).cpu().numpy()
+        np.testing.assert_allclose(runs[0].rew.cpu().numpy()[:, same], runs[1].rew.cpu().numpy()[:, same], rtol=0, atol=5e-2)
+
+
+def test_pendulum_balanced_count_survives_a_split_fused_rollout(tg, dev):
+    """tg_fused_rollout in two segments [0, 50) + [50, T): the consecutive-balanced-step count crosses the boundary in
+    d_len (negative while the episode runs), so the termination step and every recorded byte are those of one launch."""
+    g = load_golden("rollout_pendulum.npz")
+    T = 140
+    env = tg.Pendulum(max_steps=T, gravity=0.0)
+    pol = tg.GaussianActor_NeuralNetwork(3, 1, (128, 128), cov=1e-4, device=dev)
+    with torch.no_grad():
+        for prm in pol.actor.network[-1].parameters():
+            prm.mul_(1e-3)
+    init = np.tile(g["hold_obs"][:, :, 0, :].reshape(6, 3).astype(np.float64), (64, 1))
+    out = []
+    for split in (None, 50):
+        eng = tg.DeviceRollout(env, pol, 4, 96, seed=3, compute_dtype=torch.bfloat16, fused=True)
+        if split is None:
+            tr = eng.run(initial_states=init)
+        else:
+            eng.params = env.native_params()
+            with torch.cuda.device(dev):
+                eng._enqueue_prepare(init)
+                eng._enqueue_fused(0, split)
+                torch.cuda.synchronize()
+                mid = eng.traj.len.clone()
+                eng.rng[1] -= 1                              # _enqueue_fused advanced the rollout id; same keys for part two
+                eng._enqueue_fused(split, T)
+            tr = eng.traj
+            assert int((mid < 0).sum()) > 0.9 * mid.numel() and int(mid.min()) == -split      # running counts, negative
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (tr.obs, tr.act, tr.rew, tr.mask, tr.len)])
+    assert float((out[0][4] == 101).float().mean()) > 0.9
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)

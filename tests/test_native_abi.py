@@ -49,6 +49,14 @@ def test_env_dims_and_default_params_follow_the_reference():
     for ms in (10, 64, 100, 128, 256, 500):
         p = N.default_params(N.TG_ENV_CARTPOLE, ms)
         assert p.time_trunc_step == E.cartpole_time_trunc_step(ms) >= ms     # float-accumulated time clause
+    # Pendulum: defaults, the time clause and the balanced-step count behind `time_balanced > 5`
+    assert N.env_dims(N.TG_ENV_PENDULUM) == (3, 1)
+    p = N.default_params(N.TG_ENV_PENDULUM, 0)
+    assert p.max_steps == 200 and p.timestep == 0.05 and list(p.p)[:4] == [1.0, 0.5, 9.80665, 0.0]
+    assert p.time_trunc_step == E.cartpole_time_trunc_step(200, 0.05) and int(p.p[4]) == E.pendulum_balance_term_steps(0.05) == 101
+    p.timestep = 0.02
+    N.check(N.load().tg_env_finalize_params(C.byref(p)))
+    assert int(p.p[4]) == E.pendulum_balance_term_steps(0.02) == 251
 
 
 def test_errors_are_status_codes_with_messages():

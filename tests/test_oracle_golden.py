@@ -188,3 +188,38 @@ def test_ppo_step_with_gae_and_per_dimension_covariance():
     for net in ("actor", "critic"):
         for k, p in getattr(pol, net).named_parameters():
             np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)
+
+
+# --------------------------------------------------------------------------------------------
+# Pendulum: the env that can terminate (time_balanced > 5)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["default", "custom"])
+def test_pendulum_single_step_matches_reference(tag):
+    g = load_golden(f"env_step_pendulum_{tag}.npz")
+    kw = {k[len("param_"):]: float(g[k]) for k in g if k.startswith("param_")}
+    nxt, rew, trunc, _, tb = E.pendulum_step(g["state"], g["action"], g["steps"], g["time_balanced"],
+                                             max_steps=int(g["max_steps"]), **kw)
+    np.testing.assert_allclose(nxt, g["next_state"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(rew, g["reward"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(trunc, g["truncated"])
+    np.testing.assert_allclose(tb, g["time_balanced_after"], rtol=0, atol=1e-15)
+    assert np.array_equal(tb > E.PENDULUM_BALANCE_TIME, g["terminated"]) and g["terminated"].sum() > 4
+    # the balanced-step count at which the accumulated time first exceeds 5 s
+    dt = kw.get("timestep", 0.05)
+    k = E.pendulum_balance_term_steps(dt)
+    assert k == {0.05: 101, 0.02: 251}[dt]
+
+
+@pytest.mark.parametrize("tag,T,ends", [("fall", 64, 64), ("hold", 140, 101)])
+def test_pendulum_teacher_forced_rollout_matches_reference(tag, T, ends):
+    g = load_golden("rollout_pendulum.npz")
+    obs, act, rew, ln, mask = (g[f"{tag}_{k}"] for k in ("obs", "act", "rew", "len", "mask"))
+    G, Eps = ln.shape
+    assert int(g[f"{tag}_max_steps"]) == T and np.all(ln == ends)          # 'hold': terminated after 101 balanced steps
+    init = obs[:, :, 0, :].astype(np.float64)
+    o2, a2, r2, l2, m2 = L.rollout(lambda: L.OracleEnv("Pendulum", max_steps=T, gravity=float(g[f"{tag}_gravity"])), None, G, Eps,
+                                   initial_states=init, forced_actions=act)
+    assert np.array_equal(l2.numpy(), ln) and np.array_equal(m2.numpy(), mask)
+    # the initial state went through a float32 round trip in the fixture -> trajectories agree to fp32 noise
+    np.testing.assert_allclose(o2.numpy(), obs, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(r2.numpy(), rew, rtol=2e-4, atol=2e-4)

@@ -5,7 +5,7 @@ include/trajopt_grpo_hip.h, PyTorch-ROCm GEMMs for the MLP, and one RCCL gradien
 optimizer step.  Import as `trajopt_grpo_amd` (the directory name carries a hyphen).
 """
 from . import _native
-from .environments import Box, Env, CartPole, QuadPole, QuadPole2D, QuadPoleSwarm, Quadrotor, QuadrotorSwarm
+from .environments import Box, Env, CartPole, Pendulum, QuadPole, QuadPole2D, QuadPoleSwarm, Quadrotor, QuadrotorSwarm
 from .policies import (NeuralNetwork, ActorCritic, GaussianActor_NeuralNetwork,
                        GaussianActorCritic_NeuralNetwork)
 from .rollout import DeviceRollout, DeviceTrajectory, RolloutManager, RolloutWorker
@@ -16,7 +16,7 @@ from .pipelines import (Pipeline, create_cartpole_pipeline_grpo, create_cartpole
 from . import distributed, hip_ops
 
 __all__ = [
-    "Box", "Env", "CartPole", "QuadPole", "QuadPole2D", "QuadPoleSwarm", "Quadrotor", "QuadrotorSwarm",
+    "Box", "Env", "CartPole", "Pendulum", "QuadPole", "QuadPole2D", "QuadPoleSwarm", "Quadrotor", "QuadrotorSwarm",
     "NeuralNetwork", "ActorCritic", "GaussianActor_NeuralNetwork", "GaussianActorCritic_NeuralNetwork",
     "DeviceRollout", "DeviceTrajectory", "RolloutManager", "RolloutWorker", "Buffer", "Rollout_Buffer",
     "Algorithm", "GRPO", "PPO", "Pipeline", "create_cartpole_pipeline_grpo", "create_cartpole_pipeline_ppo",

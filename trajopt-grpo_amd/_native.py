@@ -15,10 +15,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
 
-TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12 = 0, 1, 2, 3
+TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
 ENV_IDS = {"CartPole": TG_ENV_CARTPOLE, "QuadPole2D": TG_ENV_QUADPOLE2D, "QuadPole": TG_ENV_QUADPOLE,
-           "Quadrotor": TG_ENV_QUADROTOR12}
+           "Quadrotor": TG_ENV_QUADROTOR12, "Pendulum": TG_ENV_PENDULUM}
 
 
 class NativeLibraryError(RuntimeError):

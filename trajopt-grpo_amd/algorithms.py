@@ -85,6 +85,12 @@ class _GpuLearner(Algorithm):
         self._mlps = {}
         self.last_stats = {}
 
+    def learn(self, buffer) -> None:
+        """One training iteration on `buffer` (algorithms/grpo.py:50-148, ppo.py:64-186).  The native kernels are
+        launched through ctypes on the policy's device: make it the current one for the duration."""
+        with torch.cuda.device(self.policy.device):
+            self._learn(buffer)
+
     @property
     def bucket(self) -> D.GradBucket:
         if self._bucket is None:
@@ -159,7 +165,7 @@ class GRPO(_GpuLearner):
         self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp)
         self.old_policy = copy.deepcopy(self.policy)                        # grpo.py:48
 
-    def learn(self, buffer) -> None:
+    def _learn(self, buffer) -> None:
         if self.ref_model is not None:
             raise NotImplementedError("the reference's ref_model branch mis-unpacks a 3-tuple (grpo.py:129-132) "
                                       "and never runs in shipped code; it is not reproduced")
@@ -254,7 +260,7 @@ class PPO(_GpuLearner):
         self._refresh(actor, critic)
         sums_out.append(sums)
 
-    def learn(self, buffer) -> None:
+    def _learn(self, buffer) -> None:
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         T, n = traj.T, traj.n

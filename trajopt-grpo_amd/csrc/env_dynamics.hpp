@@ -40,15 +40,20 @@ template <> struct Math<double> {
 __device__ static inline float clip1(float a) { return fminf(fmaxf(a, -1.0f), 1.0f); }
 
 struct StepOut {
-    bool truncated;   // env-level `truncated` (terminated is always False for these envs)
+    bool truncated;   // env-level `truncated`
     bool balanced;    // bonus condition held on the new state (drives info['time_balanced'])
 };
+// `terminated` is always False except for Pendulum, whose episode ends once it has been balanced for more than 5 s
+// (pendulum_env.py:151).  Such an env sets kBalanceTerminates and carries `term_steps` in its constants: the number
+// of CONSECUTIVE balanced steps after which the fp64-accumulated `_time_balanced` first exceeds the limit.  The
+// rollout kernels keep the running count (as -len[env] while the episode runs).
 
 // ---------------------------------------------------------------------------
 // CartPole swing-up.  cartpole_env.py:48-49, 51-92, 138-182.
 // ---------------------------------------------------------------------------
 template <typename R> struct CartPoleEnv {
     static constexpr int S = 5, A = 1;
+    static constexpr bool kBalanceTerminates = false;
     struct C {
         R mc, mp, l, g, dt;
         int max_steps, time_trunc_step;
@@ -112,6 +117,7 @@ template <typename R> struct CartPoleEnv {
 // ---------------------------------------------------------------------------
 template <typename R> struct QuadPole2DEnv {
     static constexpr int S = 10, A = 2;
+    static constexpr bool kBalanceTerminates = false;
     struct C {
         R mq_Lp, mpLp, M, g, dt, bound, balance_radius;
         float hover32, Lq_over_I32, dt32;
@@ -199,6 +205,7 @@ template <typename R> __device__ static inline void quat_mult(const R (&q)[4], c
 
 template <typename R> struct QuadPoleEnv {
     static constexpr int S = 20, A = 4;
+    static constexpr bool kBalanceTerminates = false;
     struct C {
         R m0, m_p, g, L, Ixx, Iyy, Izz, arm, dt, bound, tension_k, m0L, inv_m0, s22, mpL2;
         float hover32, tc32;
@@ -359,6 +366,65 @@ template <typename R> struct QuadPoleEnv {
         o[6] = 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[13 + i] = qp[i] / n;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Pendulum.  pendulum_env.py:45-46, 48-74, 124-158.
+// ---------------------------------------------------------------------------
+template <typename R> struct PendulumEnv {
+    static constexpr int S = 3, A = 1;
+    static constexpr bool kBalanceTerminates = true;
+    struct C {
+        R mgl, inv_ml2, dt;
+        int max_steps, time_trunc_step, term_steps, swingup;
+        __host__ static C make(const tg_env_params& p) {
+            C c;
+            const double mass = p.p[0], length = p.p[1], gravity = p.p[2];
+            c.mgl = (R)(mass * gravity * length);                             // python-float product, :61
+            c.inv_ml2 = (R)(1.0 / (mass * (length * length)));
+            c.dt = (R)p.timestep;
+            c.max_steps = p.max_steps; c.time_trunc_step = p.time_trunc_step;
+            c.swingup = p.p[3] != 0.0; c.term_steps = (int)p.p[4];
+            return c;
+        }
+    };
+
+    __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
+                                          R (&o)[S], R& reward) {
+        using M = Math<R>;
+        const float a32 = clip1(a[0]);                                        // :46 (float32, no scaling)
+        const R u = (R)a32;                                                   // promoted by the float64 scalar at :61
+        const R thd = fmin(fmax(s[2], (R)-10), (R)10);                        // :57
+        const R theta = M::atan2_(s[0], s[1]);                                // :59
+        R sn, cs;
+        M::sincos_(theta, &sn, &cs);
+        const R alpha = c.inv_ml2 * (u - c.mgl * sn);                         // :61
+        const R thd_n = thd + alpha * c.dt;                                   // :63
+        const R th_n = theta + thd_n * c.dt;                                  // :64
+        R sn_n, cs_n;
+        M::sincos_(th_n, &sn_n, &cs_n);
+        o[0] = sn_n; o[1] = cs_n; o[2] = thd_n;                               // :68-72
+        StepOut out;
+        out.balanced = cs_n <= (R)-0.99;                                      // :135
+        out.truncated = steps_after >= c.time_trunc_step;                     // :150, float-accumulated time
+        const float energy32 = rn_mul(-0.001f, rn_mul(a32, a32));           // float32 in the reference, :145
+        const R e1 = (R)-10 * M::sqrt_(M::abs_((R)-1 - cs_n));                // :143 (x ** 0.5)
+        const R e2 = (R)-0.1 * (thd_n * thd_n);                               // :144
+        R r = c.dt * ((e1 + e2) + (R)energy32);                               // :142
+        if (out.balanced) r += (R)1;                                          // :148-149 (time_balanced > 0 <=> balanced now)
+        reward = r;
+        return out;
+    }
+
+    // reset: theta0 ~ U(pi - 0.05, pi + 0.05), or U(-pi, pi) with swingup; state [sin, cos, 0].  :86-106
+    __device__ static inline void reset(const uint32_t (&rnd)[4], R (&o)[S]) { reset(rnd, o, 0); }
+    __device__ static inline void reset(const uint32_t (&rnd)[4], R (&o)[S], int swingup) {
+        const double u = Philox::u01d(rnd[0], rnd[1]);
+        const double th = swingup ? -3.141592653589793 + 6.283185307179586 * u : (3.141592653589793 - 0.05) + 0.1 * u;
+        R sn, cs;
+        Math<R>::sincos_((R)th, &sn, &cs);
+        o[0] = sn; o[1] = cs; o[2] = 0;
     }
 };
 

@@ -15,13 +15,14 @@ namespace tg {
 // ---------------------------------------------------------------------------
 template <typename Env, typename R>
 __global__ __launch_bounds__(256) void reset_kernel(R* __restrict__ state, int64_t ld, int64_t n, uint64_t seed,
-                                                    uint32_t stream_id, int64_t key_offset, int64_t key_div) {
+                                                    uint32_t stream_id, int64_t key_offset, int64_t key_div, int variant) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t rnd[4];
     Philox::draw(seed, (uint64_t)((key_offset + i) / key_div), 0xFFFFFFFFu /* sub = reset */, stream_id, rnd);
     R o[Env::S];
-    Env::reset(rnd, o);
+    if constexpr (Env::kBalanceTerminates) Env::reset(rnd, o, variant);   // Pendulum: swingup or near-upright start
+    else Env::reset(rnd, o);
 #pragma unroll
     for (int k = 0; k < Env::S; ++k) state[k * ld + i] = o[k];
 }
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
             for (int k = 0; k < A; ++k) a[k] = act[((int64_t)k * T + t) * n + ic];
         }
     }
-    const bool alive = in_range && (my_len == 0);
+    // len == 0 while the episode runs (for Pendulum: -(consecutive balanced steps so far), see StepOut)
+    const bool alive = in_range && (Env::kBalanceTerminates ? my_len <= 0 : my_len == 0);
     // wavefront-wide termination: if all 64 envs of this wave have ended, leave before touching the
     // trajectory again (wave-uniform branch, no divergence)
     if (__ballot(alive) == 0ull) return;
@@ -126,7 +128,13 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
     R r;
     const StepOut out = Env::step(s, a, c, t + 1, o, r);
     // the worker also stops at t == max_steps (rollout_worker.py:51); a swarm stops when any of its bodies does
-    const bool done = any_in_segment(alive && out.truncated, agents) || (t + 1 >= T);
+    bool ended = out.truncated;
+    int balanced_steps = 0;
+    if constexpr (Env::kBalanceTerminates) {
+        balanced_steps = out.balanced ? 1 - my_len : 0;
+        ended = ended || (balanced_steps >= c.term_steps);                  // terminated, pendulum_env.py:151
+    }
+    const bool done = any_in_segment(alive && ended, agents) || (t + 1 >= T);
     const bool carry = alive && !done;
     if (in_range) {
         // every lane of a live wave stores (zeros for ended envs, which is what the padding must hold):
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
 #pragma unroll
         for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = carry ? o[k] : (R)0;
         if (alive && done) len[i] = t + 1;
+        else if (Env::kBalanceTerminates && alive) len[i] = -balanced_steps;
     }
 }
 
@@ -222,7 +231,7 @@ static int reset_dispatch(const tg_env_params* p, void* state, int64_t ld, int64
     int block;
     dim3 grid = env_grid(n, block);
     hipLaunchKernelGGL((reset_kernel<EnvT<R>, R>), grid, dim3(block), 0, st, (R*)state, ld, n, seed, (uint32_t)stream_id,
-                       key_offset, key_div);
+                       key_offset, key_div, (int)(p->p[3] != 0.0));
     TG_LAUNCH_CHECK("tg_env_reset");
     return TG_OK;
 }
@@ -272,6 +281,8 @@ static int rollout_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t
         case TG_ENV_QUADPOLE2D * 2 + TG_F64: return CALL(QuadPole2DEnv, double);               \
         case TG_ENV_QUADPOLE * 2 + TG_F32: return CALL(QuadPoleEnv, float);                    \
         case TG_ENV_QUADPOLE * 2 + TG_F64: return CALL(QuadPoleEnv, double);                   \
+        case TG_ENV_PENDULUM * 2 + TG_F32: return CALL(PendulumEnv, float);                    \
+        case TG_ENV_PENDULUM * 2 + TG_F64: return CALL(PendulumEnv, double);                   \
         default: return set_error(TG_ERR_UNSUPPORTED, "unsupported env_id %d / dtype %d", (int)(env_id), (int)(dtype)); \
     }
 
@@ -295,8 +306,8 @@ using namespace tg;
 extern "C" {
 
 int tg_env_dims(int env_id, int* obs_dim, int* act_dim) {
-    static const int dims[4][2] = {{5, 1}, {10, 2}, {20, 4}, {12, 4}};
-    TG_REQUIRE(env_id >= 0 && env_id < 4, "tg_env_dims: bad env_id %d", env_id);
+    static const int dims[5][2] = {{5, 1}, {10, 2}, {20, 4}, {12, 4}, {3, 1}};
+    TG_REQUIRE(env_id >= 0 && env_id < 5, "tg_env_dims: bad env_id %d", env_id);
     if (obs_dim) *obs_dim = dims[env_id][0];
     if (act_dim) *act_dim = dims[env_id][1];
     return TG_OK;
@@ -305,7 +316,15 @@ int tg_env_dims(int env_id, int* obs_dim, int* act_dim) {
 int tg_env_finalize_params(tg_env_params* p) {
     TG_REQUIRE(p != nullptr, "tg_env_finalize_params: null params");
     TG_REQUIRE(p->max_steps > 0 && p->timestep > 0, "tg_env_finalize_params: max_steps/timestep must be positive");
-    p->time_trunc_step = (p->env_id == TG_ENV_CARTPOLE) ? cartpole_time_trunc_step(p->max_steps, p->timestep) : p->max_steps;
+    const bool timed = p->env_id == TG_ENV_CARTPOLE || p->env_id == TG_ENV_PENDULUM;   // `_time > max_time` clauses
+    p->time_trunc_step = timed ? cartpole_time_trunc_step(p->max_steps, p->timestep) : p->max_steps;
+    if (p->env_id == TG_ENV_PENDULUM) {
+        // consecutive balanced steps after which the fp64-accumulated `_time_balanced` first exceeds 5 s (pendulum_env.py:135,151)
+        double tb = 0;
+        int k = 0;
+        do { tb = tb + p->timestep; ++k; } while (!(tb > 5.0) && k < (1 << 24));
+        p->p[4] = (double)k;
+    }
     return TG_OK;
 }
 
@@ -329,6 +348,13 @@ int tg_env_default_params(int env_id, int max_steps, tg_env_params* out) {
         case TG_ENV_QUADPOLE: {  // quadrotor_env.py:362-382
             const double d[] = {1.5, 0.5, 9.80665, 0.5, 4e-1, 4e-1, 2.5e-1, 0.1, 0.5, 1.5};
             memcpy(out->p, d, sizeof(d));
+            break;
+        }
+        case TG_ENV_PENDULUM: {  // pendulum_env.py:8-16: mass, length, gravity, swingup (0/1); p[4] = term steps (finalize)
+            const double d[] = {1.0, 0.5, 9.80665, 0.0};
+            memcpy(out->p, d, sizeof(d));
+            out->timestep = 0.05;
+            out->max_steps = max_steps > 0 ? max_steps : 200;
             break;
         }
         case TG_ENV_QUADROTOR12: {  // quadrotor_env.py:9-16

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
     float s[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = obs[(k * T1 + t0) * n + ic];
-    bool alive = in_range && (len[ic] == 0);
+    // len == 0 while the episode runs; Pendulum keeps -(consecutive balanced steps) there (env_dynamics.hpp, StepOut)
+    const int32_t len0 = len[ic];
+    bool alive = in_range && (Env::kBalanceTerminates ? len0 <= 0 : len0 == 0);
+    int balanced_steps = Env::kBalanceTerminates ? -len0 : 0;
     unsigned short* my_x = xs + (wave * 64 + lane) * 32;
     // zero the padding features once (columns S..31 never change)
 #pragma unroll
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
 
     for (int32_t t = t0; t < t1; ++t) {
         bool wave_alive;
-        if (NT == 1 && agents <= 1 && t > t0 && ((t - t0) % kCompactEvery) == 0) {
+        if (NT == 1 && agents <= 1 && !Env::kBalanceTerminates && t > t0 && ((t - t0) % kCompactEvery) == 0) {
             // ---- compaction: the workgroup's running envs move to its lowest lanes, so the waves that hold only
             // ended envs (and, between compactions, fill up with them) stop doing MFMA work.  An env keeps its
             // identity `i`: recording and the Philox key follow the env, not the lane.
@@ -330,7 +333,12 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
         }
         float o[S], r;
         const StepOut out = Env::step(s, a, c, t + 1, o, r);
-        const bool done = any_in_segment(alive && out.truncated, agents) || (t + 1 >= T);
+        bool ended = out.truncated;
+        if constexpr (Env::kBalanceTerminates) {
+            balanced_steps = out.balanced ? balanced_steps + 1 : 0;
+            ended = ended || (balanced_steps >= c.term_steps);              // terminated, pendulum_env.py:151
+        }
+        const bool done = any_in_segment(alive && ended, agents) || (t + 1 >= T);
         const bool carry = alive && !done;
         if (in_range) {
 #pragma unroll
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
         for (int k = 0; k < S; ++k) s[k] = carry ? o[k] : 0.0f;
         alive = carry;
     }
+    if (Env::kBalanceTerminates && in_range && alive) len[i] = -balanced_steps;   // a later segment [t1, ..) picks the count up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
@@ -419,6 +428,8 @@ int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wf
         case TG_ENV_QUADPOLE2D * 1000 + 256: return CALL(QuadPole2DEnv, 256);
         case TG_ENV_QUADPOLE * 1000 + 128: return CALL(QuadPoleEnv, 128);
         case TG_ENV_QUADPOLE * 1000 + 256: return CALL(QuadPoleEnv, 256);
+        case TG_ENV_PENDULUM * 1000 + 128: return CALL(PendulumEnv, 128);
+        case TG_ENV_PENDULUM * 1000 + 256: return CALL(PendulumEnv, 256);
         default:
             return set_error(TG_ERR_UNSUPPORTED, "tg_fused_rollout: env %d with hidden width %d is not instantiated "
                              "(widths 128 and 256)", p->env_id, hidden);

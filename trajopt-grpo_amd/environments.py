@@ -110,8 +110,9 @@ class Env:
         self._alloc()
         p = self.native_params()
         self._reset_count += 1
-        N.check(N.load().tg_env_reset(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1, 1,
-                                      self._seed, self._reset_count, 0, 1, N.stream_ptr(self._device)), "tg_env_reset")
+        with torch.cuda.device(self._device):
+            N.check(N.load().tg_env_reset(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1, 1,
+                                          self._seed, self._reset_count, 0, 1, N.stream_ptr(self._device)), "tg_env_reset")
         self._initial = self._state.clone()
         self._steps_t.zero_()
         self._tb_t.zero_()
@@ -143,23 +144,27 @@ class Env:
         return self._obs_np(), self._get_info()
 
     def step(self, action):
+        info = self._get_info()     # the reference builds `info` BEFORE updating time_balanced
+        reward, truncated = self._native_step(action)
+        return self._obs_np(), reward, False, truncated, info
+
+    def _native_step(self, action):
+        """Advance the scalar env by one tg_env_step; returns (reward, truncated) and updates the bookkeeping."""
         if self._state is None:
             raise RuntimeError("step() before reset()")
         p = self.native_params()
         a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(self.act_dim, 1), device=self._device)
         self._act_t.copy_(a)
-        info = self._get_info()     # the reference builds `info` BEFORE updating time_balanced
-        N.check(N.load().tg_env_step(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1,
-                                     self._act_t.data_ptr(), 1, self._state.data_ptr(), 1, self._steps_t.data_ptr(),
-                                     self._tb_t.data_ptr(), self._rew_t.data_ptr(), self._trunc_t.data_ptr(), 1,
-                                     N.stream_ptr(self._device)), "tg_env_step")
+        with torch.cuda.device(self._device):
+            N.check(N.load().tg_env_step(C.byref(p), N.dtype_code(self._dtype), self._state.data_ptr(), 1,
+                                         self._act_t.data_ptr(), 1, self._state.data_ptr(), 1, self._steps_t.data_ptr(),
+                                         self._tb_t.data_ptr(), self._rew_t.data_ptr(), self._trunc_t.data_ptr(), 1,
+                                         N.stream_ptr(self._device)), "tg_env_step")
         self._steps += 1
         self._time += self.timestep
         self._time_balanced = float(self._tb_t.item())
         self._sync_state_dict()
-        reward = float(self._rew_t.item())
-        truncated = bool(self._trunc_t.item())
-        return self._obs_np(), reward, False, truncated, info
+        return float(self._rew_t.item()), bool(self._trunc_t.item())
 
     def render(self, *a, **k):
         raise NotImplementedError("render() is matplotlib plotting in the reference and is out of scope here")
@@ -184,6 +189,35 @@ class CartPole(Env):
 
     def _fill_params(self, p):
         p.p[0], p.p[1], p.p[2], p.p[3] = self.masscart, self.masspole, self.length, self.gravity
+
+
+class Pendulum(Env):
+    """Torque-driven pendulum, upright at theta = pi.  environments/pendulum_env.py:7-158.
+
+    The one env whose episode TERMINATES: once `time_balanced` (consecutive time with cos(theta) <= -0.99) exceeds 5 s.
+    `step` returns `(observation, reward, truncated, terminated, info)` -- truncated BEFORE terminated, as the reference
+    does (:158); its rollout worker unpacks them the other way round and only uses their disjunction."""
+    ENV_ID = N.TG_ENV_PENDULUM
+    _state_split = (("pendulum", 3),)
+    BALANCE_TIME = 5.0                                                        # :151
+
+    def __init__(self, env_name: str = "Pendulum", swingup: bool = False, mass: float = 1.0, length: float = 0.5,
+                 gravity: float = 9.80665, timestep: float = 0.05, max_steps: int = 200, device=None, dtype=torch.float64):
+        super().__init__(env_name, device, dtype)
+        self.swingup, self.mass, self.length, self.gravity = swingup, mass, length, gravity
+        self.timestep, self.max_steps = timestep, max_steps
+        self.max_time = max_steps * timestep
+        self.state_dict = {"pendulum": np.zeros(3)}
+        self.observation_space = Box(low=-1, high=1, shape=(3,), dtype=np.float32)
+        self.action_space = Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+
+    def _fill_params(self, p):
+        p.p[0], p.p[1], p.p[2], p.p[3] = self.mass, self.length, self.gravity, 1.0 if self.swingup else 0.0
+
+    def step(self, action):
+        reward, truncated = self._native_step(action)
+        info = self._get_info()                       # built AFTER the time_balanced update here (:135-139)
+        return self._obs_np(), reward, truncated, self._time_balanced > self.BALANCE_TIME, info
 
 
 class QuadPole2D(Env):
@@ -298,4 +332,5 @@ class QuadrotorSwarm(Quadrotor):
     pass
 
 
-ENV_CLASSES = {"CartPole": CartPole, "QuadPole2D": QuadPole2D, "QuadPole": QuadPole, "QuadPoleSwarm": QuadPoleSwarm}
+ENV_CLASSES = {"CartPole": CartPole, "QuadPole2D": QuadPole2D, "QuadPole": QuadPole, "QuadPoleSwarm": QuadPoleSwarm,
+               "Pendulum": Pendulum}
