@@ -16,38 +16,17 @@
 //     all ended skips its MFMA work, a workgroup whose envs have all ended leaves the time loop.
 // HBM traffic per env-step is the trajectory record only (S*4 + A*4 + 4 + 1 B written, nothing read).
 #include "env_dynamics.hpp"
+#include "mfma_ring.hpp"
 
 #include <stdlib.h>
 #include <string.h>
 
 namespace tg {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SigmaF { float v[8]; };
 
-typedef __attribute__((address_space(3))) void lds_void;
-
 constexpr int kCompactEvery = 8;   // time steps between compactions of a workgroup's running envs
-
-// One weight block = the A fragments of one 32-row output tile for all k-steps (hidden layers and head),
-// or of all MT output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB = KS pieces of
-// 1 KiB (one wave-instruction each).  The block stream is the same every time step (L2-resident) and flows
-// L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging) into a ring of D slots with P blocks
-// in flight: the stream needs ~15-30 GB/s per CU, far more bytes in flight than two register sets can hold
-// (the register-staged version spent 9 of 36 us per step waiting for it).  Per block: a COUNTED
-// `s_waitcnt vmcnt` (this wave's pieces of the block have landed; the P-1 younger blocks stay in flight),
-// a raw `s_barrier` (everyone's pieces have landed, and everyone has finished reading the slot that is
-// about to be refilled), then the DMA for block +P is issued.  `__syncthreads()` would drain the ring.
-template <int KS, int WPW>
-__device__ static inline void dma_block(const uint4* __restrict__ gblock, uint4* __restrict__ slot, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < KS / WPW; ++q) {
-        const int piece = q * WPW + wave;
-        __builtin_amdgcn_global_load_lds(gblock + piece * 64 + lane, (lds_void*)(slot + piece * 64), 16, 0, 0);
-    }
-}
 
 // Accumulator start values: rows (r&3) + 8(r>>2) + 4h of a 32-row tile, `b` = tile base + 4h.  The `__restrict__`
 // parameter of this inlined function gives its LDS reads alias-scope metadata; without it hipcc makes an LDS read wait
@@ -71,15 +50,8 @@ __device__ static inline bf16x8 x_fragment(const unsigned short* __restrict__ p)
     return __builtin_bit_cast(bf16x8, v);
 }
 
-#define TG_STAGE_ADVANCE                                                                      \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * (KS / WPW)) : "memory");               \
-    __builtin_amdgcn_s_barrier();                                                             \
-    asm volatile("" ::: "memory");                                                            \
-    dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane); \
-    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                    \
-    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                        \
-    const uint4* cur = ring + cur_slot * KS * 64;                                             \
-    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+// the trajectory stores of a step are issued behind the blocks in flight; not counting them only makes the wait stricter
+#define TG_STAGE_ADVANCE TG_RING_ADVANCE((P - 1) * (KS / WPW))
 
 // NT = env tiles (of 32) per wave, WPW = waves per workgroup.
 //   NT = 2, WPW = 4: 64 envs per wave, one lane per env, one wave per SIMD (the X fragments of two tiles fill
@@ -131,7 +103,7 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
     __syncthreads();                                  // bias table and padding are in place; no DMA outstanding yet
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     for (int b0 = 0; b0 < P; ++b0) {                  // blocks 0..P-1 in flight before the first step
-        dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
         pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
         pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
     }

@@ -1,0 +1,49 @@
+// Shared pieces of the persistent MFMA-chain kernels (fused_rollout.hip, mlp_fwd_chain.hip): vector types and the
+// weight ring that streams A fragments L2 -> LDS by LDS-DMA.
+//
+// One weight block = the A fragments of one 32-row output tile for all k-steps (hidden layers and head), or of all
+// output tiles of the first layer (K padded to 32 = 2 k-steps): always KS KiB = KS pieces of 1 KiB (one
+// wave-instruction each).  The block stream is the same every pass (L2-resident) and flows into a ring of D slots with
+// P = D - 1 blocks in flight (`global_load_lds_dwordx4`, no VGPR staging: the stream needs ~15-30 GB/s per CU, far more
+// bytes in flight than two register sets can hold).  Per block: a COUNTED `s_waitcnt vmcnt` (this wave's pieces of
+// the block have landed; the younger blocks stay in flight), a raw `s_barrier` (everyone's pieces have landed, and
+// everyone has finished reading the slot that is about to be refilled), then the DMA for block +P is issued.
+// `__syncthreads()` would drain the ring (its fence waits vmcnt(0)).
+//
+// Two compiler behaviours to design around (hipcc, ROCm 7.2):
+//   * vector-memory operations retire in issue order, stores included: the counted wait must allow for every
+//     vector-memory operation issued behind the block it waits for (the caller passes that count);
+//   * an LDS read WITHOUT alias-scope metadata is made to wait for every outstanding LDS-DMA (vmcnt(0)): LDS reads
+//     inside the ring loop go through inlined helpers with `__restrict__` parameters (which attaches the metadata),
+//     or are opaque inline assembly.
+#pragma once
+#include "tg_common.hpp"
+
+namespace tg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int KS, int WPW>
+__device__ static inline void ring_dma_block(const uint4* __restrict__ gblock, uint4* __restrict__ slot, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < KS / WPW; ++q) {
+        const int piece = q * WPW + wave;
+        __builtin_amdgcn_global_load_lds(gblock + piece * 64 + lane, (lds_void*)(slot + piece * 64), 16, 0, 0);
+    }
+}
+
+// Consume the next block.  Expects in scope: wfrag, ring, n_blocks, wave, lane, the ring state (pre_pos, pre_slot,
+// cur_slot) and the constants KS, WPW, D; declares `cur` (the block's fragments).  WAITN: see above.
+#define TG_RING_ADVANCE(WAITN)                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                                           \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);    \
+    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                                 \
+    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                                     \
+    const uint4* cur = ring + cur_slot * KS * 64;                                                          \
+    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+
+}  // namespace tg

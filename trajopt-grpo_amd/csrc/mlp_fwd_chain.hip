@@ -19,25 +19,12 @@
 //     for the stores issued since the block it waits for.  The stores are unconditional (rows past the end are
 //     clamped to the last row and rewrite it with identical bytes) and their number per block is a compile-time
 //     pattern (4 after every odd tile), so every wait site has its own exact count.
-#include "tg_common.hpp"
+#include "mfma_ring.hpp"
 
 namespace tg {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
 constexpr int kChainMaxHidden = 8;
 struct ChainActs { uint16_t* p[kChainMaxHidden]; };
-
-template <int KS, int WPW>
-__device__ static inline void chain_dma_block(const uint4* __restrict__ gblock, uint4* __restrict__ slot, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < KS / WPW; ++q) {
-        const int piece = q * WPW + wave;
-        __builtin_amdgcn_global_load_lds(gblock + piece * 64 + lane, (lds_void_t*)(slot + piece * 64), 16, 0, 0);
-    }
-}
 
 // Accumulator start values = the tile's 32 biases (LDS table), 16 per lane half.  `__restrict__` on an inlined
 // function's pointer parameters is what gives its LDS reads alias-scope metadata; hipcc makes an LDS read WITHOUT it
@@ -102,15 +89,7 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
 
 __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
 
-#define TG_CHAIN_ADVANCE(WAITN)                                                                    \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                                   \
-    __builtin_amdgcn_s_barrier();                                                                  \
-    asm volatile("" ::: "memory");                                                                 \
-    chain_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane); \
-    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                         \
-    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                             \
-    const uint4* cur = ring + cur_slot * KS * 64;                                                  \
-    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+#define TG_CHAIN_ADVANCE(WAITN) TG_RING_ADVANCE(WAITN)
 
 // x [rows][32] bf16 (features >= in_dim zero); acts.p[l] [rows][H] bf16 for hidden layer l (kStore); out f32
 // [rows][out_cols], out_cols in {8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
@@ -150,7 +129,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         for (int p = 0; p < 2; ++p) {
             int64_t r = base + 16 * p + (lane >> 2);
             r = r < rows ? r : rows - 1;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(x) + r * 4 + (lane & 3), (lds_void_t*)(my_xs + 64 * p), 16, 0,
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(x) + r * 4 + (lane & 3), (lds_void*)(my_xs + 64 * p), 16, 0,
                                              0);
         }
     };
@@ -158,7 +137,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     dma_x(blockIdx.x);
     for (int b0 = 0; b0 < P; ++b0) {                  // blocks 0..P-1 in flight before the first round
-        chain_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
         pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
         pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
     }
