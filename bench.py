@@ -3,21 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: a 65,536-env x 256-step QuadPole rollout
-(reset -> [actor GEMMs -> fused sample+step HIP kernel] x T) followed by PPO.learn on that buffer with
-the reference factory's hyper-parameters (pipelines/quadpole_pipeline_ppo.py: 20-256x5-{4,1}
-actor-critic, cov 0.3, gamma 0.999, 32 full-batch updates, Adam 3e-4), i.e. BASELINE.json configs[2]
-(C3).  Metric: env-steps/s, where an env-step is one valid (mask == 1) Env.step.  Weak scaling: every
-rank runs 65,536 envs; gradients are all-reduced once per optimizer step (RCCL).
+One "step" = one pass of the hot path over one batch: a 65,536-env x 256-step QuadPole rollout (one persistent
+kernel: actor MLP on the matrix cores + sampling + dynamics + recording) followed by PPO.learn on that buffer with
+the reference factory's hyper-parameters (pipelines/quadpole_pipeline_ppo.py: 20-256x5-{4,1} actor-critic, cov 0.3,
+gamma 0.999, 32 full-batch updates, Adam 3e-4), i.e. BASELINE.json configs[2] (C3).  Metric: env-steps/s, where an
+env-step is one valid (mask == 1) Env.step.  Weak scaling: every rank runs 65,536 envs; gradients are all-reduced
+once per optimizer step (RCCL).
 
 Besides the contract fields, the JSON line carries
-  roofline      HBM roofline of the dynamics kernel (tg rollout_step_kernel): algorithmic bytes
-                (state-in-trajectory variant: 189 B / env-step for QuadPole) x env-steps
-                processed per launch / measured launch time (HIP events on the launch stream, in the
-                timed region, event-pair overhead calibrated and subtracted);
-  cpu_baseline  the CPU port of the reference path (oracle/: scalar fp64 env + batch-1 torch policy
-                per step in forked worker processes, then PPO.learn on CPU) timed on this box's host
-                cores over a bounded sample of the same workload.
+  roofline         the kernel with the most GPU time in the step (36 %): tg_dx_relu_bias, a hidden layer's backward-data
+                   product fused with the ReLU backward and bias gradient below it.  HBM-bound; algorithmic bytes = read
+                   dZ + read A + write dZ_below = 1536 B per row at 256 bf16 features; EVERY launch of the timed steps
+                   is bracketed by HIP events on the launch stream.  (With an fp32 policy that kernel does not run and
+                   `roofline` is the rollout kernel's.)
+  rollout_kernel   the fused rollout kernel against the MFMA roofline: 2 x actor parameters flop per valid env-step
+                   (539 kflop), HIP events around each rollout's launch; `all_alive` = the same kernel with
+                   nobody terminating.  With --no-fused: the per-step dynamics kernel against the HBM roofline (189 B
+                   per env-step, SURVEY 8d state-in-trajectory variant).
+  dynamics_kernel  the stand-alone dynamics kernel (tg_rollout_step) at this env count, HBM roofline, timed after the run;
+  learner_kernel   tg_dx_relu_bias on random data at the learner's chunk size (2^22 rows), timed after the run;
+  cpu_baseline     the CPU port of the reference path (oracle/: scalar fp64 env + batch-1 torch policy per step in
+                   forked worker processes, then PPO.learn on CPU) timed on this box's host cores over a bounded
+                   sample of the same workload.
 """
 import argparse
 import json
@@ -200,6 +207,9 @@ def main():
     launch_units = []
     if not args.graph:
         mgr.engine.step_events = []
+    learner_mlps = [m for m in (algo._mlp(policy.actor), algo._mlp(policy.critic)) if m is not None]
+    for m in learner_mlps:
+        m.dx_events = []                    # HIP-event pairs around every tg_dx_relu_bias launch of the timed steps
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -219,6 +229,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    dx_launches = []                        # (ms, algorithmic bytes, rows) per launch, the update's dominant kernel
+    for m in learner_mlps:
+        dx_launches += [(a.elapsed_time(b), rows * 2 * (k + 2 * mm), rows) for a, b, rows, k, mm in m.dx_events]
+        m.dx_events = None
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     relu_probe = None
     if rank == 0 and cdt is not None:
@@ -302,7 +316,7 @@ def main():
             n_par = sum(p.numel() for p in policy.actor.parameters())
             dur = sum(d for d, _ in launches) * 1e-3
             ach = 2.0 * n_par * sum(launch_units) / dur / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+            out["rollout_kernel"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                                "traffic": 1706642656 if args.envs == 65536 else None,
                                "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
                                                  "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
@@ -317,7 +331,7 @@ def main():
             full = [(d, u) for d, u in launches if u == args.envs]
             ach = ALGO_BYTES["QuadPole"] * units / dur / 1e9
             traffic = 14334976 if args.envs == 65536 else None
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["rollout_kernel"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (all-alive launch)",
                                "kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>",
@@ -326,8 +340,29 @@ def main():
                                "event_pair_overhead_us": 1e3 * ev_overhead_ms}
             if full:
                 d_full = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in full) * 1e-3 / len(full)
-                out["roofline"]["full_launch_us"] = 1e6 * d_full
-                out["roofline"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
+                out["rollout_kernel"]["full_launch_us"] = 1e6 * d_full
+                out["rollout_kernel"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
+        if dx_launches:
+            # the kernel with the most GPU time in the step (36 %, profiles/r01_learner_bench_kernel_stats.csv): a hidden
+            # layer's backward-data product fused with the ReLU backward and bias gradient below it.  Algorithmic bytes
+            # per row = read dZ (2K) + read A for the mask (2M) + write dZ_below (2M) = 1536 B at 256 bf16 features.
+            dur = sum(d for d, _, _ in dx_launches) * 1e-3
+            nbytes = sum(b for _, b, _ in dx_launches)
+            nrows = sum(r for _, _, r in dx_launches)
+            ach = nbytes / dur / 1e9
+            # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
+            traffic = 6552869208 / 4194304 * nrows / len(dx_launches)
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic,
+                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1562 B/row "
+                                                 "(1.017 x algorithmic), times this run's average rows per launch",
+                               "kernel": "tg::dx_relu_bias_kernel<256,256,1,8>", "bytes_per_row": 1536,
+                               "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
+                               "avg_rows_per_launch": nrows / len(dx_launches),
+                               "TFLOPs": 2.0 * 256 * 256 * nrows / dur / 1e12,
+                               "note": "dominant kernel by GPU time; every launch of the timed steps, HIP events on the launch stream"}
+        elif "rollout_kernel" in out:
+            out["roofline"] = out["rollout_kernel"]
         out["dynamics_kernel"] = dyn
         out["learner_kernel"] = relu_probe
         if cpu is not None:

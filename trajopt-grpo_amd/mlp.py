@@ -67,6 +67,9 @@ class GemmMLP:
                 if lib.tg_dx_relu_bias_supported(o, k):
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
+        # when set to a list, every tg_dx_relu_bias launch is bracketed by HIP events on the launch stream and
+        # (start, end, rows, K, M) is appended (bench.py reads them back for that kernel's roofline)
+        self.dx_events = None
         # all layers of the forward pass in one launch (tg_mlp_forward_chain) when the shape allows
         self._chain = None
         H = fused_rollout_supported(net, min(self.in_dim, 32), 1) if compute_dtype == torch.bfloat16 else 0
@@ -171,8 +174,15 @@ class GemmMLP:
                     self._dx_partial = torch.empty(lib.tg_dx_relu_bias_blocks(), cols, dtype=torch.float32, device=dout.device)
                 partial = self._dx_partial
                 dz_below = torch.empty_like(a)
+                ev = None
+                if self.dx_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), a.data_ptr(), dz_below.data_ptr(), rows,
                                             dz.shape[1], cols, partial.data_ptr(), st), "tg_dx_relu_bias")
+                if ev is not None:
+                    ev[1].record()
+                    self.dx_events.append((ev[0], ev[1], rows, dz.shape[1], cols))
                 dz = dz_below
             else:
                 if self._partial is None or self._partial.shape[1] != cols:
