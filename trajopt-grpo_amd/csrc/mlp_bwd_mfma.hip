@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
                                                                         float* __restrict__ partial) {
     extern __shared__ uint4 lds[];
     constexpr int MP = M / 32, KS = K / 32;           // feature pairs-of-blocks, k-steps
+    constexpr bool kHoistMask = (NT == 1);
     for (int i = threadIdx.x; i < M * K / 8; i += blockDim.x) lds[i] = wfrag[i];
     __syncthreads();
 
@@ -70,19 +71,37 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
 #pragma unroll
         for (int r = 0; r < 8; ++r) bsum[p][r] = 0.f;
 
+    // loads of one tile: the B operand (dZ rows) and, for NT == 1, all mask words (requested up front: loaded inside
+    // the feature loop, which the scheduling barriers keep in order, each would be needed ~0.1 us after its issue --
+    // an HBM latency stall per feature pair)
+    auto issue_loads = [&](int64_t tile, bf16x8 (&bb)[NT][KS], uint4 (&mm)[kHoistMask ? NT : 1][kHoistMask ? MP : 1]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int64_t rr = tile * (16 * NT) + 16 * t + n;
+            rr = rr < rows ? rr : rows - 1;
+            const uint4* bp = reinterpret_cast<const uint4*>(dz_in + rr * K + 8 * q);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bb[t][ks] = __builtin_bit_cast(bf16x8, bp[4 * ks]);
+            if constexpr (kHoistMask) {
+                const uint4* mp = reinterpret_cast<const uint4*>(act + rr * M + 8 * q);
+#pragma unroll
+                for (int p = 0; p < MP; ++p) mm[t][p] = mp[4 * p];
+            }
+        }
+    };
+    // (also requesting the NEXT tile's operands before this tile's arithmetic was measured: slower, 1.31 vs 1.23 ms)
     for (int64_t tile = (int64_t)blockIdx.x * kDxWaves + wave; tile < ntiles; tile += tstride) {
+        bf16x8 b[NT][KS];
+        uint4 mka[kHoistMask ? NT : 1][kHoistMask ? MP : 1];
+        issue_loads(tile, b, mka);
         bool ok[NT];
         const uint4* ap[NT];
         uint4* op[NT];
-        bf16x8 b[NT][KS];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int64_t row = tile * (16 * NT) + 16 * t + n;
             ok[t] = row < rows;
             const int64_t rr = ok[t] ? row : rows - 1;
-            const uint4* bp = reinterpret_cast<const uint4*>(dz_in + rr * K + 8 * q);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) b[t][ks] = __builtin_bit_cast(bf16x8, bp[4 * ks]);
             ap[t] = reinterpret_cast<const uint4*>(act + rr * M + 8 * q);
             op[t] = reinterpret_cast<uint4*>(dz_out + rr * M + 8 * q);
         }
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
         for (int p = 0; p < MP; ++p) {
             uint4 mk[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mk[t] = ap[t][4 * p];
+            for (int t = 0; t < NT; ++t) mk[t] = kHoistMask ? mka[t][p] : ap[t][4 * p];
             f32x4 acc[NT][2];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
