@@ -351,11 +351,11 @@ def main():
             nrows = sum(r for _, _, r in dx_launches)
             ach = nbytes / dur / 1e9
             # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
-            traffic = 6552869208 / 4194304 * nrows / len(dx_launches)
+            traffic = 6492692856 / 4194304 * nrows / len(dx_launches)
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic,
-                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1562 B/row "
-                                                 "(1.017 x algorithmic), times this run's average rows per launch",
+                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1548 B/row "
+                                                 "(1.008 x algorithmic), times this run's average rows per launch",
                                "kernel": "tg::dx_relu_bias_kernel<256,256,1,8>", "bytes_per_row": 1536,
                                "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
                                "avg_rows_per_launch": nrows / len(dx_launches),
