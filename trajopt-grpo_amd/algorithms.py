@@ -11,8 +11,9 @@ Mirrors algorithms/algorithm.py:3-35, algorithms/grpo.py:12-169 and algorithms/p
     batch-normalised returns while A = R_raw - V (ppo.py:111,139,169); the entropy of the
     fixed-covariance Gaussian is a constant (zero gradient).
 What changes is where it runs: RTG / moments / normalisation / log-prob / the loss head are HIP
-kernels over the device trajectory; the MLP forward/backward are PyTorch-ROCm GEMMs; gradients
-of all ranks are summed with ONE flat all-reduce per optimizer step.
+kernels over the device trajectory; the MLP forward/backward run through mlp.GemmMLP (forward chain
+kernel, fused backward-data kernel, batched weight-gradient GEMMs); gradients of all ranks are summed
+with ONE flat all-reduce per optimizer step.
 """
 from __future__ import annotations
 

@@ -1,16 +1,19 @@
-"""Hand-scheduled forward/backward of the reference's ReLU MLP on PyTorch-ROCm GEMMs.
+"""Hand-scheduled forward/backward of the reference's ReLU MLP on the MI355X matrix cores.
 
-`models/neural_network.py:48-66` is `Sequential(Linear, ReLU, ..., Linear)`; under torch autograd
-(the reference, algorithms/*.py `loss.backward()`) that costs ~12 launches per layer and, at the
-shapes of this path (10^6..10^7 rows x 256 features), two pathologies on MI355X:
-  * the weight gradient dW = dZ^T A is a [256 x rows] x [rows x 256] GEMM: 16 output tiles on 256
-    CUs, no split-K -> 1.6-1.9 ms per 2^20 rows.  Here it is a batched GEMM over row blocks
-    (fp32 partials) plus one small reduction: 0.24 ms;
-  * N = 1 (critic head) and K = 20 (first layer) hit slow hipBLASLt paths: the head is padded to
-    8 outputs and the input to 32 features (zero weights / zero columns; results unchanged).
-Bias + ReLU ride in the forward GEMM epilogue (`torch._addmm_activation`), ReLU-backward and the
-bias gradient are one HIP kernel (`tg_relu_bwd_bias`).  Gradients are accumulated in fp32 straight
-into `param.grad` (the learner's flat all-reduce bucket).
+`models/neural_network.py:48-66` is `Sequential(Linear, ReLU, ..., Linear)`; under torch autograd (the reference,
+algorithms/*.py `loss.backward()`) that costs ~12 launches per layer and, at the shapes of this path
+(10^6..10^7 rows x 256 features), every pass is bound by HBM traffic (137 GFLOP per GB).  `GemmMLP` therefore
+minimises bytes per row:
+  * forward: ONE persistent chain kernel (tg_mlp_forward_chain) for bf16 nets Linear(S<=32, H) ReLU [Linear(H, H)
+    ReLU]* Linear(H, A<=16), H in {128, 256}: activations stay on chip between layers and are written once
+    (2.7 instead of 5.2 KB/row at 20-256x5-4).  Other shapes: per-layer GEMMs with bias + ReLU in the epilogue
+    (`torch._addmm_activation`), K = 20 and N = 1 padded to 32 / 8 (slow hipBLASLt paths otherwise);
+  * backward data: tg_dx_relu_bias fuses `dA = dZ W` with the ReLU backward and bias gradient of the layer below
+    (1.5 instead of 2.5 KB/row) for square bf16 layers of width 64 / 128 / 256; the head's rank-A product is
+    formed inside the top layer's pass (tg_head_bwd_relu_bias); otherwise a GEMM + tg_relu_bwd_bias;
+  * weight gradients: dW = dZ^T A is a [256 x rows] x [rows x 256] GEMM -- 16 output tiles on 256 CUs without split-K
+    (1.6-1.9 ms per 2^20 rows): a batched GEMM over row blocks with fp32 partials plus one small reduction instead.
+Gradients are accumulated in fp32 straight into `param.grad` (the learner's flat all-reduce bucket).
 
 Only ReLU hidden activations take this path; anything else stays on torch autograd.
 """
