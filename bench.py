@@ -11,9 +11,10 @@ env-step is one valid (mask == 1) Env.step.  Weak scaling: every rank runs 65,53
 once per optimizer step (RCCL).
 
 Besides the contract fields, the JSON line carries
-  roofline         the kernel with the most GPU time in the step (36 %): tg_dx_relu_bias, a hidden layer's backward-data
+  roofline         the kernel with the most GPU time in the step (29 %): tg_dx_relu_bias, a hidden layer's backward-data
                    product fused with the ReLU backward and bias gradient below it.  HBM-bound; algorithmic bytes = read
-                   dZ + read A + write dZ_below = 1536 B per row at 256 bf16 features; EVERY launch of the timed steps
+                   dZ (512) + read the 1-bit ReLU masks (32) + write dZ_below (512) = 1056 B per row at 256 bf16
+                   features (1536 B when the masks come from the activations themselves); EVERY launch of the timed steps
                    is bracketed by HIP events on the launch stream.  (With an fp32 policy that kernel does not run and
                    `roofline` is the rollout kernel's.)
   rollout_kernel   the fused rollout kernel against the MFMA roofline: 2 x actor parameters flop per valid env-step
@@ -37,6 +38,7 @@ sys.path.insert(0, REPO)
 
 HIDDEN = (256, 256, 256, 256, 256)
 ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
+DX_PMC_BYTES_PER_ROW = 4438938608 / 4194304                          # profiles/r01_dx_kernel_probe_pmc.json (1-bit masks)
 HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -231,26 +233,28 @@ def main():
 
     dx_launches = []                        # (ms, algorithmic bytes, rows) per launch, the update's dominant kernel
     for m in learner_mlps:
-        dx_launches += [(a.elapsed_time(b), rows * 2 * (k + 2 * mm), rows) for a, b, rows, k, mm in m.dx_events]
+        dx_launches += [(a.elapsed_time(b), rows * (2 * (k + mm) + (mm // 8 if bits else 2 * mm)), rows)
+                        for a, b, rows, k, mm, bits in m.dx_events]
         m.dx_events = None
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     relu_probe = None
     if rank == 0 and cdt is not None:
         # the hand-written kernel with the most GPU time in the update: a hidden layer's backward-data product fused
-        # with the ReLU backward + bias gradient below it (tg_dx_relu_bias).  Algorithmic traffic: read dZ and A,
-        # write dZ_below = 3 x 512 B per row at 256 bf16 features; timed at the learner's chunk size.
+        # with the ReLU backward + bias gradient below it (tg_dx_relu_bias), on random data at the learner's chunk size.
+        # Algorithmic traffic as the learner runs it: read dZ (512 B) and the 1-bit ReLU masks (32 B), write dZ_below
+        # (512 B) per row at 256 bf16 features.
         N_ = tg._native
         lib_ = N_.load()
         rows, cols = 1 << 22, 256
         dZ = (torch.randn(rows, cols, device=dev) * 0.5).to(cdt)
-        A_ = torch.relu(torch.randn(rows, cols, device=dev)).to(cdt)
+        bits_ = torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, cols // 32), dtype=torch.int32, device=dev)
         W_ = (torch.randn(cols, cols, device=dev) / 16).to(cdt)
         frag = torch.empty(cols * cols, dtype=cdt, device=dev)
-        out_ = torch.empty_like(A_)
+        out_ = torch.empty_like(dZ)
         part = torch.empty(lib_.tg_dx_relu_bias_blocks(), cols, dtype=torch.float32, device=dev)
         st = N_.stream_ptr(dev)
         N_.check(lib_.tg_dx_pack_weights(W_.data_ptr(), frag.data_ptr(), cols, cols, st))
-        run = lambda: N_.check(lib_.tg_dx_relu_bias(dZ.data_ptr(), frag.data_ptr(), A_.data_ptr(), out_.data_ptr(), rows, cols,
+        run = lambda: N_.check(lib_.tg_dx_relu_bias(dZ.data_ptr(), frag.data_ptr(), None, bits_.data_ptr(), out_.data_ptr(), rows, cols,
                                                     cols, part.data_ptr(), st))
         for _ in range(3):
             run()
@@ -261,11 +265,12 @@ def main():
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / 10
-        gbs = 3.0 * rows * cols * 2 / us / 1e3
-        relu_probe = {"kernel": "tg::dx_relu_bias_kernel<256,256,1,8>", "bound": "hbm", "rows": rows, "cols": cols,
+        bpr = 2 * cols * 2 + cols // 8
+        gbs = float(bpr) * rows / us / 1e3
+        relu_probe = {"kernel": "tg::dx_relu_bias_kernel<256,256,1,8,bits>", "bound": "hbm", "rows": rows, "cols": cols,
                       "us_per_launch": us, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                      "bytes_per_row": 3 * cols * 2, "TFLOPs": 2.0 * rows * cols * cols / us / 1e6}
-        del dZ, A_, W_, frag, out_, part
+                      "bytes_per_row": bpr, "TFLOPs": 2.0 * rows * cols * cols / us / 1e6}
+        del dZ, bits_, W_, frag, out_, part
     fused_all_alive = None
     if rank == 0 and mgr.engine.fused:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
@@ -343,20 +348,20 @@ def main():
                 out["rollout_kernel"]["full_launch_us"] = 1e6 * d_full
                 out["rollout_kernel"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
         if dx_launches:
-            # the kernel with the most GPU time in the step (36 %, profiles/r01_learner_bench_kernel_stats.csv): a hidden
+            # the kernel with the most GPU time in the step (29 %, profiles/r01_learner_bench_kernel_stats.csv): a hidden
             # layer's backward-data product fused with the ReLU backward and bias gradient below it.  Algorithmic bytes
-            # per row = read dZ (2K) + read A for the mask (2M) + write dZ_below (2M) = 1536 B at 256 bf16 features.
+            # per row = read dZ (2K) + read the ReLU masks (M/8 as bits, 2M from the activations) + write dZ_below (2M).
             dur = sum(d for d, _, _ in dx_launches) * 1e-3
             nbytes = sum(b for _, b, _ in dx_launches)
             nrows = sum(r for _, _, r in dx_launches)
             ach = nbytes / dur / 1e9
             # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
-            traffic = 6492692856 / 4194304 * nrows / len(dx_launches)
+            traffic = DX_PMC_BYTES_PER_ROW * nrows / len(dx_launches)
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic,
-                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1548 B/row "
-                                                 "(1.008 x algorithmic), times this run's average rows per launch",
-                               "kernel": "tg::dx_relu_bias_kernel<256,256,1,8>", "bytes_per_row": 1536,
+                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1058 B/row "
+                                                 "(1.002 x algorithmic), times this run's average rows per launch",
+                               "kernel": "tg::dx_relu_bias_kernel<256,256,1,8,bits>", "bytes_per_row": nbytes / nrows,
                                "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
                                "avg_rows_per_launch": nrows / len(dx_launches),
                                "TFLOPs": 2.0 * 256 * 256 * nrows / dur / 1e12,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -228,9 +228,12 @@ int  tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, i
 /* The head's backward-data product fused into the top hidden layer's ReLU backward:
  *   dZ[r][c] = (sum_{k<act_dim} dout[r][k] * Whead[k][c]) * (A[r][c] > 0),  d_partial as tg_relu_bwd_bias.
  * d_dout f32 [rows][act_dim] (contiguous), d_whead f32 [act_dim][cols] (the head's master weights),
- * d_act / d_dz [rows][cols] bf16 (is_bf16) or f32; cols % 8 == 0. */
-int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, void* d_dz,
-                           int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream);
+ * d_act / d_dz [rows][cols] bf16 (is_bf16) or f32; cols % 8 == 0.
+ * d_maskbits (optional, bf16, cols 128 / 256): the layer's ReLU mask bits from tg_mlp_forward_chain (cols / 8 bytes
+ * per row) are read instead of d_act (which may then be NULL): 4 B instead of 16 B per thread. */
+int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act,
+                           const void* d_maskbits, void* d_dz, int64_t rows, int32_t cols, int32_t is_bf16,
+                           float* d_partial, void* stream);
 
 /* A hidden layer's backward-data product on the matrix cores, fused with the ReLU backward and the bias gradient
  * of the layer below (bf16 operands, fp32 accumulate; replaces `dA = dZ @ W` + tg_relu_bwd_bias):
@@ -239,12 +242,14 @@ int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_
  * d_dz_in bf16 [rows][k_dim], d_act / d_dz_out bf16 [rows][m_dim] (row-major, contiguous, distinct buffers),
  * W = Linear.weight bf16 [k_dim = out_features][m_dim = in_features].  d_wfrag is W re-ordered by
  * tg_dx_pack_weights (k_dim*m_dim bf16, MFMA A-fragment order; rebuild it whenever W changes).
- * tg_dx_relu_bias_supported(k_dim, m_dim) != 0 for the shapes that have a kernel (square 64 / 128 / 256). */
+ * tg_dx_relu_bias_supported(k_dim, m_dim) != 0 for the shapes that have a kernel (square 64 / 128 / 256).
+ * d_maskbits (optional, widths 128 / 256): the ReLU mask bits of A written by tg_mlp_forward_chain (m_dim / 8 bytes per
+ * row) are read instead of d_act (which may then be NULL): 1.03 instead of 1.5 KB of traffic per row at 256. */
 int  tg_dx_relu_bias_supported(int32_t k_dim, int32_t m_dim);
 int  tg_dx_relu_bias_blocks(void);
 int  tg_dx_pack_weights(const void* d_w, void* d_wfrag, int32_t k_dim, int32_t m_dim, void* stream);
-int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, void* d_dz_out, int64_t rows,
-                     int32_t k_dim, int32_t m_dim, float* d_partial, void* stream);
+int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, const void* d_maskbits, void* d_dz_out,
+                     int64_t rows, int32_t k_dim, int32_t m_dim, float* d_partial, void* stream);
 
 /* ---- MLP forward, all layers in one persistent launch (models/neural_network.py:67-77) ----
  * Linear(in<=32, H) ReLU [Linear(H, H) ReLU]^(n_hidden_layers-1) Linear(H, out<=out_cols), H in {128, 256}, bf16
@@ -255,10 +260,13 @@ int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act
  *            documents and builds it), d_bias f32 [n_hidden_layers + 1][H] (natural order, head row zero-padded)
  *   d_acts   HOST array of n_hidden_layers device pointers, bf16 [rows][H] each (post-ReLU outputs of the hidden
  *            layers, row-major), or NULL to skip storing them
+ *   d_masks  HOST array of n_hidden_layers device pointers, u32 [rows][H / 32] each, or NULL: the ReLU masks of the
+ *            stored activations, 1 bit each (all the backward-data kernels need of them).  Per row: [lane half h = 0, 1]
+ *            [H / 64 words]; feature 32 mt + 16 h + r is bit (mt & 1) * 8 + (r >> 1) + 16 * (r & 1) of word mt >> 1
  *   d_out    f32 [rows][out_cols], out_cols in {8, 16} (columns >= out hold the padded head rows: zeros + bias 0) */
 int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden,
-                          int32_t n_hidden_layers, int64_t rows, void* const* d_acts, float* d_out,
-                          int32_t out_cols, void* stream);
+                          int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_masks,
+                          float* d_out, int32_t out_cols, void* stream);
 
 #ifdef __cplusplus
 }

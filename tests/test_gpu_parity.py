@@ -624,7 +624,7 @@ def test_fused_backward_data_relu_bias_kernel(tg, dev, width, rows):
     Nn.check(lib.tg_dx_pack_weights(W.data_ptr(), frag.data_ptr(), width, width, Nn.stream_ptr(dev)))
     out = torch.full((rows, width), float("nan"), dtype=torch.bfloat16, device=dev)
     partial = torch.full((lib.tg_dx_relu_bias_blocks(), width), float("nan"), dtype=torch.float32, device=dev)
-    Nn.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), act.data_ptr(), out.data_ptr(), rows, width, width,
+    Nn.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), act.data_ptr(), None, out.data_ptr(), rows, width, width,
                                  partial.data_ptr(), Nn.stream_ptr(dev)))
     torch.cuda.synchronize()
     exact = (dz.double() @ W.double()) * (act > 0)
@@ -636,6 +636,28 @@ def test_fused_backward_data_relu_bias_kernel(tg, dev, width, rows):
     assert torch.all(got[act <= 0] == 0)
     # the bias-gradient partials add up to the column sums of what was written
     np.testing.assert_allclose(partial.sum(0).cpu().numpy(), got.sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4 * rows ** 0.5)
+    if width >= 128:
+        # the same launch reading 1 bit per activation (tg_mlp_forward_chain's mask layout) instead of the activations
+        bits = _pack_mask_bits(act)
+        out2 = torch.full_like(out, float("nan"))
+        partial2 = torch.full_like(partial, float("nan"))
+        Nn.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), None, bits.data_ptr(), out2.data_ptr(), rows, width, width,
+                                     partial2.data_ptr(), Nn.stream_ptr(dev)))
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out) and torch.equal(partial2, partial)
+
+
+def _pack_mask_bits(act):
+    """[rows][H] activations -> [rows][H/32] int32 ReLU-mask words in tg_mlp_forward_chain's layout: per row
+    [lane half h][H/64 words]; feature 32 mt + 16 h + r is bit (mt&1)*8 + (r>>1) + 16*(r&1) of word mt>>1."""
+    rows, H = act.shape
+    f = torch.arange(H, device=act.device)
+    mt, h, r = f >> 5, (f >> 4) & 1, f & 15
+    word = h * (H // 64) + (mt >> 1)
+    bit = (mt & 1) * 8 + (r >> 1) + 16 * (r & 1)
+    out = torch.zeros(rows, H // 32, dtype=torch.int64, device=act.device)
+    out.index_add_(1, word, (act > 0).to(torch.int64) << bit)
+    return torch.where(out >= 2 ** 31, out - 2 ** 32, out).to(torch.int32)
 
 
 @pytest.mark.parametrize("dims", [(20, 4, (256,) * 5), (10, 2, (128, 128)), (5, 1, (256,)), (32, 12, (128,) * 3)])
@@ -655,6 +677,10 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     out_c = mlp.forward(xp, keep=True, padded=True)
     acts_c = mlp._acts
     assert len(acts_c) == len(hidden) + 1 and acts_c[0] is xp
+    # the ReLU mask bits written beside the activations are exactly (activation > 0), in the documented layout
+    assert len(mlp._bits) == len(acts_c) and mlp._bits[0] is None
+    for a_l, b_l in zip(acts_c[1:], mlp._bits[1:]):
+        assert torch.equal(b_l, _pack_mask_bits(a_l))
     out_nokeep = mlp.forward(xp, keep=False, padded=True)
     assert mlp._acts is None and torch.equal(out_nokeep, out_c)          # same arithmetic with and without the stores
     chain, mlp._chain = mlp._chain, None

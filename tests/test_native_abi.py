@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
-    assert lib.tg_abi_version() == 1
+    assert lib.tg_abi_version() == 2
 
 
 def test_single_hip_runtime_is_shared_with_torch():

@@ -13,6 +13,18 @@ import trajopt_grpo_amd as tg  # noqa: E402
 N = tg._native
 
 
+def pack_mask_bits(act):
+    """[rows][H] activations -> [rows][H/32] int32 mask words in tg_mlp_forward_chain's layout (include/trajopt_grpo_hip.h)."""
+    rows, H = act.shape
+    f = torch.arange(H, device=act.device)
+    mt, h, r = f >> 5, (f >> 4) & 1, f & 15
+    word = h * (H // 64) + (mt >> 1)
+    bit = (mt & 1) * 8 + (r >> 1) + 16 * (r & 1)
+    out = torch.zeros(rows, H // 32, dtype=torch.int64, device=act.device)
+    out.index_add_(1, word, (act > 0).to(torch.int64) << bit)
+    return torch.where(out >= 2 ** 31, out - 2 ** 32, out).to(torch.int32)          # bit 31 = the sign of the int32 word
+
+
 def timed(fn, iters):
     for _ in range(3):
         fn()
@@ -31,6 +43,7 @@ def main():
     ap.add_argument("--rows", type=int, nargs="+", default=[1 << 20, 1 << 22])
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--bits", action="store_true", help="ReLU masks as 1 bit per activation (tg_mlp_forward_chain layout)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = N.load()
@@ -47,8 +60,12 @@ def main():
         part2 = torch.empty(lib.tg_relu_bwd_bias_blocks(), H, dtype=torch.float32, device=dev)
         st = N.stream_ptr(dev)
 
+        bits_ptr = None
+        if a.bits:
+            bits_ptr = pack_mask_bits(act).data_ptr()
+
         def fused():
-            N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), act.data_ptr(), dzo.data_ptr(), rows, H, H,
+            N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), act.data_ptr(), bits_ptr, dzo.data_ptr(), rows, H, H,
                                         part.data_ptr(), st))
 
         da = torch.empty_like(act)
@@ -58,7 +75,7 @@ def main():
             N.check(lib.tg_relu_bwd_bias(da.data_ptr(), act.data_ptr(), rows, H, 1, part2.data_ptr(), st))
 
         tf, t2 = timed(fused, a.iters), timed(two_pass, a.iters)
-        bytes_alg = rows * H * 2 * 3
+        bytes_alg = rows * H * 2 * 3 if not a.bits else rows * (H * 2 * 2 + H // 8)
         out.append({"rows": rows, "width": H, "fused_us": tf, "two_pass_us": t2, "fused_GBps": bytes_alg / tf / 1e3,
                     "fused_frac_of_8TBps": bytes_alg / tf / 1e3 / 8000, "fused_TFLOPs": 2.0 * rows * H * H / tf / 1e6,
                     "speedup": t2 / tf})

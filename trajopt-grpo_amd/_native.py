@@ -72,12 +72,13 @@ SIGNATURES = {
     "tg_surrogate_loss": (C.c_int, [_P(LossArgs), _VP]),
     "tg_relu_bwd_bias_blocks": (C.c_int, []),
     "tg_relu_bwd_bias": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP, _VP]),
-    "tg_head_bwd_relu_bias": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "tg_head_bwd_relu_bias": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "tg_dx_relu_bias_supported": (C.c_int, [_I32, _I32]),
     "tg_dx_relu_bias_blocks": (C.c_int, []),
     "tg_dx_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
-    "tg_dx_relu_bias": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
-    "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), _VP, _I32, _VP]),
+    "tg_dx_relu_bias": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,
+                                       _VP]),
 }
 
 _lib = None
@@ -102,8 +103,8 @@ def load():
         except AttributeError as e:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
-    if lib.tg_abi_version() != 1:
-        raise NativeLibraryError(f"ABI version mismatch: library {lib.tg_abi_version()} != binding 1")
+    if lib.tg_abi_version() != 2:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.tg_abi_version()} != binding 2")
     _lib = lib
     return lib
 

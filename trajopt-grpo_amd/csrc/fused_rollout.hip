@@ -202,10 +202,8 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
                         }
 #pragma unroll
                         for (int sh = 0; sh < 2; ++sh) {
-                            bf16x8 o;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
-                            xout[tile][2 * mt + sh] = o;
+                            xout[tile][2 * mt + sh] = relu_pack_bf16(acc[8 * sh], acc[8 * sh + 1], acc[8 * sh + 2], acc[8 * sh + 3],
+                                                                     acc[8 * sh + 4], acc[8 * sh + 5], acc[8 * sh + 6], acc[8 * sh + 7]);
                         }
                     }
                 }
@@ -230,10 +228,8 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
                         }
 #pragma unroll
                         for (int sh = 0; sh < 2; ++sh) {
-                            bf16x8 o;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
-                            xout[tile][2 * mt + sh] = o;
+                            xout[tile][2 * mt + sh] = relu_pack_bf16(acc[8 * sh], acc[8 * sh + 1], acc[8 * sh + 2], acc[8 * sh + 3],
+                                                                     acc[8 * sh + 4], acc[8 * sh + 5], acc[8 * sh + 6], acc[8 * sh + 7]);
                         }
                     }
                 }

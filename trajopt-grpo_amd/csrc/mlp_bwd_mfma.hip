@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void dx_pack_weights_kernel(const uint16_t* __
     }
 }
 
-template <int M, int K, int NT, int kDxWaves>
+template <int M, int K, int NT, int kDxWaves, bool kBits>
 __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const uint16_t* __restrict__ dz_in,
                                                                         const uint4* __restrict__ wfrag,
                                                                         const uint16_t* __restrict__ act,
+                                                                        const uint32_t* __restrict__ maskbits,
                                                                         uint16_t* __restrict__ dz_out, int64_t rows,
                                                                         float* __restrict__ partial) {
     extern __shared__ uint4 lds[];
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
     // loads of one tile: the B operand (dZ rows) and, for NT == 1, all mask words (requested up front: loaded inside
     // the feature loop, which the scheduling barriers keep in order, each would be needed ~0.1 us after its issue --
     // an HBM latency stall per feature pair)
-    auto issue_loads = [&](int64_t tile, bf16x8 (&bb)[NT][KS], uint4 (&mm)[kHoistMask ? NT : 1][kHoistMask ? MP : 1]) {
+    auto issue_loads = [&](int64_t tile, bf16x8 (&bb)[NT][KS], uint4 (&mm)[kHoistMask ? NT : 1][kHoistMask ? MP : 1],
+                           uint32_t (&mb)[NT][MP / 2]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             int64_t rr = tile * (16 * NT) + 16 * t + n;
@@ -82,7 +84,17 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
             const uint4* bp = reinterpret_cast<const uint4*>(dz_in + rr * K + 8 * q);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bb[t][ks] = __builtin_bit_cast(bf16x8, bp[4 * ks]);
-            if constexpr (kHoistMask) {
+            if constexpr (kBits) {
+                // H mask bits per row as tg_mlp_forward_chain writes them: [half h = q>>1][MP/2 words]
+                const uint32_t* wp = maskbits + rr * MP + (q >> 1) * (MP / 2);
+                if constexpr (MP == 8) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(wp);
+                    mb[t][0] = v.x; mb[t][1] = v.y; mb[t][2] = v.z; mb[t][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MP / 2; ++i) mb[t][i] = wp[i];
+                }
+            } else if constexpr (kHoistMask) {
                 const uint4* mp = reinterpret_cast<const uint4*>(act + rr * M + 8 * q);
 #pragma unroll
                 for (int p = 0; p < MP; ++p) mm[t][p] = mp[4 * p];
@@ -93,7 +105,8 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
     for (int64_t tile = (int64_t)blockIdx.x * kDxWaves + wave; tile < ntiles; tile += tstride) {
         bf16x8 b[NT][KS];
         uint4 mka[kHoistMask ? NT : 1][kHoistMask ? MP : 1];
-        issue_loads(tile, b, mka);
+        uint32_t mbits[NT][MP / 2];
+        issue_loads(tile, b, mka, mbits);
         bool ok[NT];
         const uint4* ap[NT];
         uint4* op[NT];
@@ -102,14 +115,16 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
             const int64_t row = tile * (16 * NT) + 16 * t + n;
             ok[t] = row < rows;
             const int64_t rr = ok[t] ? row : rows - 1;
-            ap[t] = reinterpret_cast<const uint4*>(act + rr * M + 8 * q);
+            ap[t] = kBits ? nullptr : reinterpret_cast<const uint4*>(act + rr * M + 8 * q);
             op[t] = reinterpret_cast<uint4*>(dz_out + rr * M + 8 * q);
         }
 #pragma unroll
         for (int p = 0; p < MP; ++p) {
             uint4 mk[NT];
+            if constexpr (!kBits) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mk[t] = kHoistMask ? mka[t][p] : ap[t][4 * p];
+                for (int t = 0; t < NT; ++t) mk[t] = kHoistMask ? mka[t][p] : ap[t][4 * p];
+            }
             f32x4 acc[NT][2];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -128,14 +143,16 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const uint32_t mw[4] = {mk[t].x, mk[t].y, mk[t].z, mk[t].w};
+                // bit form: features 2w / 2w+1 of this lane are bits (p&1)*8 + 4(q&1) + w (+16) of word p>>1
+                const uint32_t bw = kBits ? mbits[t][p >> 1] >> ((p & 1) * 8 + 4 * (q & 1)) : 0u;
                 uint32_t ow[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     // features 2w, 2w+1 of the lane's 8: accumulator (e = w>>1, r = 2(w&1) + {0,1}).
                     // post-ReLU activations are >= 0: positive  <=>  nonzero magnitude bits and sign clear
                     const uint32_t a_lo = mw[w] & 0xFFFFu, a_hi = mw[w] >> 16;
-                    const bool p_lo = ok[t] && (a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u);
-                    const bool p_hi = ok[t] && (a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u);
+                    const bool p_lo = ok[t] && (kBits ? ((bw >> w) & 1u) != 0 : ((a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u)));
+                    const bool p_hi = ok[t] && (kBits ? ((bw >> (w + 16)) & 1u) != 0 : ((a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u)));
                     const uint32_t o_lo = p_lo ? f32_to_bf16_bits(acc[t][w >> 1][2 * (w & 1)]) : 0u;
                     const uint32_t o_hi = p_hi ? f32_to_bf16_bits(acc[t][w >> 1][2 * (w & 1) + 1]) : 0u;
                     bsum[p][2 * w] += bf16_bits_to_f32(o_lo);
@@ -185,11 +202,11 @@ static int dx_blocks() {
     return n;
 }
 
-template <int M, int K, int NT, int kDxWaves>
-static int dx_launch(const void* dz_in, const void* wfrag, const void* act, void* dz_out, int64_t rows, float* partial,
-                     hipStream_t st) {
+template <int M, int K, int NT, int kDxWaves, bool kBits>
+static int dx_launch(const void* dz_in, const void* wfrag, const void* act, const void* maskbits, void* dz_out, int64_t rows,
+                     float* partial, hipStream_t st) {
     const size_t shmem = (size_t)M * K * 2;
-    auto kern = dx_relu_bias_kernel<M, K, NT, kDxWaves>;
+    auto kern = dx_relu_bias_kernel<M, K, NT, kDxWaves, kBits>;
     static bool attr_done = false;
     if (shmem > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -200,7 +217,7 @@ static int dx_launch(const void* dz_in, const void* wfrag, const void* act, void
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(dx_blocks()), dim3(64 * kDxWaves), shmem, st, (const uint16_t*)dz_in, (const uint4*)wfrag,
-                       (const uint16_t*)act, (uint16_t*)dz_out, rows, partial);
+                       (const uint16_t*)act, (const uint32_t*)maskbits, (uint16_t*)dz_out, rows, partial);
     TG_LAUNCH_CHECK("tg_dx_relu_bias");
     return TG_OK;
 }
@@ -228,19 +245,22 @@ int tg_dx_pack_weights(const void* d_w, void* d_wfrag, int32_t k_dim, int32_t m_
     return TG_OK;
 }
 
-int tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, void* d_dz_out, int64_t rows, int32_t k_dim,
-                    int32_t m_dim, float* d_partial, void* stream) {
-    TG_REQUIRE(d_dz_in && d_wfrag && d_act && d_dz_out && d_partial, "tg_dx_relu_bias: null pointer");
+int tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act, const void* d_maskbits, void* d_dz_out,
+                    int64_t rows, int32_t k_dim, int32_t m_dim, float* d_partial, void* stream) {
+    TG_REQUIRE(d_dz_in && d_wfrag && (d_act || d_maskbits) && d_dz_out && d_partial, "tg_dx_relu_bias: null pointer");
     TG_REQUIRE(rows >= 0, "tg_dx_relu_bias: rows=%lld is negative", (long long)rows);
     TG_REQUIRE(tg_dx_relu_bias_supported(k_dim, m_dim), "tg_dx_relu_bias: K=%d, M=%d has no kernel (256x256, 128x128, 64x64)", k_dim,
                m_dim);
     hipStream_t st = (hipStream_t)stream;
-#define TG_DX_ARGS d_dz_in, d_wfrag, d_act, d_dz_out, rows, d_partial, st
+#define TG_DX_ARGS d_dz_in, d_wfrag, d_act, d_maskbits, d_dz_out, rows, d_partial, st
+#define TG_DX_CALL(M_, NT_) (d_maskbits ? dx_launch<M_, M_, NT_, 8, true>(TG_DX_ARGS) : dx_launch<M_, M_, NT_, 8, false>(TG_DX_ARGS))
     // 16-row tiles and 8 waves measured fastest at 256 x 256 (1.34 ms per 2^22 rows; 32-row tiles spill: 1.71 ms;
     // 12 / 16 waves per workgroup spill harder: 1.46 / 2.31 ms)
-    if (k_dim == 256) return dx_launch<256, 256, 1, 8>(TG_DX_ARGS);
-    if (k_dim == 128) return dx_launch<128, 128, 2, 8>(TG_DX_ARGS);
-    return dx_launch<64, 64, 2, 8>(TG_DX_ARGS);
+    if (k_dim == 256) return TG_DX_CALL(256, 1);
+    if (k_dim == 128) return TG_DX_CALL(128, 2);
+    TG_REQUIRE(!d_maskbits, "tg_dx_relu_bias: mask bits need a width of 128 or 256 (tg_mlp_forward_chain writes them)");
+    return dx_launch<64, 64, 2, 8, false>(TG_DX_ARGS);
+#undef TG_DX_CALL
 #undef TG_DX_ARGS
 }
 

@@ -24,7 +24,7 @@
 namespace tg {
 
 constexpr int kChainMaxHidden = 8;
-struct ChainActs { uint16_t* p[kChainMaxHidden]; };
+struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; };   // activations, ReLU mask bits (or null)
 
 // Accumulator start values = the tile's 32 biases (LDS table), 16 per lane half.  `__restrict__` on an inlined
 // function's pointer parameters is what gives its LDS reads alias-scope metadata; hipcc makes an LDS read WITHOUT it
@@ -62,6 +62,40 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
     }
 }
 
+// ReLU masks for the backward pass, 1 bit per activation (the backward-data kernels only need `activation > 0`: 32 B per
+// row instead of re-reading the 512-B activation row).  `lo`/`hi` are a lane's 16 post-ReLU features of one tile
+// (feature r in dword r>>1, half r&1); the result has bit k (even features 2k) and bit 16+k (odd features 2k+1), k < 8.
+__device__ static inline uint32_t tile_mask_bits(bf16x8 lo, bf16x8 hi) {
+    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
+    const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t one = 0x00010001u;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit.  (Inline
+        // assembly: written with __builtin_elementwise_min, hipcc turns it into two compares + selects per dword.)
+        uint32_t y;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(d[k]), "v"(one));
+        m |= y << k;
+    }
+    return m;
+}
+
+// Mask word i of lane (n, h) covers tiles 2i (bits 0-7 / 16-23) and 2i+1 (bits 8-15 / 24-31) of a layer's output `x`; a
+// row's mask is [h = 0: MT/2 words][h = 1: MT/2 words] = H bits.  The words of layer l are formed while layer l+1 (or
+// the head) runs its MFMAs -- `x` is that layer's input, the arithmetic hides in the matrix-core issue shadow -- and
+// leave as one store per lane, 1 KiB contiguous per wave at H = 256.
+template <int KS>
+__device__ static inline uint32_t pair_mask_word(const bf16x8 (&x)[KS], int i) {
+    return tile_mask_bits(x[4 * i], x[4 * i + 1]) | (tile_mask_bits(x[4 * i + 2], x[4 * i + 3]) << 8);
+}
+template <int MT>
+__device__ static inline void store_mask_words(uint32_t* __restrict__ g, int64_t row, int h, const uint32_t (&w)[MT / 2]) {
+    uint32_t* p = g + row * MT + h * (MT / 2);
+    if constexpr (MT == 8) *reinterpret_cast<uint4*>(p) = uint4{w[0], w[1], w[2], w[3]};
+    else *reinterpret_cast<uint2*>(p) = uint2{w[0], w[1]};
+}
+
 // One 32-feature output tile of a hidden layer: bias-init, K/16 MFMAs against the block's fragments, ReLU, bf16 pack.
 template <int KS>
 __device__ static inline void chain_tile(const uint4* __restrict__ cur, const float* __restrict__ b16, const bf16x8 (&xin)[KS],
@@ -72,11 +106,8 @@ __device__ static inline void chain_tile(const uint4* __restrict__ cur, const fl
         const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lo[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[j], 0.0f, __builtin_inff());
-        hi[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 + j], 0.0f, __builtin_inff());
-    }
+    lo = relu_pack_bf16(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+    hi = relu_pack_bf16(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
 }
 
 // 16 B from LDS without telling the compiler it is an LDS read (same reason); waits for it itself.
@@ -167,12 +198,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
 #pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)__builtin_amdgcn_fmed3f(acc[8 * sh + j], 0.0f, __builtin_inff());
-                    xout[2 * mt + sh] = o;
-                }
+                for (int sh = 0; sh < 2; ++sh)
+                    xout[2 * mt + sh] = relu_pack_bf16(acc[8 * sh], acc[8 * sh + 1], acc[8 * sh + 2], acc[8 * sh + 3], acc[8 * sh + 4],
+                                                       acc[8 * sh + 5], acc[8 * sh + 6], acc[8 * sh + 7]);
                 if (kStore && (mt & 1))
                     store_pair(stage, acts.p[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
@@ -183,16 +211,23 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         // ---- hidden H x H layers: one block per 32-feature output tile ----
         for (int l = 0; l < n_hh; ++l) {
             const float* bl = bias_s + (l + 1) * H + 16 * h;
+            uint32_t mw[MT / 2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                // (the mask bits of this layer's INPUT, activation l: one word per tile for the first MT/2 tiles, after the
+                // barrier so that the arithmetic sits beside the tile's MFMAs)
                 if (mt & 1) {
                     TG_CHAIN_ADVANCE(kWaitOdd)
+                    if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
                     chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
+                    // (with the mask store one more store sits behind this tile than the wait sites count: stricter, never weaker)
+                    if (kStore && mt == MT / 2 - 1 && acts.m[l]) store_mask_words<MT>(acts.m[l], row, h, mw);
                     if (kStore)
                         store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1],
                                    xout[2 * mt], xout[2 * mt + 1]);
                 } else {
                     TG_CHAIN_ADVANCE(kWaitEven)
+                    if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
                     chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
                 }
             }
@@ -202,6 +237,12 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         // ---- head: 32 padded output rows; features 0..15 are registers 0..15 of the h == 0 lanes ----
         {
             TG_CHAIN_ADVANCE(kWaitEven)
+            if (kStore && acts.m[n_hh]) {                       // the last hidden activation's mask bits
+                uint32_t mw[MT / 2];
+#pragma unroll
+                for (int i = 0; i < MT / 2; ++i) mw[i] = pair_mask_word<KS>(xin, i);
+                store_mask_words<MT>(acts.m[n_hh], row, h, mw);
+            }
             f32x16 acc = bias_tile(bias_s + (n_hh + 1) * H + 16 * h);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -264,7 +305,7 @@ using namespace tg;
 extern "C" {
 
 int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
-                         int64_t rows, void* const* d_acts, float* d_out, int32_t out_cols, void* stream) {
+                         int64_t rows, void* const* d_acts, void* const* d_masks, float* d_out, int32_t out_cols, void* stream) {
     TG_REQUIRE(d_x && d_wfrag && d_bias && d_out, "tg_mlp_forward_chain: null pointer");
     TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_forward_chain: hidden width %d unsupported (128, 256)", hidden);
     TG_REQUIRE(n_hidden_layers >= 1 && n_hidden_layers <= kChainMaxHidden, "tg_mlp_forward_chain: %d hidden layers outside 1..%d",
@@ -277,7 +318,9 @@ int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bi
         for (int l = 0; l < n_hidden_layers; ++l) {
             TG_REQUIRE(d_acts[l], "tg_mlp_forward_chain: activation buffer %d is null", l);
             acts.p[l] = (uint16_t*)d_acts[l];
+            acts.m[l] = d_masks ? (uint32_t*)d_masks[l] : nullptr;
         }
+    TG_REQUIRE(d_acts || !d_masks, "tg_mlp_forward_chain: mask bits are only produced together with the activations");
     hipStream_t st = (hipStream_t)stream;
     const int n_hh = n_hidden_layers - 1;
 #define TG_CHAIN_ARGS d_x, d_wfrag, d_bias, n_hh, rows, acts, d_out, out_cols, st

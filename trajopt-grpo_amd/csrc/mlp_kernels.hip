@@ -87,9 +87,12 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_f32_kernel(float* __restric
 // replaces the [rows x 8] x [8 x cols] GEMM (which only writes 512 B/row) plus the read of dA in relu_bwd_bias.
 __device__ static inline uint16_t f32_to_bf16_rne(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 
-template <bool kBf16>
+// `maskbits` (bf16 only): 1 bit per activation as tg_mlp_forward_chain writes them (cols bits per row: [half h][cols/64
+// words], feature 32 mt + 16 h + r -> bit (mt&1)*8 + (r>>1) + 16 (r&1) of word mt>>1) instead of the activation row.
+template <bool kBf16, int KA>        // KA = the head's output count rounded up to 1, 2, 4 or 8
 __global__ __launch_bounds__(256) void head_bwd_relu_bias_kernel(const float* __restrict__ dout, int a_dim,
                                                                  const float* __restrict__ Wh, const void* __restrict__ act,
+                                                                 const uint32_t* __restrict__ maskbits,
                                                                  void* __restrict__ dz, int64_t rows, int cols,
                                                                  float* __restrict__ partial) {
     extern __shared__ float sh[];
@@ -101,33 +104,42 @@ __global__ __launch_bounds__(256) void head_bwd_relu_bias_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc[j] = 0.f;
     if (rl < rpp) {
-        float w[8][PER];                                      // this thread's columns of the head weights
+        float w[KA][PER];                                     // this thread's columns of the head weights
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < KA; ++k)
 #pragma unroll
             for (int j = 0; j < PER; ++j) w[k][j] = (k < a_dim) ? Wh[(int64_t)k * cols + cl + j] : 0.f;
+        // (issuing the loads of 2 or 4 rows per trip ahead of the arithmetic was measured: slower, the kernel is bound by
+        // its vector ALU work and occupancy, not by load latency)
+        const int mt = cl >> 5, hh = (cl >> 4) & 1, wpr = cols >> 5;          // mask bits: tile, lane half, words per row
         for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < rows; r += (int64_t)gridDim.x * rpp) {
-            float d[8];
+            float d[KA];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) d[k] = (k < a_dim) ? dout[r * a_dim + k] : 0.f;
+            for (int k = 0; k < KA; ++k) d[k] = (k < a_dim) ? dout[r * a_dim + k] : 0.f;
             float v[PER];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += d[k] * w[k][j];
+                for (int k = 0; k < KA; ++k) s += d[k] * w[k][j];
                 v[j] = s;
             }
             const int64_t off = r * cols + cl;
             if constexpr (kBf16) {
-                const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(act) + off);
-                const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+                uint32_t av[4] = {0u, 0u, 0u, 0u}, bw = 0u;
+                if (maskbits) {
+                    // this thread's 8 features cl .. cl+7: tile mt = cl>>5, half h = (cl>>4)&1, r16 = (cl&15) + j
+                    bw = maskbits[r * wpr + hh * (wpr >> 1) + (mt >> 1)] >> ((mt & 1) * 8 + ((cl & 15) >> 1));
+                } else {
+                    const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(act) + off);
+                    av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w;
+                }
                 uint32_t ov[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint16_t a_lo = (uint16_t)(av[j] & 0xFFFFu), a_hi = (uint16_t)(av[j] >> 16);
-                    const bool p_lo = (a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u);
-                    const bool p_hi = (a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u);
+                    const bool p_lo = maskbits ? ((bw >> j) & 1u) != 0 : ((a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u));
+                    const bool p_hi = maskbits ? ((bw >> (j + 16)) & 1u) != 0 : ((a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u));
                     const uint16_t o_lo = p_lo ? f32_to_bf16_rne(v[2 * j]) : (uint16_t)0;
                     const uint16_t o_hi = p_hi ? f32_to_bf16_rne(v[2 * j + 1]) : (uint16_t)0;
                     acc[2 * j] += bf16_to_f32(o_lo);
@@ -185,22 +197,37 @@ int tg_relu_bwd_bias(void* d_dA, const void* d_A, int64_t rows, int32_t cols, in
     return TG_OK;
 }
 
-int tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, void* d_dz,
-                          int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream) {
-    TG_REQUIRE(d_dout && d_whead && d_act && d_dz && d_partial, "tg_head_bwd_relu_bias: null pointer");
+int tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_whead, const void* d_act, const void* d_maskbits,
+                          void* d_dz, int64_t rows, int32_t cols, int32_t is_bf16, float* d_partial, void* stream) {
+    TG_REQUIRE(d_dout && d_whead && (d_act || d_maskbits) && d_dz && d_partial, "tg_head_bwd_relu_bias: null pointer");
+    TG_REQUIRE(!d_maskbits || (is_bf16 && (cols == 128 || cols == 256)),
+               "tg_head_bwd_relu_bias: mask bits need bf16 and 128 or 256 columns (tg_mlp_forward_chain writes them)");
     TG_REQUIRE(act_dim >= 1 && act_dim <= 8, "tg_head_bwd_relu_bias: act_dim %d outside 1..8", act_dim);
     TG_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols / 8 <= 256, "tg_head_bwd_relu_bias: cols=%d must be a multiple of 8 and <= 2048",
                cols);
     const int tpr = cols / 8, rpp = 256 / tpr;
     const size_t shmem = (size_t)rpp * cols * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+#define TG_HEAD_LAUNCH(BF, KA_)                                                                                          \
+    hipLaunchKernelGGL((head_bwd_relu_bias_kernel<BF, KA_>), dim3(kReluBlocks), dim3(256), shmem, st, d_dout, act_dim, d_whead, \
+                       d_act, (const uint32_t*)(BF ? d_maskbits : nullptr), d_dz, rows, cols, d_partial)
+    const int ka = act_dim <= 1 ? 1 : act_dim <= 2 ? 2 : act_dim <= 4 ? 4 : 8;
     if (is_bf16) {
-        hipLaunchKernelGGL(head_bwd_relu_bias_kernel<true>, dim3(kReluBlocks), dim3(256), shmem, st, d_dout, act_dim, d_whead, d_act,
-                           d_dz, rows, cols, d_partial);
+        switch (ka) {
+            case 1: TG_HEAD_LAUNCH(true, 1); break;
+            case 2: TG_HEAD_LAUNCH(true, 2); break;
+            case 4: TG_HEAD_LAUNCH(true, 4); break;
+            default: TG_HEAD_LAUNCH(true, 8); break;
+        }
     } else {
-        hipLaunchKernelGGL(head_bwd_relu_bias_kernel<false>, dim3(kReluBlocks), dim3(256), shmem, st, d_dout, act_dim, d_whead, d_act,
-                           d_dz, rows, cols, d_partial);
+        switch (ka) {
+            case 1: TG_HEAD_LAUNCH(false, 1); break;
+            case 2: TG_HEAD_LAUNCH(false, 2); break;
+            case 4: TG_HEAD_LAUNCH(false, 4); break;
+            default: TG_HEAD_LAUNCH(false, 8); break;
+        }
     }
+#undef TG_HEAD_LAUNCH
     TG_LAUNCH_CHECK("tg_head_bwd_relu_bias");
     return TG_OK;
 }

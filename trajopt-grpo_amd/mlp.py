@@ -60,6 +60,7 @@ class GemmMLP:
             self.w.append(torch.zeros(o, k, dtype=compute_dtype, device=dev))
             self.b.append(torch.zeros(o, dtype=compute_dtype, device=dev))
         self._acts = None
+        self._bits = None
         self._partial = None
         # hidden layers whose backward-data product runs fused with the ReLU backward below it (tg_dx_relu_bias)
         self._dxfrag = [None] * len(self.linears)
@@ -71,7 +72,7 @@ class GemmMLP:
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
         # when set to a list, every tg_dx_relu_bias launch is bracketed by HIP events on the launch stream and
-        # (start, end, rows, K, M) is appended (bench.py reads them back for that kernel's roofline)
+        # (start, end, rows, K, M, mask-bits?) is appended (bench.py reads them back for that kernel's roofline)
         self.dx_events = None
         # all layers of the forward pass in one launch (tg_mlp_forward_chain) when the shape allows
         self._chain = None
@@ -109,12 +110,16 @@ class GemmMLP:
         if self._chain is not None and xp.shape[0] > 0:
             rows, H = xp.shape[0], self._chain.H
             hid = [torch.empty(rows, H, dtype=self.cd, device=xp.device) for _ in range(L - 1)] if keep else []
+            # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
+            bits = [torch.empty(rows, H // 32, dtype=torch.int32, device=xp.device) for _ in range(L - 1)] if keep else []
             out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
             ptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in hid]) if keep else None
+            mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
             N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
-                                                  L - 1, rows, ptrs, out.data_ptr(), self.out_pad, N.stream_ptr(xp.device)),
-                    "tg_mlp_forward_chain")
+                                                  L - 1, rows, ptrs, mptrs, out.data_ptr(), self.out_pad,
+                                                  N.stream_ptr(xp.device)), "tg_mlp_forward_chain")
             self._acts = [xp] + hid if keep else None
+            self._bits = [None] + bits if keep else None
             return out if padded else out[:, :self.out_dim].contiguous()
         acts = [xp]
         h = xp
@@ -127,6 +132,7 @@ class GemmMLP:
             out = torch.mm(h, self.w[-1].t(), out_dtype=torch.float32)
             out += self.bias_out_f32
         self._acts = acts if keep else None
+        self._bits = None
         return out if padded else out[:, :self.out_dim].contiguous()
 
     def _dw(self, dz: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
@@ -154,6 +160,7 @@ class GemmMLP:
         """dout fp32 [rows][out_dim] = d loss / d output.  Accumulates into weight.grad / bias.grad (fp32)."""
         acts = self._acts
         assert acts is not None, "backward() needs forward(keep=True)"
+        bits = self._bits if self._bits is not None else [None] * len(acts)      # ReLU mask bits of acts[i] (chain forward)
         lib = N.load()
         rows = dout.shape[0]
         L = len(self.linears)
@@ -181,11 +188,13 @@ class GemmMLP:
                 if self.dx_events is not None:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), a.data_ptr(), dz_below.data_ptr(), rows,
-                                            dz.shape[1], cols, partial.data_ptr(), st), "tg_dx_relu_bias")
+                mb = bits[i + 1]
+                N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), a.data_ptr(), None if mb is None else mb.data_ptr(),
+                                            dz_below.data_ptr(), rows, dz.shape[1], cols, partial.data_ptr(), st),
+                        "tg_dx_relu_bias")
                 if ev is not None:
                     ev[1].record()
-                    self.dx_events.append((ev[0], ev[1], rows, dz.shape[1], cols))
+                    self.dx_events.append((ev[0], ev[1], rows, dz.shape[1], cols, mb is not None))
                 dz = dz_below
             else:
                 if self._partial is None or self._partial.shape[1] != cols:
@@ -194,9 +203,10 @@ class GemmMLP:
                 if i == L - 2 and fuse_head:
                     # top hidden layer: dA = dout . W_head is a rank-A product, formed inside the ReLU-backward kernel
                     da = torch.empty_like(a)
+                    mb = bits[i + 1]
                     N.check(lib.tg_head_bwd_relu_bias(dout.data_ptr(), self.out_dim, self.linears[-1].weight.data_ptr(),
-                                                      a.data_ptr(), da.data_ptr(), rows, cols, is_bf16, partial.data_ptr(), st),
-                            "tg_head_bwd_relu_bias")
+                                                      a.data_ptr(), None if mb is None else mb.data_ptr(), da.data_ptr(), rows,
+                                                      cols, is_bf16, partial.data_ptr(), st), "tg_head_bwd_relu_bias")
                 else:
                     da = dz @ self.w[i + 1]
                     N.check(lib.tg_relu_bwd_bias(da.data_ptr(), a.data_ptr(), rows, cols, is_bf16, partial.data_ptr(), st),
@@ -206,7 +216,7 @@ class GemmMLP:
             lin.bias.grad.add_(partial.sum(0))
             dw = self._dw(dz, acts[i])
             lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
-        self._acts = None
+        self._acts = self._bits = None
 
 
 # ---------------------------------------------------------------------------------------------
