@@ -28,15 +28,16 @@ typedef __attribute__((address_space(3))) void lds_void;
 // ReLU + bf16 pack of 8 accumulators: round first (v_cvt_pk_bf16_f32, 2 per instruction), then clamp the PACKED halves
 // with v_pk_max_i16(x, 0) -- a negative bf16 (and -0) is a negative int16.  relu(round(x)) == round(relu(x)); 4 + 4
 // instructions instead of 8 v_med3_f32 + 4 conversions (A/B on one box: rollout 8.3 -> 8.1 ms, chain with stores -1.5 %).
-__device__ static inline bf16x8 relu_pack_bf16(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+__device__ static inline uint32_t relu_pack_bf16x2(float a, float b) {
     typedef short i16x2 __attribute__((ext_vector_type(2)));
-    bf16x8 v = {(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3, (__bf16)a4, (__bf16)a5, (__bf16)a6, (__bf16)a7};
-    uint4 u = __builtin_bit_cast(uint4, v);
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = __builtin_convertvector(f32x2{a, b}, bf16x2);          // ONE v_cvt_pk_bf16_f32
     const i16x2 zero = {0, 0};
-    u.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, u.x), zero));
-    u.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, u.y), zero));
-    u.z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, u.z), zero));
-    u.w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, u.w), zero));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, p), zero));
+}
+__device__ static inline bf16x8 relu_pack_bf16(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    const uint4 u = {relu_pack_bf16x2(a0, a1), relu_pack_bf16x2(a2, a3), relu_pack_bf16x2(a4, a5), relu_pack_bf16x2(a6, a7)};
     return __builtin_bit_cast(bf16x8, u);
 }
 
