@@ -72,11 +72,13 @@ __device__ static inline uint32_t tile_mask_bits(bf16x8 lo, bf16x8 hi) {
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit.  (Inline
-        // assembly: written with __builtin_elementwise_min, hipcc turns it into two compares + selects per dword.)
-        uint32_t y;
+        // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit, shifted
+        // into place and merged by one v_lshl_or_b32.  (Inline assembly: from the C form hipcc makes two compares +
+        // selects per dword and separate shift / or instructions.)
+        uint32_t y, mo;
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(d[k]), "v"(one));
-        m |= y << k;
+        asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(mo) : "v"(y), "n"(k), "v"(m));
+        m = mo;
     }
     return m;
 }
