@@ -148,16 +148,24 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
                 uint32_t ow[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    // features 2w, 2w+1 of the lane's 8: accumulator (e = w>>1, r = 2(w&1) + {0,1}).
-                    // post-ReLU activations are >= 0: positive  <=>  nonzero magnitude bits and sign clear
-                    const uint32_t a_lo = mw[w] & 0xFFFFu, a_hi = mw[w] >> 16;
-                    const bool p_lo = ok[t] && (kBits ? ((bw >> w) & 1u) != 0 : ((a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u)));
-                    const bool p_hi = ok[t] && (kBits ? ((bw >> (w + 16)) & 1u) != 0 : ((a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u)));
-                    const uint32_t o_lo = p_lo ? f32_to_bf16_bits(acc[t][w >> 1][2 * (w & 1)]) : 0u;
-                    const uint32_t o_hi = p_hi ? f32_to_bf16_bits(acc[t][w >> 1][2 * (w & 1) + 1]) : 0u;
-                    bsum[p][2 * w] += bf16_bits_to_f32(o_lo);
-                    bsum[p][2 * w + 1] += bf16_bits_to_f32(o_hi);
-                    ow[w] = o_lo | (o_hi << 16);
+                    // features 2w, 2w+1 of the lane's 8: accumulator (e = w>>1, r = 2(w&1) + {0,1}), rounded as a pair
+                    // (one v_cvt_pk_bf16_f32) and ANDed with the pair's keep-mask
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const uint32_t pk = __builtin_bit_cast(
+                        uint32_t, __builtin_convertvector(f32x2{acc[t][w >> 1][2 * (w & 1)], acc[t][w >> 1][2 * (w & 1) + 1]}, bf16x2));
+                    uint32_t keep;
+                    if constexpr (kBits) {
+                        keep = ((bw >> w) & 0x00010001u) * 0xFFFFu;            // bit w -> low half, bit w+16 -> high half
+                    } else {
+                        // post-ReLU activations are >= 0: positive  <=>  nonzero magnitude bits and sign clear
+                        const uint32_t a_lo = mw[w] & 0xFFFFu, a_hi = mw[w] >> 16;
+                        keep = (((a_lo & 0x7FFFu) != 0 && !(a_lo & 0x8000u)) ? 0x0000FFFFu : 0u) |
+                               (((a_hi & 0x7FFFu) != 0 && !(a_hi & 0x8000u)) ? 0xFFFF0000u : 0u);
+                    }
+                    ow[w] = ok[t] ? (pk & keep) : 0u;
+                    bsum[p][2 * w] += bf16_bits_to_f32(ow[w] & 0xFFFFu);
+                    bsum[p][2 * w + 1] += __uint_as_float(ow[w] & 0xFFFF0000u);
                 }
                 if (ok[t]) op[t][4 * p] = uint4{ow[0], ow[1], ow[2], ow[3]};
             }
