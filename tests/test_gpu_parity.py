@@ -560,7 +560,7 @@ def test_pipeline_trains_and_checkpoints(tg, dev, tmp_path, monkeypatch):
 # hand-scheduled MLP (GEMM chain + tg_relu_bwd_bias) against torch autograd
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("dims", [(20, 4, (256, 256, 256)), (5, 1, (128, 64)), (10, 2, (32,))])
+@pytest.mark.parametrize("dims", [(20, 4, (256, 256, 256)), (5, 1, (128, 64)), (10, 2, (32,)), (10, 2, (128, 128, 128)), (3, 1, (256,))])
 def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
     """Reference = torch fp32 autograd of the same module.  Gradients are sums over ~25k rows through ReLU masks: a
     single mask flip from rounding moves a hidden-layer gradient by ~5e-4 relative (also seen between torch fp32 and
