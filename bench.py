@@ -233,8 +233,7 @@ def main():
 
     dx_launches = []                        # (ms, algorithmic bytes, rows) per launch, the update's dominant kernel
     for m in learner_mlps:
-        dx_launches += [(a.elapsed_time(b), rows * (2 * (k + mm) + (mm // 8 if bits else 2 * mm)), rows)
-                        for a, b, rows, k, mm, bits in m.dx_events]
+        dx_launches += [(a.elapsed_time(b), rows * bpr, rows, name) for a, b, rows, bpr, name in m.dx_events]
         m.dx_events = None
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     relu_probe = None
@@ -351,9 +350,9 @@ def main():
             # the kernel with the most GPU time in the step (29 %, profiles/r01_learner_bench_kernel_stats.csv): a hidden
             # layer's backward-data product fused with the ReLU backward and bias gradient below it.  Algorithmic bytes
             # per row = read dZ (2K) + read the ReLU masks (M/8 as bits, 2M from the activations) + write dZ_below (2M).
-            dur = sum(d for d, _, _ in dx_launches) * 1e-3
-            nbytes = sum(b for _, b, _ in dx_launches)
-            nrows = sum(r for _, _, r in dx_launches)
+            dur = sum(d for d, _, _, _ in dx_launches) * 1e-3
+            nbytes = sum(b for _, b, _, _ in dx_launches)
+            nrows = sum(r for _, _, r, _ in dx_launches)
             ach = nbytes / dur / 1e9
             # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
             traffic = DX_PMC_BYTES_PER_ROW * nrows / len(dx_launches)
@@ -361,7 +360,7 @@ def main():
                                "traffic": traffic,
                                "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1058 B/row "
                                                  "(1.002 x algorithmic), times this run's average rows per launch",
-                               "kernel": "tg::dx_relu_bias_kernel<256,256,1,8,bits>", "bytes_per_row": nbytes / nrows,
+                               "kernel": dx_launches[0][3], "bytes_per_row": nbytes / nrows,
                                "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
                                "avg_rows_per_launch": nrows / len(dx_launches),
                                "TFLOPs": 2.0 * 256 * 256 * nrows / dur / 1e12,

@@ -703,6 +703,37 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     assert float((out_c - out_l).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize("dims,rows", [((20, 4, (256,) * 5), 70001), ((20, 1, (256,) * 3), 257), ((10, 2, (256,) * 4), 1)])
+def test_backward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
+    """tg_mlp_backward_chain (every hidden layer's dZ in one launch) against the per-layer kernels of the same GemmMLP:
+    the same gradients up to bf16 rounding of the head's product, bit-identical from run to run."""
+    from trajopt_grpo_amd.mlp import GemmMLP
+    S, A, hidden = dims
+    torch.manual_seed(rows + S)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    mlp = GemmMLP(net, torch.bfloat16)
+    assert mlp._bchain is not None
+    xp = mlp.prepare_input(torch.randn(rows, S, device=dev))
+    g = torch.randn(rows, A, device=dev)
+
+    def grads(use_chain):
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        keep, mlp._bchain = mlp._bchain, (mlp._bchain if use_chain else None)
+        mlp.forward(xp, keep=True)
+        mlp.backward(g)
+        mlp._bchain = keep
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+
+    a, b, a2 = grads(True), grads(False), grads(True)
+    for x, y in zip(a, a2):
+        assert torch.equal(x, y)                                   # deterministic reductions
+    for (n, _), x, y in zip(net.named_parameters(), a, b):
+        denom = float(y.norm()) + 1e-12
+        assert float((x - y).norm()) / denom < 2e-2, n            # the head's product is bf16 x bf16 here, fp32 there
+
+
 def test_weight_gradient_split_k_paths_agree(tg, dev):
     """GemmMLP._dw: the fixed-batch-count split (>= 2^19 rows) and the fixed-block split below it against one fp32 GEMM."""
     from trajopt_grpo_amd.mlp import GemmMLP

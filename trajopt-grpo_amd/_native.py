@@ -77,6 +77,8 @@ SIGNATURES = {
     "tg_dx_relu_bias_blocks": (C.c_int, []),
     "tg_dx_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "tg_dx_relu_bias": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    "tg_mlp_backward_chain_blocks": (C.c_int, []),
+    "tg_mlp_backward_chain": (C.c_int, [_VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),
     "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,
                                        _VP]),
 }

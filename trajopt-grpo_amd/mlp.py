@@ -71,14 +71,20 @@ class GemmMLP:
                 if lib.tg_dx_relu_bias_supported(o, k):
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
-        # when set to a list, every tg_dx_relu_bias launch is bracketed by HIP events on the launch stream and
-        # (start, end, rows, K, M, mask-bits?) is appended (bench.py reads them back for that kernel's roofline)
+        # when set to a list, every backward-data launch (tg_mlp_backward_chain or tg_dx_relu_bias) is bracketed by HIP
+        # events on the launch stream and (start, end, rows, algorithmic bytes per row, kernel name) is appended
+        # (bench.py reads them back for that kernel's roofline)
         self.dx_events = None
         # all layers of the forward pass in one launch (tg_mlp_forward_chain) when the shape allows
         self._chain = None
         H = fused_rollout_supported(net, min(self.in_dim, 32), 1) if compute_dtype == torch.bfloat16 else 0
+        self._bchain = None
         if H and self.in_dim <= 32 and self.out_pad <= 16 and len(self.linears) - 1 <= 8:
             self._chain = FragmentStream(net, H, layout="chain")
+            # ... and the backward-data pass as one launch too (tg_mlp_backward_chain): dZ stays on chip from the head down
+            if H == 256 and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 8:
+                self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
+                self._bchain_partial = None
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
         self.refresh()
 
@@ -91,6 +97,8 @@ class GemmMLP:
             self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
             if self._chain is not None:
                 self._chain.refresh()
+            if self._bchain is not None:
+                self._bchain.refresh()
             for w, frag in zip(self.w, self._dxfrag):
                 if frag is not None:
                     N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
@@ -155,6 +163,35 @@ class GemmMLP:
             out = tail if out is None else out + tail
         return out
 
+    def _backward_chain(self, dz_head, acts, bits, rows, device):
+        """All hidden layers' dZ in one launch (tg_mlp_backward_chain), then the weight gradients layer by layer."""
+        lib = N.load()
+        L = len(self.linears)
+        nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
+        H = self._bchain.H
+        dzs = [torch.empty(rows, H, dtype=self.cd, device=device) for _ in range(nh)]
+        if self._bchain_partial is None:
+            self._bchain_partial = torch.empty(lib.tg_mlp_backward_chain_blocks(), nh, H, dtype=torch.float32, device=device)
+        dz_ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+        m_ptrs = (N.C.c_void_p * nh)(*[bits[L - 1 - j].data_ptr() for j in range(nh)])     # bits[i + 1] masks hidden layer i
+        ev = None
+        if self.dx_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(lib.tg_mlp_backward_chain(dz_head.data_ptr(), self._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
+                                          self._bchain_partial.data_ptr(), N.stream_ptr(device)), "tg_mlp_backward_chain")
+        if ev is not None:
+            ev[1].record()
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), "tg::mlp_bwd_chain_kernel<256,8>"))
+        bgrad = self._bchain_partial.sum(0)                     # [nh][H], chain order
+        for j in range(nh):
+            i = L - 2 - j
+            lin = self.linears[i]
+            lin.bias.grad.add_(bgrad[j])
+            dw = self._dw(dzs[j], acts[i])
+            lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
+        self._acts = self._bits = None
+
     @torch.no_grad()
     def backward(self, dout: torch.Tensor):
         """dout fp32 [rows][out_dim] = d loss / d output.  Accumulates into weight.grad / bias.grad (fp32)."""
@@ -170,6 +207,9 @@ class GemmMLP:
         lin = self.linears[-1]
         lin.bias.grad.add_(dout.sum(0))
         lin.weight.grad.add_(self._dw(dz, acts[L - 1])[:self.out_dim])
+        if self._bchain is not None and self._bits is not None:
+            self._backward_chain(dz, acts, bits, rows, dout.device)
+            return
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0
         nblk = lib.tg_relu_bwd_bias_blocks()
         fuse_head = self.out_dim <= 8
@@ -194,7 +234,8 @@ class GemmMLP:
                         "tg_dx_relu_bias")
                 if ev is not None:
                     ev[1].record()
-                    self.dx_events.append((ev[0], ev[1], rows, dz.shape[1], cols, mb is not None))
+                    self.dx_events.append((ev[0], ev[1], rows, 2 * (dz.shape[1] + cols) + (cols // 8 if mb is not None else 2 * cols),
+                                           "tg::dx_relu_bias_kernel<%d,%d>" % (cols, dz.shape[1])))
                 dz = dz_below
             else:
                 if self._partial is None or self._partial.shape[1] != cols:
@@ -261,16 +302,21 @@ class FragmentStream:
     for the chain kernel row(m) = 16*((m>>2)&1) + 4*(m>>3) + (m&3), which makes a lane's 16 accumulator registers
     16 consecutive output features."""
 
-    def __init__(self, net, H: int, layout: str = "rollout"):
+    def __init__(self, net, H: int, layout: str = "rollout", transposed: bool = False):
+        """transposed=True: the stream of the backward chain (tg_mlp_backward_chain): the head first, then the
+        hidden-to-hidden layers from the top down, every matrix transposed ([in][out]); no bias table."""
         assert layout in ("rollout", "chain")
-        self.lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
-        dev = self.lin[0].weight.device
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        self.transposed = transposed
+        self.lin = lin[:0:-1] if transposed else lin            # head, L-2, ..., 1  |  0, 1, ..., head
+        dev = lin[0].weight.device
         self.H = H
         m = torch.arange(64, device=dev) & 31
         row = (m if layout == "rollout" else 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)).view(1, -1, 1)
         flat_idx, self._slices, off = [], [], 0
         for li, l in enumerate(self.lin):
-            m_pad, k_pad = _round_up(l.out_features, 32), _round_up(l.in_features, 32)
+            rows_, cols_ = (l.in_features, l.out_features) if transposed else (l.out_features, l.in_features)
+            m_pad, k_pad = _round_up(rows_, 32), _round_up(cols_, 32)
             kidx = _fragment_index(k_pad, dev) if layout == "rollout" else _chain_fragment_index(k_pad, dev, li == 0)
             for mo in range(m_pad // 32):
                 flat_idx.append((off + (32 * mo + row).expand_as(kidx) * k_pad + kidx).reshape(-1))
@@ -285,10 +331,12 @@ class FragmentStream:
     @torch.no_grad()
     def refresh(self):
         for l, (off, m_pad, k_pad) in zip(self.lin, self._slices):
-            self._wflat[off:off + m_pad * k_pad].view(m_pad, k_pad)[:l.out_features, :l.in_features].copy_(l.weight)
+            w = l.weight.t() if self.transposed else l.weight
+            self._wflat[off:off + m_pad * k_pad].view(m_pad, k_pad)[:w.shape[0], :w.shape[1]].copy_(w)
         torch.index_select(self._wflat, 0, self._idx, out=self.stream)
-        for li, l in enumerate(self.lin):
-            self.bias[li, :l.out_features].copy_(l.bias)
+        if not self.transposed:
+            for li, l in enumerate(self.lin):
+                self.bias[li, :l.out_features].copy_(l.bias)
 
 
 def fragment_stream(net, H: int):
