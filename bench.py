@@ -11,18 +11,19 @@ env-step is one valid (mask == 1) Env.step.  Weak scaling: every rank runs 65,53
 once per optimizer step (RCCL).
 
 Besides the contract fields, the JSON line carries
-  roofline         the kernel with the most GPU time in the step (29 %): tg_dx_relu_bias, a hidden layer's backward-data
-                   product fused with the ReLU backward and bias gradient below it.  HBM-bound; algorithmic bytes = read
-                   dZ (512) + read the 1-bit ReLU masks (32) + write dZ_below (512) = 1056 B per row at 256 bf16
-                   features (1536 B when the masks come from the activations themselves); EVERY launch of the timed steps
-                   is bracketed by HIP events on the launch stream.  (With an fp32 policy that kernel does not run and
-                   `roofline` is the rollout kernel's.)
+  roofline         the kernel with the most GPU time in the step (29 %): tg_mlp_backward_chain, the backward-data pass of
+                   all hidden layers in one launch.  HBM-bound (writes); algorithmic bytes per row = 16 (dOut) +
+                   5 x 32 (1-bit ReLU masks) + 5 x 512 (the dZ it must write for the weight gradients) = 2736 B at
+                   20-256x5-4; EVERY launch of the timed steps is bracketed by HIP events on the launch stream.
+                   (Shapes without that kernel report tg_dx_relu_bias; with an fp32 policy `roofline` is the rollout
+                   kernel's.)
   rollout_kernel   the fused rollout kernel against the MFMA roofline: 2 x actor parameters flop per valid env-step
                    (539 kflop), HIP events around each rollout's launch; `all_alive` = the same kernel with
                    nobody terminating.  With --no-fused: the per-step dynamics kernel against the HBM roofline (189 B
                    per env-step, SURVEY 8d state-in-trajectory variant).
   dynamics_kernel  the stand-alone dynamics kernel (tg_rollout_step) at this env count, HBM roofline, timed after the run;
-  learner_kernel   tg_dx_relu_bias on random data at the learner's chunk size (2^22 rows), timed after the run;
+  learner_kernel   tg_dx_relu_bias (the per-layer form of the backward-data pass) on random data at 2^22 rows, timed after
+                   the run;
   cpu_baseline     the CPU port of the reference path (oracle/: scalar fp64 env + batch-1 torch policy per step in
                    forked worker processes, then PPO.learn on CPU) timed on this box's host cores over a bounded
                    sample of the same workload.
@@ -38,7 +39,7 @@ sys.path.insert(0, REPO)
 
 HIDDEN = (256, 256, 256, 256, 256)
 ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
-DX_PMC_BYTES_PER_ROW = 4438938608 / 4194304                          # profiles/r01_dx_kernel_probe_pmc.json (1-bit masks)
+BWD_PMC_BYTES_PER_ROW = 12092427634 / 4194304                        # profiles/r01_bwd_chain_probe_pmc.json
 HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -347,19 +348,19 @@ def main():
                 out["rollout_kernel"]["full_launch_us"] = 1e6 * d_full
                 out["rollout_kernel"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
         if dx_launches:
-            # the kernel with the most GPU time in the step (29 %, profiles/r01_learner_bench_kernel_stats.csv): a hidden
-            # layer's backward-data product fused with the ReLU backward and bias gradient below it.  Algorithmic bytes
-            # per row = read dZ (2K) + read the ReLU masks (M/8 as bits, 2M from the activations) + write dZ_below (2M).
+            # the kernel with the most GPU time in the step (29 %, profiles/r01_learner_bench_kernel_stats.csv): the
+            # backward-data pass (tg_mlp_backward_chain; per-layer tg_dx_relu_bias for shapes without it).  Algorithmic
+            # bytes per row come with each event record (mlp.GemmMLP.dx_events).
             dur = sum(d for d, _, _, _ in dx_launches) * 1e-3
             nbytes = sum(b for _, b, _, _ in dx_launches)
             nrows = sum(r for _, _, r, _ in dx_launches)
             ach = nbytes / dur / 1e9
             # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
-            traffic = DX_PMC_BYTES_PER_ROW * nrows / len(dx_launches)
+            traffic = BWD_PMC_BYTES_PER_ROW * nrows / len(dx_launches) if "bwd_chain" in dx_launches[0][3] else None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic,
-                               "traffic_source": "profiles/r01_dx_kernel_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 1058 B/row "
-                                                 "(1.002 x algorithmic), times this run's average rows per launch",
+                               "traffic_source": "profiles/r01_bwd_chain_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 2883 B/row "
+                                                 "(1.054 x algorithmic), times this run's average rows per launch",
                                "kernel": dx_launches[0][3], "bytes_per_row": nbytes / nrows,
                                "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
                                "avg_rows_per_launch": nrows / len(dx_launches),
