@@ -149,7 +149,7 @@ class GemmMLP:
         if rows >= _SPLIT_BATCHES * 4096:
             # big batches: a fixed number of row blocks (2 output tiles each: every CU busy) keeps the fp32 partials --
             # written once, read once by the reduction -- at 128 x 256 KB whatever the row count (3 % at 4 M rows)
-            nb, bs = _SPLIT_BATCHES, (rows // _SPLIT_BATCHES) // 64 * 64
+            nb, bs = _SPLIT_BATCHES, rows // _SPLIT_BATCHES            # any block length: the tail is < 128 rows
         else:
             nb, bs = rows // _ROW_BLOCK, _ROW_BLOCK
         out = None
