@@ -42,20 +42,24 @@ __device__ static inline f32x16 bias_tile(const float* __restrict__ b16) {
 // Activation stores.  After two output tiles a lane (n, h) holds 4 x 16 B of row n's 128-B line (tile t, half h, 16-B
 // piece sh at byte 64 t + 32 h + 16 sh).  Stored as they stand an instruction would write 32 rows x 32 B, and that
 // pattern alone caps at 4.1 TB/s on this chip; so the wave transposes the 32 x 128 B through its LDS staging area
-// (pitch 144 B: conflict-free b128 writes, 2-way reads) and each of its 4 store instructions writes 8 WHOLE 128-B lines
+// (XOR-swizzled chunks: conflict-free both ways) and each of its 4 store instructions writes 8 WHOLE 128-B lines
 // (5.1 TB/s for the same bytes).  `__restrict__`: see bias_tile.  Rows past the end are clamped: the lanes that
 // computed them worked on the last row's input, so they rewrite the last row with identical bytes.
 __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
                                          int lane, bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi) {
-    uint4* w = st + (lane & 31) * 9 + 2 * (lane >> 5);
-    w[0] = __builtin_bit_cast(uint4, a_lo);
-    w[1] = __builtin_bit_cast(uint4, a_hi);
-    w[4] = __builtin_bit_cast(uint4, b_lo);
-    w[5] = __builtin_bit_cast(uint4, b_hi);
+    // staging image: 32 rows x 8 chunks of 16 B, chunk c of row n at n*8 + (c ^ ((n>>1)&7)): conflict-free b128 writes
+    // (16 lanes = 16 rows, same chunk: row parity x swizzled chunk are 16 different bank groups) and reads (8 lanes per
+    // row, two rows of opposite parity per 16-lane pass)
+    const int n = lane & 31, sw = (n >> 1) & 7, c0 = 2 * (lane >> 5);
+    uint4* w = st + n * 8;
+    w[(c0 + 0) ^ sw] = __builtin_bit_cast(uint4, a_lo);
+    w[(c0 + 1) ^ sw] = __builtin_bit_cast(uint4, a_hi);
+    w[(c0 + 4) ^ sw] = __builtin_bit_cast(uint4, b_lo);
+    w[(c0 + 5) ^ sw] = __builtin_bit_cast(uint4, b_hi);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * j + (lane >> 3), c = lane & 7;
-        const uint4 v = st[r * 9 + c];
+        const uint4 v = st[r * 8 + (c ^ ((r >> 1) & 7))];
         int64_t row = row0 + r;
         row = row < rows ? row : rows - 1;
         *reinterpret_cast<uint4*>(g + row * ld + 8 * c) = v;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     uint4* ring = lds;                                                  // D * KS * 64 uint4
     float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
     uint4* xs = reinterpret_cast<uint4*>(bias_s + (n_hh + 2) * H);      // WPW waves * 2 pieces * 64 uint4
-    uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 9);    // per wave: 32 rows x 144 B (store_pair)
+    uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 8);    // per wave: 32 rows x 128 B (store_pair)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
@@ -272,7 +276,7 @@ static int chain_launch(const void* x, const void* wfrag, const float* bias, int
                         int out_cols, hipStream_t st) {
     constexpr int WPW = 8, KS = H / 16;
     const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048 +
-                         (size_t)WPW * 32 * 144;
+                         (size_t)WPW * 32 * 128;
     auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D>;
     static size_t attr_bytes = 0;
     if (shmem > 64 * 1024 && shmem > attr_bytes) {
