@@ -40,6 +40,7 @@ __device__ static inline void store_tile_swapped(uint16_t* __restrict__ p, bf16x
     const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
     const auto s2 = __builtin_amdgcn_permlane32_swap(a.z, b.z, false, false);
     const auto s3 = __builtin_amdgcn_permlane32_swap(a.w, b.w, false, false);
+    // (NOT non-temporal: these are 32-B pieces of 128-B lines that L2 merges; as non-temporal stores they took 2.4x as long)
     *reinterpret_cast<uint4*>(p) = uint4{s0[0], s1[0], s2[0], s3[0]};          // features  0..15 of the tile
     *reinterpret_cast<uint4*>(p + 16) = uint4{s0[1], s1[1], s2[1], s3[1]};     // features 16..31
 }

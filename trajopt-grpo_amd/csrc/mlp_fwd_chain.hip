@@ -62,7 +62,9 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
         const uint4 v = st[r * 8 + (c ^ ((r >> 1) & 7))];
         int64_t row = row0 + r;
         row = row < rows ? row : rows - 1;
-        *reinterpret_cast<uint4*>(g + row * ld + 8 * c) = v;
+        // non-temporal: written once, read by a later kernel (A/B: 2.96 -> 2.91 ms per 2^22 rows)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * c));
     }
 }
 
