@@ -43,6 +43,24 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class _Workspace:
+    """Grow-only named device buffers for the per-chunk tensors of a forward/backward (activations, mask bits, dZ).
+    Their size follows the number of valid rows, which changes every iteration; handed to the caching allocator, a
+    GB-sized request that outgrows what is cached costs a hipMalloc (the update was measured up to 2x slower when the
+    row count kept growing).  A buffer here is allocated once per name at the largest size seen and handed out as a view;
+    with the learner's fixed first chunk that size is reached in the first update."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, name: str, rows: int, cols: int, dtype, device) -> torch.Tensor:
+        need = rows * cols
+        b = self._buf.get(name)
+        if b is None or b.numel() < need or b.dtype != dtype or b.device != device:
+            self._buf[name] = b = torch.empty(need, dtype=dtype, device=device)
+        return b[:need].view(rows, cols)
+
+
 class GemmMLP:
     def __init__(self, net, compute_dtype=torch.bfloat16):
         assert supports(net)
@@ -61,6 +79,7 @@ class GemmMLP:
             self.b.append(torch.zeros(o, dtype=compute_dtype, device=dev))
         self._acts = None
         self._bits = None
+        self._ws = _Workspace()
         self._partial = None
         # hidden layers whose backward-data product runs fused with the ReLU backward below it (tg_dx_relu_bias)
         self._dxfrag = [None] * len(self.linears)
@@ -117,9 +136,9 @@ class GemmMLP:
         L = len(self.linears)
         if self._chain is not None and xp.shape[0] > 0:
             rows, H = xp.shape[0], self._chain.H
-            hid = [torch.empty(rows, H, dtype=self.cd, device=xp.device) for _ in range(L - 1)] if keep else []
+            hid = [self._ws.get(f"a{i}", rows, H, self.cd, xp.device) for i in range(L - 1)] if keep else []
             # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
-            bits = [torch.empty(rows, H // 32, dtype=torch.int32, device=xp.device) for _ in range(L - 1)] if keep else []
+            bits = [self._ws.get(f"m{i}", rows, H // 32, torch.int32, xp.device) for i in range(L - 1)] if keep else []
             out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
             ptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in hid]) if keep else None
             mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
@@ -169,7 +188,7 @@ class GemmMLP:
         L = len(self.linears)
         nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
         H = self._bchain.H
-        dzs = [torch.empty(rows, H, dtype=self.cd, device=device) for _ in range(nh)]
+        dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) for j in range(nh)]
         if self._bchain_partial is None:
             self._bchain_partial = torch.empty(lib.tg_mlp_backward_chain_blocks(), nh, H, dtype=torch.float32, device=device)
         dz_ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
@@ -202,7 +221,7 @@ class GemmMLP:
         rows = dout.shape[0]
         L = len(self.linears)
         dout = dout.contiguous()
-        dz = torch.zeros(rows, self.out_pad, dtype=self.cd, device=dout.device)
+        dz = self._ws.get("z_head", rows, self.out_pad, self.cd, dout.device).zero_()
         dz[:, :self.out_dim].copy_(dout)
         lin = self.linears[-1]
         lin.bias.grad.add_(dout.sum(0))
