@@ -89,6 +89,7 @@ class _GpuLearner(Algorithm):
         self.fused_mlp = fused_mlp
         self._bucket = None
         self._mlps = {}
+        self._ws = M._Workspace()       # per-iteration tensors whose size follows the number of valid rows
         self.last_stats = {}
 
     def learn(self, buffer) -> None:
@@ -117,9 +118,11 @@ class _GpuLearner(Algorithm):
             if m is not None:
                 m.refresh()
 
-    def _prep(self, net, X):
+    def _prep(self, net, X, cap_rows=0):
         m = self._mlp(net)
-        return m.prepare_input(X) if m is not None else X
+        if m is None:
+            return X
+        return m.prepare_input(X, out=self._ws.get("xin", X.shape[0], m.in_pad, m.cd, X.device, cap_rows))
 
     def _forward(self, net, x, train=False):
         """fp32 output [rows][out].  train=True keeps what backward needs (activations or the autograd graph)."""
@@ -143,11 +146,14 @@ class _GpuLearner(Algorithm):
     def _gather_valid(self, traj):
         """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
         idx = traj.mask.reshape(-1).nonzero().squeeze(1)
-        X = traj.obs_rows().index_select(0, idx)
-        if X.dtype != torch.float32:
-            X = X.float()
-        act = traj.act_rows().index_select(0, idx)
-        return idx, X.contiguous(), act.contiguous()
+        rows_all, cap = traj.obs_rows(), traj.T * traj.n
+        if rows_all.dtype == torch.float32:
+            X = torch.index_select(rows_all, 0, idx, out=self._ws.get("X", idx.numel(), traj.S, torch.float32, idx.device, cap))
+        else:
+            X = rows_all.index_select(0, idx).float().contiguous()
+        acts_all = traj.act_rows()
+        act = torch.index_select(acts_all, 0, idx, out=self._ws.get("act", idx.numel(), traj.A, acts_all.dtype, idx.device, cap))
+        return idx, X, act
 
     def _logp_nograd(self, actor, xin, act, var):
         out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
@@ -188,7 +194,7 @@ class GRPO(_GpuLearner):
         coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
         actor = self.policy.actor
         self._refresh(actor, self.old_policy.actor)
-        xin = self._prep(actor, X)
+        xin = self._prep(actor, X, traj.T * traj.n)
         old_logp = self._logp_nograd(self.old_policy.actor, xin, act, var)  # grpo.py:118-119
         Js = []
         for _ in range(self.updates_per_iter):
@@ -273,7 +279,7 @@ class PPO(_GpuLearner):
         idx, X, act = self._gather_valid(traj)
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
         self._refresh(self.policy.actor, self.policy.critic)
-        xin = self._prep(self.policy.actor, X)          # actor and critic share input width / compute dtype
+        xin = self._prep(self.policy.actor, X, traj.T * traj.n)   # actor and critic share input width / compute dtype
         # V on valid rows only; padded rows never reach a result (they are masked in both scans)
         v_valid = self._values_nograd(xin)                                  # ppo.py:93
         V = torch.zeros(T * n, dtype=torch.float32, device=X.device)

@@ -53,11 +53,12 @@ class _Workspace:
     def __init__(self):
         self._buf = {}
 
-    def get(self, name: str, rows: int, cols: int, dtype, device) -> torch.Tensor:
+    def get(self, name: str, rows: int, cols: int, dtype, device, cap_rows: int = 0) -> torch.Tensor:
+        """[rows][cols] view of buffer `name`; a (re)allocation sizes it for max(rows, cap_rows) rows."""
         need = rows * cols
         b = self._buf.get(name)
         if b is None or b.numel() < need or b.dtype != dtype or b.device != device:
-            self._buf[name] = b = torch.empty(need, dtype=dtype, device=device)
+            self._buf[name] = b = torch.empty(max(rows, cap_rows) * cols, dtype=dtype, device=device)
         return b[:need].view(rows, cols)
 
 
@@ -123,9 +124,10 @@ class GemmMLP:
                     N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
                                                         N.stream_ptr(w.device)), "tg_dx_pack_weights")
 
-    def prepare_input(self, X: torch.Tensor) -> torch.Tensor:
-        """[M][in_dim] (any float dtype, any strides) -> contiguous [M][in_pad] compute dtype, zero padded."""
-        xp = torch.zeros(X.shape[0], self.in_pad, dtype=self.cd, device=X.device)
+    def prepare_input(self, X: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """[M][in_dim] (any float dtype, any strides) -> contiguous [M][in_pad] compute dtype, zero padded
+        (into `out` when given: a [M][in_pad] buffer of the compute dtype)."""
+        xp = torch.zeros(X.shape[0], self.in_pad, dtype=self.cd, device=X.device) if out is None else out.zero_()
         xp[:, :self.in_dim].copy_(X)
         return xp
 
