@@ -269,7 +269,7 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
                           float* d_out, int32_t out_cols, void* stream);
 
 /* ---- MLP backward-data pass, all hidden layers in one persistent launch ----
- * For Linear(in, 256) ReLU [Linear(256, 256) ReLU]^(n_hidden_layers-1) Linear(256, out <= 8), 3..8 hidden layers, bf16:
+ * For Linear(in, 256) ReLU [Linear(256, 256) ReLU]^(n_hidden_layers-1) Linear(256, out <= 8), 3..6 hidden layers, bf16:
  *   dZ_top   = (dOut . W_head)  * (a_top   > 0)
  *   dZ_below = (dZ   . W_layer) * (a_below > 0)           for every hidden-to-hidden layer, from the top down
  * a row's gradient stays on chip from the head to the first hidden layer; read 16 B + 32 B of mask bits per layer,

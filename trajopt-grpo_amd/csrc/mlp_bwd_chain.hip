@@ -15,9 +15,9 @@
 // accumulator tile of a layer IS the B operand of the layer below (keep-mask AND instead of bias + ReLU), W^T streams
 // L2 -> LDS through the LDS-DMA ring (mlp.FragmentStream(layout="chain") of the transposed weights, head first).
 // The mask bits of a layer (1 KiB per wave) arrive by LDS-DMA two layers ahead, dOut one round ahead; neither is counted
-// in the ring's waits (more operations behind a block only make its wait stricter).  Every output tile issues exactly
-// two stores per wave, always (rows past the end are clamped to the last row and rewrite it with identical bytes), so
-// the counted wait is vmcnt(2 P + (P-1) KS/WPW) at every site.
+// in the ring's waits (more operations behind a block only make its wait stricter).  Every second output tile issues
+// exactly four stores per wave, always (rows past the end are clamped to the last row and rewrite it with identical
+// bytes), so the counted wait is the same at every site.
 // Bias gradients: the column sums of a tile over the wave's 32 rows are formed by letting the matrix core transpose the
 // tile (column_sums below) and accumulated in a per-wave LDS table, which the workgroup adds up in a fixed order at
 // the end: deterministic.
@@ -25,24 +25,33 @@
 
 namespace tg {
 
-constexpr int kBwdMaxLayers = 8;
+constexpr int kBwdMaxLayers = 6;        // 8 KiB of LDS per layer for the per-wave bias tables: 112 + 8 n <= 160 KiB
 struct BwdChainPtrs {
     uint16_t* dz[kBwdMaxLayers];            // outputs, top hidden layer first: bf16 [rows][H]
     const uint32_t* mask[kBwdMaxLayers];    // ReLU mask bits of the same layers (tg_mlp_forward_chain): u32 [rows][H/32]
 };
 
-// A lane (n, h) holds features 16 h + 0..15 of its row's 32-feature tile as two 16-B halves (lo, hi).  After swapping
-// the upper lanes' lo with the lower lanes' hi (v_permlane32_swap) each store instruction writes 32 contiguous bytes
-// per row.  `p` = row base + 32 mt + 8 h (elements).
-__device__ static inline void store_tile_swapped(uint16_t* __restrict__ p, bf16x8 lo, bf16x8 hi) {
-    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
-    const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-    const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-    const auto s2 = __builtin_amdgcn_permlane32_swap(a.z, b.z, false, false);
-    const auto s3 = __builtin_amdgcn_permlane32_swap(a.w, b.w, false, false);
-    // (NOT non-temporal: these are 32-B pieces of 128-B lines that L2 merges; as non-temporal stores they took 2.4x as long)
-    *reinterpret_cast<uint4*>(p) = uint4{s0[0], s1[0], s2[0], s3[0]};          // features  0..15 of the tile
-    *reinterpret_cast<uint4*>(p + 16) = uint4{s0[1], s1[1], s2[1], s3[1]};     // features 16..31
+// dZ stores (as the forward chain's activation stores): after two output tiles a lane (n, h) holds 4 x 16 B of row n's
+// 128-B line; the wave transposes the 32 x 128 B through its LDS staging area (XOR-swizzled 16-B chunks: conflict-free
+// both ways) and each of its 4 store instructions writes 8 WHOLE 128-B lines, non-temporal (written once, read by the
+// weight-gradient GEMM).  As 32-B pieces the same bytes took 5 % longer.  `__restrict__`: alias scope (mfma_ring.hpp).
+__device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
+                                         int lane, bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi) {
+    const int n = lane & 31, sw = (n >> 1) & 7, c0 = 2 * (lane >> 5);
+    uint4* w = st + n * 8;
+    w[(c0 + 0) ^ sw] = __builtin_bit_cast(uint4, a_lo);
+    w[(c0 + 1) ^ sw] = __builtin_bit_cast(uint4, a_hi);
+    w[(c0 + 4) ^ sw] = __builtin_bit_cast(uint4, b_lo);
+    w[(c0 + 5) ^ sw] = __builtin_bit_cast(uint4, b_hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), c = lane & 7;
+        const uint4 v = st[r * 8 + (c ^ ((r >> 1) & 7))];
+        int64_t row = row0 + r;
+        row = row < rows ? row : rows - 1;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * c));
+    }
 }
 
 // Column sums of a tile over the wave's 32 rows (the bias gradient).  Rows sit on lanes, so a lane-wise reduction costs
@@ -80,11 +89,11 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
 }
 
 // Masked epilogue of one 32-feature tile: round the accumulators pairwise, AND with the keep-masks from the layer's
-// mask word `w` (feature r of this lane: bit (mt&1)*8 + (r>>1) + 16 (r&1)), hand the packed halves on, store them and
-// add their column sums to the wave's bias table (`own` = all ones for a lane with a row of its own, else 0).
+// mask word `w` (feature r of this lane: bit (mt&1)*8 + (r>>1) + 16 (r&1)), hand the packed halves on and add their
+// column sums to the wave's bias table (`own` = all ones for a lane with a row of its own, else 0).
 template <int H>
-__device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt, bf16x8& lo, bf16x8& hi, uint16_t* __restrict__ gp,
-                                          float* __restrict__ btab, bool writer, uint32_t own, bf16x8 sel) {
+__device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt, bf16x8& lo, bf16x8& hi, float* __restrict__ btab,
+                                          bool writer, uint32_t own, bf16x8 sel) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const uint32_t wk = w >> ((mt & 1) * 8);
@@ -97,7 +106,6 @@ __device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt,
     }
     lo = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
     hi = __builtin_bit_cast(bf16x8, uint4{o[4], o[5], o[6], o[7]});
-    store_tile_swapped(gp + 32 * mt, lo, hi);
     // operand slot k = 8 h + j of `lo` is feature 16 h + j, of `hi` feature 16 h + 8 + j: lane n' = 8 h + j (n' < 16) gets
     // their sums, i.e. table entries 32 mt + 16 (n'>>3) + (n'&7) and + 8
     const float s_lo = column_sums(__builtin_bit_cast(bf16x8, uint4{ob[0], ob[1], ob[2], ob[3]}), sel);
@@ -111,14 +119,18 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                                                                     int32_t n_layers, int64_t rows, BwdChainPtrs ptrs,
                                                                     float* __restrict__ partial) {
     constexpr int MT = H / 32, KS = H / 16;
-    constexpr int D = 4, P = D - 1;
-    constexpr int kWaitN = 2 * P + (P - 1) * (KS / WPW);
+    // ring of 3 slots, 2 blocks in flight (4 / 3 measured the same; the LDS goes to the store staging instead).  Behind
+    // the block a wait is for: the DMA of the one later block and the stores of the last two tiles, one of them odd
+    // (4 stores; the head block's 16 only add to that).
+    constexpr int D = 3, P = D - 1;
+    constexpr int kWaitN = (P - 1) * (KS / WPW) + 4;
     static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
     extern __shared__ uint4 lds[];
     uint4* ring = lds;                                                  // D * KS * 64 uint4
     uint4* dzs = lds + D * KS * 64;                                     // WPW waves * 64 uint4 (lanes 0..31 used)
     uint4* mks = dzs + WPW * 64;                                        // WPW waves * 3 buffers * 64 uint4
-    float* bacc = reinterpret_cast<float*>(mks + WPW * 3 * 64);         // WPW waves * n_layers * H floats
+    uint4* stage = mks + WPW * 3 * 64 + (threadIdx.x >> 6) * (32 * 8);   // per wave: 32 rows x 128 B (store_pair)
+    float* bacc = reinterpret_cast<float*>(mks + WPW * 3 * 64 + WPW * 32 * 8);   // WPW waves * n_layers * H floats
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
@@ -191,7 +203,6 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
             dma_dzh(round + gridDim.x);
             prefetch_mask(round, 0);
             mask_words(mw);
-            uint16_t* gp = ptrs.dz[0] + row * H + 8 * h;
             float* bt = my_bacc;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -201,7 +212,10 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], gp, bt, writer, own, sel);
+                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, sel);
+                if (mt & 1)
+                    store_pair(stage, ptrs.dz[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
+                               xout[2 * mt + 1]);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
@@ -209,7 +223,6 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         }
         // ---- hidden layers, top down: dZ_below^T = W^T . dZ^T, one block per 32-feature output tile ----
         for (int j = 1; j < n_layers; ++j) {
-            uint16_t* gp = ptrs.dz[j] + row * H + 8 * h;
             float* bt = my_bacc + j * H;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -224,7 +237,10 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], gp, bt, writer, own, sel);
+                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, sel);
+                if (mt & 1)
+                    store_pair(stage, ptrs.dz[j] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
+                               xout[2 * mt + 1]);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
@@ -283,7 +299,7 @@ int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidd
         ptrs.dz[j] = (uint16_t*)d_dz[j];
         ptrs.mask[j] = (const uint32_t*)d_masks[j];
     }
-    const size_t shmem = (size_t)4 * KS * 1024 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024 + (size_t)WPW * n_hidden_layers * H * sizeof(float);
+    const size_t shmem = (size_t)3 * KS * 1024 + (size_t)WPW * 32 * 128 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024 + (size_t)WPW * n_hidden_layers * H * sizeof(float);
     TG_REQUIRE(shmem <= 160 * 1024, "tg_mlp_backward_chain: %zu B of LDS needed (> 160 KiB)", shmem);
     auto kern = mlp_bwd_chain_kernel<H, WPW>;
     static size_t attr_bytes = 0;

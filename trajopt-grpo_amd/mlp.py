@@ -102,7 +102,7 @@ class GemmMLP:
         if H and self.in_dim <= 32 and self.out_pad <= 16 and len(self.linears) - 1 <= 8:
             self._chain = FragmentStream(net, H, layout="chain")
             # ... and the backward-data pass as one launch too (tg_mlp_backward_chain): dZ stays on chip from the head down
-            if H == 256 and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 8:
+            if H == 256 and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 6:     # 6: the kernel's LDS budget
                 self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
                 self._bchain_partial = None
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
