@@ -39,7 +39,7 @@ sys.path.insert(0, REPO)
 
 HIDDEN = (256, 256, 256, 256, 256)
 ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
-BWD_PMC_BYTES_PER_ROW = 12092427634 / 4194304                        # profiles/r01_bwd_chain_probe_pmc.json
+BWD_PMC_BYTES_PER_ROW = 11481697627 / 4194304                        # profiles/r01_bwd_chain_probe_pmc.json
 HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -359,8 +359,8 @@ def main():
             traffic = BWD_PMC_BYTES_PER_ROW * nrows / len(dx_launches) if "bwd_chain" in dx_launches[0][3] else None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic,
-                               "traffic_source": "profiles/r01_bwd_chain_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 2883 B/row "
-                                                 "(1.054 x algorithmic), times this run's average rows per launch",
+                               "traffic_source": "profiles/r01_bwd_chain_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 2737 B/row "
+                                                 "(1.001 x algorithmic), times this run's average rows per launch",
                                "kernel": dx_launches[0][3], "bytes_per_row": nbytes / nrows,
                                "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
                                "avg_rows_per_launch": nrows / len(dx_launches),
