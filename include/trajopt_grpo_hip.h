@@ -269,17 +269,18 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
                           float* d_out, int32_t out_cols, void* stream);
 
 /* ---- MLP backward-data pass, all hidden layers in one persistent launch ----
- * For Linear(in, 256) ReLU [Linear(256, 256) ReLU]^(n_hidden_layers-1) Linear(256, out <= 8), 3..6 hidden layers, bf16:
+ * For Linear(in, H) ReLU [Linear(H, H) ReLU]^(n_hidden_layers-1) Linear(H, out <= 8), H in {128, 256}, 3..6 hidden
+ * layers, bf16:
  *   dZ_top   = (dOut . W_head)  * (a_top   > 0)
  *   dZ_below = (dZ   . W_layer) * (a_below > 0)           for every hidden-to-hidden layer, from the top down
- * a row's gradient stays on chip from the head to the first hidden layer; read 16 B + 32 B of mask bits per layer,
- * write 512 B per layer (2.7 instead of 4.8 KB per row at 5 layers).
+ * a row's gradient stays on chip from the head to the first hidden layer; read 16 B + H/8 B of mask bits per layer,
+ * write 2 H B per layer (H = 256, 5 layers: 2.7 instead of 4.8 KB per row).
  *   d_dout8   bf16 [rows][8]: d loss / d head output, columns >= out zero
  *   d_wfrag   bf16 stream of the TRANSPOSED weights, head first then the hidden-to-hidden layers top down
  *             (trajopt-grpo_amd/mlp.py `FragmentStream(layout="chain", transposed=True)`)
- *   d_dz      HOST array of n_hidden_layers device pointers, bf16 [rows][256]: outputs, TOP hidden layer first
- *   d_masks   HOST array of the same layers' ReLU mask bits (u32 [rows][8], as tg_mlp_forward_chain writes them)
- *   d_partial f32 [tg_mlp_backward_chain_blocks()][n_hidden_layers][256]: per-workgroup column sums of the dZ (bias
+ *   d_dz      HOST array of n_hidden_layers device pointers, bf16 [rows][H]: outputs, TOP hidden layer first
+ *   d_masks   HOST array of the same layers' ReLU mask bits (u32 [rows][H/32], as tg_mlp_forward_chain writes them)
+ *   d_partial f32 [tg_mlp_backward_chain_blocks()][n_hidden_layers][H]: per-workgroup column sums of the dZ (bias
  *             gradients; the caller sums axis 0).  Deterministic. */
 int  tg_mlp_backward_chain_blocks(void);
 int  tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,

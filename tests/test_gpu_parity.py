@@ -703,7 +703,8 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     assert float((out_c - out_l).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("dims,rows", [((20, 4, (256,) * 5), 70001), ((20, 1, (256,) * 3), 257), ((10, 2, (256,) * 4), 1)])
+@pytest.mark.parametrize("dims,rows", [((20, 4, (256,) * 5), 70001), ((20, 1, (256,) * 3), 257), ((10, 2, (256,) * 4), 1),
+                                       ((5, 1, (128,) * 3), 33333), ((20, 4, (128,) * 6), 255)])
 def test_backward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     """tg_mlp_backward_chain (every hidden layer's dZ in one launch) against the per-layer kernels of the same GemmMLP:
     the same gradients up to bf16 rounding of the head's product, bit-identical from run to run."""

@@ -154,12 +154,19 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
             __builtin_amdgcn_global_load_lds(dzh + r, (lds_void*)my_dzs, 16, 0, 0);
         }
     };
-    // mask bits of layer j for the 32 rows of `round`: lane L fetches the 16 B of (row L>>1, lane half L&1)
-    static_assert(MT == 8, "the mask staging below moves 16 B per lane half (H = 256)");
+    // mask bits of layer j for the 32 rows of `round`.  H = 256: lane L fetches the 16 B of (row L>>1, lane half L&1);
+    // H = 128: a row's two halves are 16 B together and lanes 0..31 fetch one row each.
+    static_assert(MT == 8 || MT == 4, "the mask staging moves 16 B per lane (H = 256 or 128)");
     auto dma_mask = [&](int64_t round, int j, int buf) {
-        int64_t r = round * (32 * WPW) + wave * 32 + (lane >> 1);
-        r = r < rows ? r : rows - 1;
-        __builtin_amdgcn_global_load_lds(ptrs.mask[j] + r * MT + (lane & 1) * WPL, (lds_void*)(my_mks + buf * 64), 16, 0, 0);
+        if constexpr (MT == 8) {
+            int64_t r = round * (32 * WPW) + wave * 32 + (lane >> 1);
+            r = r < rows ? r : rows - 1;
+            __builtin_amdgcn_global_load_lds(ptrs.mask[j] + r * MT + (lane & 1) * WPL, (lds_void*)(my_mks + buf * 64), 16, 0, 0);
+        } else if (lane < 32) {
+            int64_t r = round * (32 * WPW) + wave * 32 + lane;
+            r = r < rows ? r : rows - 1;
+            __builtin_amdgcn_global_load_lds(ptrs.mask[j] + r * MT, (lds_void*)(my_mks + buf * 64), 16, 0, 0);
+        }
     };
 
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
@@ -182,8 +189,13 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         dma_mask(r2, j2, (mseq + 2) % 3);
     };
     auto mask_words = [&](uint32_t (&mw)[WPL]) {
-        const uint4 v = lds_read_b128_opaque(my_mks + (mseq % 3) * 64 + col * 2 + h);
-        mw[0] = v.x; mw[1] = v.y; mw[2] = v.z; mw[3] = v.w;
+        if constexpr (MT == 8) {
+            const uint4 v = lds_read_b128_opaque(my_mks + (mseq % 3) * 64 + col * 2 + h);
+            mw[0] = v.x; mw[1] = v.y; mw[2] = v.z; mw[3] = v.w;
+        } else {
+            const uint4 v = lds_read_b128_opaque(my_mks + (mseq % 3) * 64 + col);
+            mw[0] = h ? v.z : v.x; mw[1] = h ? v.w : v.y;
+        }
     };
 
     for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
@@ -275,20 +287,11 @@ static int bwd_chain_blocks() {
 
 using namespace tg;
 
-extern "C" {
-
-int tg_mlp_backward_chain_blocks(void) { return bwd_chain_blocks(); }
-
-int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
-                          void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream) {
-    TG_REQUIRE(d_dout8 && d_wfrag && d_dz && d_masks && d_partial, "tg_mlp_backward_chain: null pointer");
-    TG_REQUIRE(hidden == 256, "tg_mlp_backward_chain: hidden width %d unsupported (256)", hidden);
-    TG_REQUIRE(n_hidden_layers >= 3 && n_hidden_layers <= kBwdMaxLayers, "tg_mlp_backward_chain: %d hidden layers outside 3..%d",
-               n_hidden_layers, kBwdMaxLayers);
-    TG_REQUIRE(rows >= 0, "tg_mlp_backward_chain: negative row count");
-    constexpr int H = 256, WPW = 8, KS = H / 16;
+template <int H>
+static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_hidden_layers, int64_t rows, void* const* d_dz,
+                            const void* const* d_masks, float* d_partial, hipStream_t st) {
+    constexpr int WPW = 8, KS = H / 16;
     const int grid_max = bwd_chain_blocks();
-    hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
         hipError_t e = hipMemsetAsync(d_partial, 0, (size_t)grid_max * n_hidden_layers * H * sizeof(float), st);
         return e == hipSuccess ? TG_OK : set_error(TG_ERR_HIP, "tg_mlp_backward_chain: memset failed (%s)", hipGetErrorString(e));
@@ -321,6 +324,22 @@ int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidd
                        ptrs, d_partial);
     TG_LAUNCH_CHECK("tg_mlp_backward_chain");
     return TG_OK;
+}
+
+extern "C" {
+
+int tg_mlp_backward_chain_blocks(void) { return bwd_chain_blocks(); }
+
+int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
+                          void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream) {
+    TG_REQUIRE(d_dout8 && d_wfrag && d_dz && d_masks && d_partial, "tg_mlp_backward_chain: null pointer");
+    TG_REQUIRE(hidden == 256 || hidden == 128, "tg_mlp_backward_chain: hidden width %d unsupported (128, 256)", hidden);
+    TG_REQUIRE(n_hidden_layers >= 3 && n_hidden_layers <= kBwdMaxLayers, "tg_mlp_backward_chain: %d hidden layers outside 3..%d",
+               n_hidden_layers, kBwdMaxLayers);
+    TG_REQUIRE(rows >= 0, "tg_mlp_backward_chain: negative row count");
+    hipStream_t st = (hipStream_t)stream;
+    return hidden == 256 ? launch_bwd_chain<256>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st)
+                         : launch_bwd_chain<128>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st);
 }
 
 }  // extern "C"

@@ -102,7 +102,7 @@ class GemmMLP:
         if H and self.in_dim <= 32 and self.out_pad <= 16 and len(self.linears) - 1 <= 8:
             self._chain = FragmentStream(net, H, layout="chain")
             # ... and the backward-data pass as one launch too (tg_mlp_backward_chain): dZ stays on chip from the head down
-            if H == 256 and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 6:     # 6: the kernel's LDS budget
+            if H in (128, 256) and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 6:     # 6: the kernel's LDS budget
                 self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
                 self._bchain_partial = None
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
@@ -203,7 +203,7 @@ class GemmMLP:
                                           self._bchain_partial.data_ptr(), N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), "tg::mlp_bwd_chain_kernel<256,8>"))
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8>"))
         bgrad = self._bchain_partial.sum(0)                     # [nh][H], chain order
         for j in range(nh):
             i = L - 2 - j
