@@ -116,9 +116,23 @@ def dynamics_kernel_probe(tg, dev, n, launches=64):
         us = a.elapsed_time(b) * 1e3 / launches
         best = us if best is None else min(best, us)
     gbs = ALGO_BYTES["QuadPole"] * n / best / 1e3
+    # yardstick for a launch this small: a bare device copy that moves the same number of bytes (half read, half
+    # written), launched back to back the same way
+    half = ALGO_BYTES["QuadPole"] * n // 8
+    src, dst = torch.zeros(half, device=dev), torch.empty(half, device=dev)
+    copy_us = None
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for t in range(launches):
+            dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / launches
+        copy_us = us if copy_us is None else min(copy_us, us)
     return {"kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>", "bound": "hbm", "n_envs": n,
             "us_per_launch": best, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-            "bytes_per_env_step": ALGO_BYTES["QuadPole"],
+            "bytes_per_env_step": ALGO_BYTES["QuadPole"], "same_bytes_device_copy_us": copy_us,
             "traffic": 14334976 if n == 65536 else None,
             "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per launch)"}
 

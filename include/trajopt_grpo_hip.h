@@ -153,6 +153,20 @@ int  tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_w
                       int32_t hidden, int32_t n_hidden_layers, const float* sigma, const uint64_t* d_rng,
                       int64_t env_offset, int32_t t_begin, int32_t t_end, void* stream);
 
+/* The same for float32 policies (the reference's own precision; rollout/rollout_worker.py:19-84): every product in
+ * fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), one workgroup per 32 envs, the weights register-resident for the
+ * whole rollout -- built for latency at the reference's net sizes and a few thousand envs.  The means differ from the
+ * GEMM path only by fp32 summation order.  Actor: Linear(S,H) ReLU [Linear(H,H) ReLU]^(n_hidden_layers-1) Linear(H,A),
+ * H in {64, 128}, 1..4 hidden layers, S <= 32, A <= 4 (tg_fused_rollout_f32_supported()).
+ *   d_wstream: f32 [H/32 waves][K1/2 + (n_hidden_layers-1)*H/2 registers][64 lanes], K1 = S rounded up to 8: register
+ *              4q + j of lane (m, kh) of wave w is W[32w + m][8q + 4kh + j] (zero beyond the matrix), first layer
+ *              then the H x H layers (trajopt-grpo_amd/mlp.py `RegisterStreamF32`);
+ *   d_tab:     f32 [(n_hidden_layers)*H hidden biases][4*H head weights, rows >= A zero][4 head biases]. */
+int  tg_fused_rollout_f32_supported(int32_t hidden, int32_t n_hidden_layers);
+int  tg_fused_rollout_f32(const tg_env_params* p, const tg_traj* tr, const float* d_wstream, const float* d_tab,
+                          int32_t hidden, int32_t n_hidden_layers, const float* sigma, const uint64_t* d_rng,
+                          int64_t env_offset, int32_t t_begin, int32_t t_end, void* stream);
+
 /* d_rng[1] += 1 (enqueued; one thread) */
 int  tg_rng_advance(uint64_t* d_rng, void* stream);
 

@@ -16,7 +16,7 @@ from oracle import learner as L
 pytestmark = pytest.mark.gpu
 
 ENVS = ["CartPole", "QuadPole2D", "QuadPole"]
-DIMS = {"CartPole": (5, 1), "QuadPole2D": (10, 2), "QuadPole": (20, 4)}
+DIMS = {"CartPole": (5, 1), "QuadPole2D": (10, 2), "QuadPole": (20, 4), "Pendulum": (3, 1)}
 
 
 @pytest.fixture(scope="module")
@@ -842,6 +842,54 @@ def test_fused_rollout_matches_unfused_path(tg, dev, name, hidden):
     mean0 = pol.actor(fo[:, 0, :].t()).detach()
     z = ((fa[:, 0, :].t() - mean0) / std).cpu().numpy()
     assert abs(z.mean()) < 0.15 and 0.8 < z.std() < 1.2
+
+
+@pytest.mark.parametrize("name,hidden", [("CartPole", (128, 128)), ("CartPole", (128, 128, 128, 128)), ("QuadPole2D", (128, 128, 128)),
+                                         ("QuadPole", (64, 64)), ("QuadPole", (128,)), ("Pendulum", (64, 64, 64))])
+def test_fused_f32_rollout_matches_unfused_path(tg, dev, name, hidden):
+    """tg_fused_rollout_f32 (fp32 products on the matrix cores, register-resident weights) against the per-step path:
+    same reset and Philox draws, means equal to fp32 summation order; its recorded trajectory replays bit-exactly
+    through the teacher-forced step kernel; a rollout split into two launches equals the unsplit one."""
+    S, A = DIMS[name]
+    T, G, Eps = 40, 3, 43                       # 129 envs: 4 full workgroups + one with a single env
+    torch.manual_seed(8)
+    pol = tg.GaussianActor_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
+    mk = lambda: tg.environments.ENV_CLASSES[name](max_steps=T)
+    fused = tg.DeviceRollout(mk(), pol, G, Eps, seed=22)
+    plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=22, fused=False)
+    assert fused.fused and fused._fused_f32 and not plain.fused
+    tf = fused.run()
+    fo, fa, fr, fm, fl = (x.clone() for x in (tf.obs, tf.act, tf.rew, tf.mask, tf.len))
+    tp = plain.run()
+    assert torch.equal(tp.obs[:, 0, :], fo[:, 0, :])                           # same reset draw
+    scale = max(1.0, float(fa[:, 0, :].abs().max()))
+    assert float((tp.act[:, 0, :] - fa[:, 0, :]).abs().max()) < 2e-5 * scale    # same noise, fp32 means
+    mean0 = pol.actor(fo[:, 0, :].t()).detach().double()
+    std = float(np.sqrt(0.3))
+    z = ((fa[:, 0, :].t().double() - mean0) / std).cpu().numpy()
+    assert abs(z.mean()) < 0.25 and 0.7 < z.std() < 1.3
+    # later steps: the two paths stay together until rounding flips a termination (rare at T = 40)
+    both = (fm.bool() & tp.mask.bool())
+    assert float(both.float().mean()) > 0.9 * float(fm.float().mean())
+    assert float(((fr - tp.rew).abs() * both).max()) < 1e-2
+    # teacher-forced replay of the recorded actions through the step kernel (same fp32 dynamics code)
+    replay = plain.run(initial_states=fo[:, 0, :].t().cpu().numpy(), forced_actions=fa.permute(2, 1, 0).cpu().numpy())
+    assert torch.equal(replay.len, fl) and torch.equal(replay.mask, fm)
+    assert torch.allclose(replay.obs, fo, rtol=0, atol=1e-5) and torch.allclose(replay.rew, fr, rtol=1e-5, atol=1e-5)
+    m = fm.bool()
+    assert torch.equal(fm.sum(0, dtype=torch.int32), fl) and tf.env_steps() == int(fm.sum())
+    assert torch.all(fr[~m] == 0) and torch.all(fa[:, ~m] == 0) and torch.all(fo[:, :T][:, ~m] == 0)
+    # split launch: [0, 13) then [13, T) gives the same bits as one launch
+    split = tg.DeviceRollout(mk(), pol, G, Eps, seed=22)
+    split._seed_host, split._stream_host = 22, 0
+    with torch.cuda.device(dev):
+        split._enqueue_prepare(None)
+        split._enqueue_fused(0, 13)
+        split.rng[1] -= 1                                   # _enqueue_fused advanced the stream id; same rollout continues
+        split._enqueue_fused(13, T)
+    torch.cuda.synchronize()
+    assert torch.equal(split.traj.obs, fo) and torch.equal(split.traj.act, fa) and torch.equal(split.traj.rew, fr)
+    assert torch.equal(split.traj.mask, fm)
 
 
 def test_fused_rollout_auto_selection_and_manager(tg, dev):

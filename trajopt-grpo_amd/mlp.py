@@ -364,3 +364,64 @@ def fragment_stream(net, H: int):
     """(bf16 weight stream, f32 bias table) in the layout tg_fused_rollout consumes (one-shot form of FragmentStream)."""
     fs = FragmentStream(net, H)
     return fs.stream, fs.bias
+
+
+# ---------------------------------------------------------------------------------------------
+# register-resident fp32 weights of the fp32 fused rollout kernel (csrc/fused_rollout_f32.hip)
+# ---------------------------------------------------------------------------------------------
+def fused_rollout_f32_supported(net, obs_dim: int, act_dim: int) -> int:
+    """Hidden width H if `net` is Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {64,128} and 1..4 hidden
+    layers (what tg_fused_rollout_f32 has kernels for), else 0."""
+    if not supports(net) or obs_dim > 32 or act_dim > 4:
+        return 0
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
+    if H not in (64, 128) or not (1 <= len(lin) - 1 <= 4):
+        return 0
+    if any(l.out_features != H for l in lin[:-1]) or any(l.in_features != H for l in lin[1:]):
+        return 0
+    return H
+
+
+class RegisterStreamF32:
+    """fp32 weights in the order tg_fused_rollout_f32 loads them into registers, refreshed from the master weights
+    with one gather: [H/32 waves][K1/2 + n_hh*H/2 registers][64 lanes]; register 4q + j of lane (m, kh) of wave w holds
+    W[32w + m][8q + 4kh + j] (first layer: K1 = in_features rounded up to 8, zero beyond).  `table` =
+    [n_hidden*H hidden biases][4*H head weights][4 head biases]."""
+
+    def __init__(self, net, H: int):
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        self.lin, self.H = lin, H
+        dev = lin[0].weight.device
+        n_hidden = len(lin) - 1
+        k1 = _round_up(lin[0].in_features, 8)
+        self._k = [k1] + [H] * (n_hidden - 1)
+        lane = torch.arange(64, device=dev).view(1, 1, -1)
+        wave = torch.arange(H // 32, device=dev).view(-1, 1, 1)
+        idx, off = [], 0
+        for k in self._k:
+            r = torch.arange(k // 2, device=dev).view(1, -1, 1)
+            row = 32 * wave + (lane & 31)
+            colk = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)
+            idx.append(off + row * k + colk)                   # [waves][k/2][64]
+            off += H * k
+        self._idx = torch.cat(idx, dim=1).reshape(-1)
+        self._wflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.stream = torch.empty(self._idx.numel(), dtype=torch.float32, device=dev)
+        self.table = torch.zeros(n_hidden * H + 4 * H + 4, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        H, off = self.H, 0
+        n_hidden = len(self.lin) - 1
+        for l, k in zip(self.lin[:-1], self._k):
+            self._wflat[off:off + H * k].view(H, k)[:, :l.in_features].copy_(l.weight)
+            off += H * k
+        torch.index_select(self._wflat, 0, self._idx, out=self.stream)
+        for li, l in enumerate(self.lin[:-1]):
+            self.table[li * H:(li + 1) * H].copy_(l.bias)
+        head = self.lin[-1]
+        hw = self.table[n_hidden * H:n_hidden * H + 4 * H].view(4, H)
+        hw[:head.out_features].copy_(head.weight)
+        self.table[n_hidden * H + 4 * H:n_hidden * H + 4 * H + head.out_features].copy_(head.bias)

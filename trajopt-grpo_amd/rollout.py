@@ -114,9 +114,16 @@ class DeviceRollout:
         # the matrix cores.  Auto-selected for bf16 policies whose shape it supports; `fused=True` insists.
         H = M.fused_rollout_supported(policy.actor, self.S, self.A)
         can_fuse = bool(H) and dtype == torch.float32 and compute_dtype == torch.bfloat16
+        # ... and its float32 sibling (csrc/fused_rollout_f32.hip) for fp32 policies of the reference's sizes (64 / 128
+        # wide, up to 4 hidden layers): fp32 products, weights register-resident, one workgroup per 32 envs.
+        H32 = M.fused_rollout_f32_supported(policy.actor, self.S, self.A)
+        self._fused_f32 = (not can_fuse) and bool(H32) and dtype == torch.float32 and compute_dtype in (None, torch.float32)
+        if self._fused_f32:
+            can_fuse, H = True, H32
         if fused and not can_fuse:
-            raise ValueError("fused rollout needs a float32 trajectory, compute_dtype=bfloat16 and an actor "
-                             "Linear(S,H) ReLU [Linear(H,H) ReLU]* Linear(H,A) with H in {128,256}, S<=32, A<=4")
+            raise ValueError("fused rollout needs a float32 trajectory and an actor Linear(S,H) ReLU [Linear(H,H) ReLU]* "
+                             "Linear(H,A), S<=32, A<=4: H in {128,256} with compute_dtype=bfloat16, or H in {64,128} and "
+                             "1..4 hidden layers in float32")
         self.fused = can_fuse if fused is None else bool(fused)
         self._fused_H = H
         self._frag = None
@@ -204,18 +211,23 @@ class DeviceRollout:
         """All steps [t_begin, t_end) in one persistent launch (tg_fused_rollout)."""
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
         if self._frag is None:
-            self._frag = M.FragmentStream(self.policy.actor, self._fused_H)
+            self._frag = (M.RegisterStreamF32 if self._fused_f32 else M.FragmentStream)(self.policy.actor, self._fused_H)
         else:
             self._frag.refresh()                                  # weights change every learn()
-        self._wfrag, self._bias_tab = self._frag.stream, self._frag.bias
         n_hidden = len(self._linears) - 1
         ev = None
         if self.step_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        N.check(lib.tg_fused_rollout(C.byref(self.params), C.byref(tr), self._wfrag.data_ptr(), self._bias_tab.data_ptr(),
-                                     self._fused_H, n_hidden, self._sigma, self.rng.data_ptr(),
-                                     self.group_offset * self.E, t_begin, t_end, st), "tg_fused_rollout")
+        if self._fused_f32:
+            N.check(lib.tg_fused_rollout_f32(C.byref(self.params), C.byref(tr), self._frag.stream.data_ptr(),
+                                             self._frag.table.data_ptr(), self._fused_H, n_hidden, self._sigma,
+                                             self.rng.data_ptr(), self.group_offset * self.E, t_begin, t_end, st),
+                    "tg_fused_rollout_f32")
+        else:
+            N.check(lib.tg_fused_rollout(C.byref(self.params), C.byref(tr), self._frag.stream.data_ptr(),
+                                         self._frag.bias.data_ptr(), self._fused_H, n_hidden, self._sigma, self.rng.data_ptr(),
+                                         self.group_offset * self.E, t_begin, t_end, st), "tg_fused_rollout")
         if ev is not None:
             ev[1].record()
             self.step_events.append((None, ev[0], ev[1]))
