@@ -15,6 +15,17 @@ N = tg._native
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def header_abi_version() -> int:
+    header = open(os.path.join(REPO, "include", "trajopt_grpo_hip.h")).read()
+    return int(re.search(r"#define\s+TG_ABI_VERSION\s+(\d+)", header).group(1))
+
+
+def test_graft_entry_build_checks_the_current_abi():
+    """__graft_entry__.build() compares the built library with the binding's ABI constant, not a literal."""
+    src = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert "tg._native.ABI_VERSION" in src and not re.search(r"tg_abi_version\(\)\s*==\s*\d", src)
+
+
 def test_library_exports_every_declared_symbol():
     lib = N.load()
     header = open(os.path.join(REPO, "include", "trajopt_grpo_hip.h")).read()
@@ -23,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
-    assert lib.tg_abi_version() == 2
+    assert lib.tg_abi_version() == N.ABI_VERSION == header_abi_version()
 
 
 def test_single_hip_runtime_is_shared_with_torch():

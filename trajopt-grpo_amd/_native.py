@@ -14,6 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
+ABI_VERSION = 2                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -107,8 +108,8 @@ def load():
         except AttributeError as e:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
-    if lib.tg_abi_version() != 2:
-        raise NativeLibraryError(f"ABI version mismatch: library {lib.tg_abi_version()} != binding 2")
+    if lib.tg_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.tg_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 
