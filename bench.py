@@ -322,7 +322,7 @@ def main():
                                    f"natural termination, actor-critic 20-256x5-{{4,1}}, {args.updates} full-batch "
                                    f"updates/iter, {args.policy_dtype} policy",
                        "envs_per_gpu": args.envs, "horizon": T, "updates_per_iter": args.updates,
-                       "parallelism": f"env-shard x{world}, 1 grad all-reduce/step"},
+                       "parallelism": f"env-shard x{world}, 1 grad all-reduce per optimizer step"},
             "rollout_only_env_steps_per_s": total_steps / t_roll if t_roll > 0 else None,
             "rollout_ms": 1e3 * t_roll / args.steps,
             "env_steps_per_step": total_steps / args.steps,
