@@ -912,12 +912,13 @@ def test_fused_rollout_auto_selection_and_manager(tg, dev):
 # --------------------------------------------------------------------------------------------
 # swarm (BASELINE config 5; build-defined semantics, no reference oracle beyond n_agents = 1)
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fused", [False, True])
-def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused):
+@pytest.mark.parametrize("fused,cdt", [(False, torch.bfloat16), (True, torch.bfloat16), (True, None)])
+def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused, cdt):
+    """cdt None + fused: the fp32 fused rollout kernel (tg_fused_rollout_f32); bf16 + fused: tg_fused_rollout."""
     T, G, Eps, K = 48, 2, 16, 8
     torch.manual_seed(8)
     pol = tg.GaussianActor_NeuralNetwork(20, 4, (128, 128), cov=0.3, device=dev)
-    kw = dict(seed=5, compute_dtype=torch.bfloat16, fused=fused)
+    kw = dict(seed=5, compute_dtype=cdt, fused=fused)
     swarm = tg.DeviceRollout(tg.QuadPoleSwarm(n_agents=K, max_steps=T), pol, G, Eps, **kw).run()
     s_len, s_act, s_obs = swarm.len.clone(), swarm.act.clone(), swarm.obs.clone()
     assert swarm.n == G * Eps * K and swarm.E == Eps * K
