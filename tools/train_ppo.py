@@ -2,7 +2,7 @@
 """End-to-end learning check: PPO with the reference factories' hyper-parameters but 4,096 parallel episodes per
 epoch instead of 50-80.
 
-    python3 tools/train_ppo.py [epochs] [CartPole|QuadPole2D|QuadPole]
+    python3 tools/train_ppo.py [epochs] [CartPole|QuadPole2D|QuadPole] [bf16]
 
 CartPole / QuadPole2D (pipelines/cartpole_pipeline_ppo.py, quadpole2d_pipeline_ppo.py): 128x3 actor-critic, cov 0.5,
 eps 0.2, gamma 0.99, 24 full-batch updates, Adam 2e-4 (published curves: -37 -> ~800 and -70 -> ~1047).
@@ -27,6 +27,8 @@ def main():
     else:
         S, A = (5, 1) if name == "CartPole" else (10, 2)
         hidden, cov, lr, upd, gamma, cdt = (128, 128, 128), 0.5, 2e-4, 24, 0.99, None
+        if len(sys.argv) > 3 and sys.argv[3] == "bf16":          # bf16 policy compute: fused bf16 rollout + chain kernels at H = 128
+            cdt = torch.bfloat16
     pol = tg.GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=cov, device=dev)
     mgr = tg.RolloutManager(lambda: tg.environments.ENV_CLASSES[name](), pol, num_workers=64, num_episodes_per_worker=64,
                             seed=0, compute_dtype=cdt)
