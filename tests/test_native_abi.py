@@ -222,3 +222,48 @@ def test_chain_fragment_stream_layout_gives_every_lane_consecutive_features():
     w1 = torch.zeros(128, 128)
     w1.copy_(lin[1].weight.detach().to(torch.bfloat16).float())
     assert torch.equal(torch.sort(st[KS:5 * KS].reshape(-1))[0], torch.sort(w1.reshape(-1))[0])
+
+
+def test_register_stream_f32_layout_follows_the_lds_exchange_order():
+    """Host logic of tg_fused_rollout_f32's weight registers (mlp.RegisterStreamF32), checked on CPU.  A layer's output
+    goes to LDS in groups of 4 consecutive features and lane (env, kh) reads group 2q + kh back, so MFMA step 4q + j
+    multiplies feature 8q + 4kh + j: register 4q + j of lane (m, kh) of wave w must hold W[32w + m][8q + 4kh + j].
+    The accumulator rows of lane half h, (r&3) + 8(r>>2) + 4h, are exactly the groups 2g + h it writes (g = r>>2)."""
+    torch.manual_seed(2)
+    net = tg.NeuralNetwork(10, 2, (128, 128, 128), "ReLU")
+    assert tg.mlp.fused_rollout_f32_supported(net, 10, 2) == 128
+    assert tg.mlp.fused_rollout_f32_supported(tg.NeuralNetwork(10, 2, (256, 256), "ReLU"), 10, 2) == 0
+    assert tg.mlp.fused_rollout_f32_supported(tg.NeuralNetwork(10, 2, (128,) * 5, "ReLU"), 10, 2) == 0
+    assert tg.mlp.fused_rollout_f32_supported(tg.NeuralNetwork(10, 2, (64, 64), "Tanh"), 10, 2) == 0
+    rs = tg.mlp.RegisterStreamF32(net, 128)
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    K1 = 16                                                     # 10 inputs rounded up to 8
+    R = K1 // 2 + 2 * 64
+    st = rs.stream.view(4, R, 64)
+    for h in range(2):
+        for r in range(16):
+            assert ((r & 3) + 8 * (r >> 2) + 4 * h) // 4 == 2 * (r >> 2) + h
+    rng = np.random.default_rng(2)
+    for _ in range(400):
+        w, lane = int(rng.integers(4)), int(rng.integers(64))
+        m, kh = lane & 31, lane >> 5
+        r = int(rng.integers(K1 // 2))
+        c = 8 * (r >> 2) + 4 * kh + (r & 3)
+        assert float(st[w, r, lane]) == (float(lin[0].weight[32 * w + m, c]) if c < 10 else 0.0)
+        layer, r = int(rng.integers(2)), int(rng.integers(64))
+        c = 8 * (r >> 2) + 4 * kh + (r & 3)
+        assert float(st[w, K1 // 2 + layer * 64 + r, lane]) == float(lin[1 + layer].weight[32 * w + m, c])
+    # every weight of an H x H layer appears exactly once
+    blk = st[:, K1 // 2:K1 // 2 + 64, :].reshape(-1)
+    assert torch.equal(torch.sort(blk)[0], torch.sort(lin[1].weight.detach().reshape(-1))[0])
+    tab = rs.table
+    assert torch.equal(tab[:128], lin[0].bias.detach()) and torch.equal(tab[256:384], lin[2].bias.detach())
+    head = tab[384:384 + 4 * 128].view(4, 128)
+    assert torch.equal(head[:2], lin[3].weight.detach()) and torch.all(head[2:] == 0)
+    assert torch.equal(tab[896:898], lin[3].bias.detach()) and torch.all(tab[898:] == 0)
+    # refresh() follows the master weights
+    with torch.no_grad():
+        lin[2].weight.mul_(2.0)
+    old = st[1, K1 // 2 + 64 + 5, 7].item()
+    rs.refresh()
+    assert rs.stream.view(4, R, 64)[1, K1 // 2 + 64 + 5, 7].item() == 2.0 * old
