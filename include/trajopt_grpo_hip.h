@@ -249,6 +249,15 @@ int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_
                            const void* d_maskbits, void* d_dz, int64_t rows, int32_t cols, int32_t is_bf16,
                            float* d_partial, void* stream);
 
+/* Weight-gradient epilogue (replaces the reduction, tail GEMM and additions PyTorch would run after a split-K batched
+ * GEMM dz^T a; torch autograd's accumulation into Linear.weight.grad):
+ *   grad[m][k] += sum_{b<n_batches} partial[b][m][k] + sum_{r<tail} dz_tail[r][m] * a_tail[r][k],  m < m_out, k < k_out
+ * d_partial f32 [n_batches][m_dim][k_dim]; d_dz_tail [tail][m_dim], d_a_tail [tail][k_dim] (bf16 if is_bf16 else f32;
+ * may be NULL when tail == 0); d_grad f32 with row stride grad_ld.  Fixed summation order: deterministic. */
+int  tg_dw_finish(const float* d_partial, int32_t n_batches, int32_t m_dim, int32_t k_dim, const void* d_dz_tail,
+                  const void* d_a_tail, int32_t tail, int32_t is_bf16, float* d_grad, int64_t grad_ld, int32_t m_out,
+                  int32_t k_out, void* stream);
+
 /* A hidden layer's backward-data product on the matrix cores, fused with the ReLU backward and the bias gradient
  * of the layer below (bf16 operands, fp32 accumulate; replaces `dA = dZ @ W` + tg_relu_bwd_bias):
  *   dZ_below[r][m] = (sum_{k<k_dim} dZ[r][k] * W[k][m]) * (A[r][m] > 0)

@@ -749,6 +749,38 @@ def test_weight_gradient_split_k_paths_agree(tg, dev):
         assert float((got - ref).norm() / ref.norm()) < 1e-5
 
 
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_weight_gradient_epilogue_kernel(tg, dev, cdt):
+    """GemmMLP._dw_into: split-K batched GEMM + tg_dw_finish (partial sums + row tail + accumulation into a window of
+    the gradient) against one fp64 product; identical from run to run."""
+    from trajopt_grpo_amd.mlp import GemmMLP
+    net = tg.NeuralNetwork(20, 4, (64, 64), "ReLU").to(dev)
+    m = GemmMLP(net, cdt)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    for rows, M, K, mo, ko in ((128 * 4096 + 77, 64, 64, 64, 64), (128 * 4096, 64, 32, 64, 20), (128 * 4100 + 127, 8, 64, 4, 64)):
+        dz = torch.randn(rows, M, generator=gen).to(cdt).to(dev)
+        a = torch.randn(rows, K, generator=gen).to(cdt).to(dev)
+        g0 = torch.randn(mo, ko, generator=gen).to(dev)
+        flat = torch.zeros(mo * ko + 5, device=dev)                       # a view into a flat bucket, like GradBucket's
+        grad = flat[5:].view(mo, ko)
+        grad.copy_(g0)
+        m._dw_into(grad, dz, a)
+        ref = g0.double() + (dz.double().t() @ a.double())[:mo, :ko]
+        tol = 1e-5 if cdt == torch.bfloat16 else 1e-4                     # fp32 operands: the GEMM's own fp32 summation
+        assert float((grad.double() - ref).norm() / ref.norm()) < tol
+        assert torch.all(flat[:5] == 0)
+        again = g0.clone()
+        m._dw_into(again, dz, a)
+        assert torch.equal(again, grad)
+    # below the split threshold the torch path is used; same contract
+    dz = torch.randn(5000, 64, generator=gen).to(cdt).to(dev)
+    a = torch.randn(5000, 64, generator=gen).to(cdt).to(dev)
+    grad = torch.ones(64, 64, device=dev)
+    m._dw_into(grad, dz, a)
+    ref = 1.0 + dz.double().t() @ a.double()
+    assert float((grad.double() - ref).norm() / ref.norm()) < 1e-4
+
+
 def test_learners_fall_back_to_autograd_for_non_relu_nets(tg, dev):
     """A Tanh policy cannot use the GEMM chain; learn() must still run (torch autograd path) and move the weights."""
     torch.manual_seed(5)

@@ -169,7 +169,45 @@ __global__ __launch_bounds__(256) void head_bwd_relu_bias_kernel(const float* __
     }
 }
 
+// Weight-gradient epilogue.  The split-K batched GEMM of mlp.py leaves n_batches partial products [M][K] in fp32 and a
+// row tail shorter than one batch row count; PyTorch finished that with a reduction, a tail GEMM (50-95 us for < 128
+// rows on hipBLASLt), and two additions.  One launch instead:
+//   grad[m][k] += sum_b partial[b][m][k] + sum_{r < tail} dz_tail[r][m] * a_tail[r][k],   m < m_out, k < k_out.
+// One thread per output element; the partials are read coalesced along k, summed in a fixed order (four interleaved
+// chains, then the tail rows in order): deterministic.
+template <bool kBf16>
+__global__ __launch_bounds__(256) void dw_finish_kernel(const float* __restrict__ partial, int n_batches, int M, int K,
+                                                        const void* __restrict__ dz_tail, const void* __restrict__ a_tail, int tail,
+                                                        float* __restrict__ grad, int64_t grad_ld, int m_out, int k_out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m_out * k_out) return;
+    const int m = idx / k_out, k = idx - m * k_out;
+    const int64_t mk = (int64_t)M * K;
+    const float* p = partial + (int64_t)m * K + k;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= n_batches; b += 4) {
+        s0 += p[(int64_t)b * mk];
+        s1 += p[(int64_t)(b + 1) * mk];
+        s2 += p[(int64_t)(b + 2) * mk];
+        s3 += p[(int64_t)(b + 3) * mk];
+    }
+    for (; b < n_batches; ++b) s0 += p[(int64_t)b * mk];
+    float s = (s0 + s1) + (s2 + s3);
+    if (kBf16) {
+        const uint16_t* dz = static_cast<const uint16_t*>(dz_tail);
+        const uint16_t* a = static_cast<const uint16_t*>(a_tail);
+        for (int r = 0; r < tail; ++r) s = __builtin_fmaf(bf16_to_f32(dz[(int64_t)r * M + m]), bf16_to_f32(a[(int64_t)r * K + k]), s);
+    } else {
+        const float* dz = static_cast<const float*>(dz_tail);
+        const float* a = static_cast<const float*>(a_tail);
+        for (int r = 0; r < tail; ++r) s = __builtin_fmaf(dz[(int64_t)r * M + m], a[(int64_t)r * K + k], s);
+    }
+    grad[(int64_t)m * grad_ld + k] += s;
+}
+
 }  // namespace tg
+
 
 using namespace tg;
 
@@ -229,6 +267,26 @@ int tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_w
     }
 #undef TG_HEAD_LAUNCH
     TG_LAUNCH_CHECK("tg_head_bwd_relu_bias");
+    return TG_OK;
+}
+
+int tg_dw_finish(const float* d_partial, int32_t n_batches, int32_t m_dim, int32_t k_dim, const void* d_dz_tail, const void* d_a_tail,
+                 int32_t tail, int32_t is_bf16, float* d_grad, int64_t grad_ld, int32_t m_out, int32_t k_out, void* stream) {
+    TG_REQUIRE(d_grad && (d_partial || n_batches == 0), "tg_dw_finish: null pointer");
+    TG_REQUIRE(n_batches >= 0 && m_dim > 0 && k_dim > 0, "tg_dw_finish: bad partial shape [%d][%d][%d]", n_batches, m_dim, k_dim);
+    TG_REQUIRE(m_out >= 0 && m_out <= m_dim && k_out >= 0 && k_out <= k_dim && grad_ld >= k_out,
+               "tg_dw_finish: window %d x %d (ld %lld) outside %d x %d", m_out, k_out, (long long)grad_ld, m_dim, k_dim);
+    TG_REQUIRE(tail >= 0 && tail <= 4096 && (tail == 0 || (d_dz_tail && d_a_tail)), "tg_dw_finish: bad tail (%d rows)", tail);
+    if (m_out == 0 || k_out == 0) return TG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div((int64_t)m_out * k_out, 256));
+    if (is_bf16)
+        hipLaunchKernelGGL(dw_finish_kernel<true>, grid, dim3(256), 0, st, d_partial, n_batches, m_dim, k_dim, d_dz_tail, d_a_tail, tail,
+                           d_grad, grad_ld, m_out, k_out);
+    else
+        hipLaunchKernelGGL(dw_finish_kernel<false>, grid, dim3(256), 0, st, d_partial, n_batches, m_dim, k_dim, d_dz_tail, d_a_tail, tail,
+                           d_grad, grad_ld, m_out, k_out);
+    TG_LAUNCH_CHECK("tg_dw_finish");
     return TG_OK;
 }
 

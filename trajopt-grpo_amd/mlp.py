@@ -184,6 +184,26 @@ class GemmMLP:
             out = tail if out is None else out + tail
         return out
 
+    def _dw_into(self, grad: torch.Tensor, dz: torch.Tensor, a: torch.Tensor):
+        """grad += (dz^T a)[:grad.shape[0], :grad.shape[1]].  Big batches: the split-K batched GEMM, then ONE launch of
+        tg_dw_finish (partial sums + the < 128-row tail product + the accumulation) instead of a reduction, a tail
+        GEMM and two additions."""
+        rows = dz.shape[0]
+        if (rows < _SPLIT_BATCHES * 4096 or grad.stride(1) != 1 or grad.dtype != torch.float32
+                or self.cd not in (torch.bfloat16, torch.float32)):
+            grad.add_(self._dw(dz, a)[:grad.shape[0], :grad.shape[1]])
+            return
+        nb, bs = _SPLIT_BATCHES, rows // _SPLIT_BATCHES
+        main = nb * bs
+        M, K = dz.shape[1], a.shape[1]
+        p = torch.bmm(dz[:main].view(nb, bs, M).transpose(1, 2), a[:main].view(nb, bs, K), out_dtype=torch.float32) \
+            if self.cd != torch.float32 else torch.bmm(dz[:main].view(nb, bs, M).transpose(1, 2), a[:main].view(nb, bs, K))
+        tail = rows - main
+        N.check(N.load().tg_dw_finish(p.data_ptr(), nb, M, K, dz[main:].data_ptr() if tail else None,
+                                      a[main:].data_ptr() if tail else None, tail, 1 if self.cd == torch.bfloat16 else 0,
+                                      grad.data_ptr(), grad.stride(0), grad.shape[0], grad.shape[1], N.stream_ptr(dz.device)),
+                "tg_dw_finish")
+
     def _backward_chain(self, dz_head, acts, bits, rows, device):
         """All hidden layers' dZ in one launch (tg_mlp_backward_chain), then the weight gradients layer by layer."""
         lib = N.load()
@@ -209,8 +229,7 @@ class GemmMLP:
             i = L - 2 - j
             lin = self.linears[i]
             lin.bias.grad.add_(bgrad[j])
-            dw = self._dw(dzs[j], acts[i])
-            lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
+            self._dw_into(lin.weight.grad, dzs[j], acts[i])
         self._acts = self._bits = None
 
     @torch.no_grad()
@@ -227,7 +246,7 @@ class GemmMLP:
         dz[:, :self.out_dim].copy_(dout)
         lin = self.linears[-1]
         lin.bias.grad.add_(dout.sum(0))
-        lin.weight.grad.add_(self._dw(dz, acts[L - 1])[:self.out_dim])
+        self._dw_into(lin.weight.grad, dz, acts[L - 1])
         if self._bchain is not None and self._bits is not None:
             self._backward_chain(dz, acts, bits, rows, dout.device)
             return
@@ -276,8 +295,7 @@ class GemmMLP:
                 dz = da
             lin = self.linears[i]
             lin.bias.grad.add_(partial.sum(0))
-            dw = self._dw(dz, acts[i])
-            lin.weight.grad.add_(dw[:, :lin.in_features] if i == 0 else dw)
+            self._dw_into(lin.weight.grad, dz, acts[i])
         self._acts = self._bits = None
 
 
