@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void head_bwd_relu_bias_kernel(const float* __
 // row tail shorter than one batch row count; PyTorch finished that with a reduction, a tail GEMM (50-95 us for < 128
 // rows on hipBLASLt), and two additions.  One launch instead:
 //   grad[m][k] += sum_b partial[b][m][k] + sum_{r < tail} dz_tail[r][m] * a_tail[r][k],   m < m_out, k < k_out.
-// One thread per output element; the partials are read coalesced along k, summed in a fixed order (four interleaved
+// One thread per output element; the partials are read coalesced along k, summed in a fixed order (eight interleaved
 // chains, then the tail rows in order): deterministic.
 template <bool kBf16>
 __global__ __launch_bounds__(256) void dw_finish_kernel(const float* __restrict__ partial, int n_batches, int M, int K,
@@ -184,23 +184,23 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* __restrict_
     const int m = idx / k_out, k = idx - m * k_out;
     const int64_t mk = (int64_t)M * K;
     const float* p = partial + (int64_t)m * K + k;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int b = 0;
-    for (; b + 4 <= n_batches; b += 4) {
-        s0 += p[(int64_t)b * mk];
-        s1 += p[(int64_t)(b + 1) * mk];
-        s2 += p[(int64_t)(b + 2) * mk];
-        s3 += p[(int64_t)(b + 3) * mk];
+    for (; b + 8 <= n_batches; b += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += p[(int64_t)(b + q) * mk];      // 8 loads in flight per thread
     }
-    for (; b < n_batches; ++b) s0 += p[(int64_t)b * mk];
-    float s = (s0 + s1) + (s2 + s3);
+    for (; b < n_batches; ++b) acc[0] += p[(int64_t)b * mk];
+    float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     if (kBf16) {
         const uint16_t* dz = static_cast<const uint16_t*>(dz_tail);
         const uint16_t* a = static_cast<const uint16_t*>(a_tail);
+#pragma unroll 8
         for (int r = 0; r < tail; ++r) s = __builtin_fmaf(bf16_to_f32(dz[(int64_t)r * M + m]), bf16_to_f32(a[(int64_t)r * K + k]), s);
     } else {
         const float* dz = static_cast<const float*>(dz_tail);
         const float* a = static_cast<const float*>(a_tail);
+#pragma unroll 8
         for (int r = 0; r < tail; ++r) s = __builtin_fmaf(dz[(int64_t)r * M + m], a[(int64_t)r * K + k], s);
     }
     grad[(int64_t)m * grad_ld + k] += s;
