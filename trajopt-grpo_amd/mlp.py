@@ -109,20 +109,31 @@ class GemmMLP:
         self.refresh()
 
     def refresh(self):
-        """Copy the fp32 master weights into the (padded) compute-dtype operands."""
+        """The fp32 master weights changed: every derived operand (padded compute-dtype copies, chain streams, packed
+        backward-data fragments) is rebuilt the next time the path that reads it runs -- with the chain kernels active
+        the per-layer copies are never touched (17 of 36 tiny launches per update and net)."""
+        self._stale = {"w", "chain", "bchain", "dx"}
+
+    def _fresh(self, what: str):
+        if what not in self._stale:
+            return
+        self._stale.discard(what)
         with torch.no_grad():
-            for w, b, l in zip(self.w, self.b, self.linears):
-                w[:l.out_features, :l.in_features].copy_(l.weight)
-                b[:l.out_features].copy_(l.bias)
-            self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
-            if self._chain is not None:
+            if what == "w":
+                for w, b, l in zip(self.w, self.b, self.linears):
+                    w[:l.out_features, :l.in_features].copy_(l.weight)
+                    b[:l.out_features].copy_(l.bias)
+                self.bias_out_f32[:self.out_dim].copy_(self.linears[-1].bias)
+            elif what == "chain":
                 self._chain.refresh()
-            if self._bchain is not None:
+            elif what == "bchain":
                 self._bchain.refresh()
-            for w, frag in zip(self.w, self._dxfrag):
-                if frag is not None:
-                    N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
-                                                        N.stream_ptr(w.device)), "tg_dx_pack_weights")
+            elif what == "dx":
+                self._fresh("w")
+                for w, frag in zip(self.w, self._dxfrag):
+                    if frag is not None:
+                        N.check(N.load().tg_dx_pack_weights(w.data_ptr(), frag.data_ptr(), w.shape[0], w.shape[1],
+                                                            N.stream_ptr(w.device)), "tg_dx_pack_weights")
 
     def prepare_input(self, X: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """[M][in_dim] (any float dtype, any strides) -> contiguous [M][in_pad] compute dtype, zero padded
@@ -137,6 +148,7 @@ class GemmMLP:
         (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward()."""
         L = len(self.linears)
         if self._chain is not None and xp.shape[0] > 0:
+            self._fresh("chain")
             rows, H = xp.shape[0], self._chain.H
             hid = [self._ws.get(f"a{i}", rows, H, self.cd, xp.device) for i in range(L - 1)] if keep else []
             # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
@@ -150,6 +162,7 @@ class GemmMLP:
             self._acts = [xp] + hid if keep else None
             self._bits = [None] + bits if keep else None
             return out if padded else out[:, :self.out_dim].contiguous()
+        self._fresh("w")
         acts = [xp]
         h = xp
         for i in range(L - 1):
@@ -207,6 +220,7 @@ class GemmMLP:
     def _backward_chain(self, dz_head, acts, bits, rows, device):
         """All hidden layers' dZ in one launch (tg_mlp_backward_chain), then the weight gradients layer by layer."""
         lib = N.load()
+        self._fresh("bchain")
         L = len(self.linears)
         nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
         H = self._bchain.H
@@ -250,6 +264,7 @@ class GemmMLP:
         if self._bchain is not None and self._bits is not None:
             self._backward_chain(dz, acts, bits, rows, dout.device)
             return
+        self._fresh("dx")
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0
         nblk = lib.tg_relu_bwd_bias_blocks()
         fuse_head = self.out_dim <= 8
@@ -352,30 +367,45 @@ class FragmentStream:
         self.H = H
         m = torch.arange(64, device=dev) & 31
         row = (m if layout == "rollout" else 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)).view(1, -1, 1)
-        flat_idx, self._slices, off = [], [], 0
+        # One gather builds the stream: source = the master weights laid end to end (row-major, unpadded) + the biases +
+        # one zero that every padded position points at.
+        flat_idx, off = [], 0
+        n_src = sum(l.weight.numel() for l in self.lin)
+        n_bias = sum(l.bias.numel() for l in self.lin)
+        zero_at = n_src + n_bias
         for li, l in enumerate(self.lin):
             rows_, cols_ = (l.in_features, l.out_features) if transposed else (l.out_features, l.in_features)
             m_pad, k_pad = _round_up(rows_, 32), _round_up(cols_, 32)
             kidx = _fragment_index(k_pad, dev) if layout == "rollout" else _chain_fragment_index(k_pad, dev, li == 0)
             for mo in range(m_pad // 32):
-                flat_idx.append((off + (32 * mo + row).expand_as(kidx) * k_pad + kidx).reshape(-1))
-            self._slices.append((off, m_pad, k_pad))
-            off += m_pad * k_pad
+                r = (32 * mo + row).expand_as(kidx)                           # row / column of the (transposed) padded matrix
+                c = kidx
+                src = off + (c * l.in_features + r if transposed else r * l.in_features + c)   # weight is [out][in]
+                flat_idx.append(torch.where((r < rows_) & (c < cols_), src, torch.full_like(src, zero_at)).reshape(-1))
+            off += l.weight.numel()
+        n_stream = sum(t.numel() for t in flat_idx)
+        if not transposed:                                                     # bias table [layers][H], zero padded
+            boff = n_src
+            for l in self.lin:
+                j = torch.arange(H, device=dev)
+                flat_idx.append(torch.where(j < l.out_features, boff + j, torch.full_like(j, zero_at)))
+                boff += l.bias.numel()
         self._idx = torch.cat(flat_idx)
-        self._wflat = torch.zeros(off, dtype=torch.bfloat16, device=dev)     # padded weights, layer after layer
-        self.stream = torch.empty(self._idx.numel(), dtype=torch.bfloat16, device=dev)
+        self._n_stream = n_stream
+        self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._gath = torch.empty(self._idx.numel(), dtype=torch.float32, device=dev)
+        self.stream = torch.empty(n_stream, dtype=torch.bfloat16, device=dev)
         self.bias = torch.zeros(len(self.lin), H, dtype=torch.float32, device=dev)
         self.refresh()
 
     @torch.no_grad()
     def refresh(self):
-        for l, (off, m_pad, k_pad) in zip(self.lin, self._slices):
-            w = l.weight.t() if self.transposed else l.weight
-            self._wflat[off:off + m_pad * k_pad].view(m_pad, k_pad)[:w.shape[0], :w.shape[1]].copy_(w)
-        torch.index_select(self._wflat, 0, self._idx, out=self.stream)
+        """Three launches: concatenate the master tensors, gather, convert to bf16 (+ one copy for the bias table)."""
+        src = torch.cat([l.weight.reshape(-1) for l in self.lin] + [l.bias for l in self.lin] + [self._zero])
+        torch.index_select(src.float() if src.dtype != torch.float32 else src, 0, self._idx, out=self._gath)
+        self.stream.copy_(self._gath[:self._n_stream])
         if not self.transposed:
-            for li, l in enumerate(self.lin):
-                self.bias[li, :l.out_features].copy_(l.bias)
+            self.bias.view(-1).copy_(self._gath[self._n_stream:])
 
 
 def fragment_stream(net, H: int):
