@@ -249,6 +249,19 @@ int  tg_head_bwd_relu_bias(const float* d_dout, int32_t act_dim, const float* d_
                            const void* d_maskbits, void* d_dz, int64_t rows, int32_t cols, int32_t is_bf16,
                            float* d_partial, void* stream);
 
+/* Bias gradients: out[v][c] += sum_{b<n_blocks} partial[b][v][c] for n_vec <= 8 gradient vectors of `width` entries in
+ * one launch (d_partial = the per-workgroup column sums tg_mlp_backward_chain / tg_dx_relu_bias / tg_relu_bwd_bias /
+ * tg_head_prep leave; d_out = HOST array of n_vec device pointers).  Fixed summation order. */
+int  tg_colsum_finish(const float* d_partial, int32_t n_blocks, int32_t n_vec, int32_t width, float* const* d_out,
+                      void* stream);
+
+/* Head of the backward pass: d_dz[r][k] = dout[r][k] (k < act_dim; compute dtype bf16 / f32), zero for the padding
+ * columns up to out_pad (8 or 16), and d_partial f32 [tg_head_prep_blocks()][act_dim] = per-workgroup column sums of
+ * dout (the head's bias gradient, finished by tg_colsum_finish with width act_dim). */
+int  tg_head_prep_blocks(void);
+int  tg_head_prep(const float* d_dout, int64_t rows, int32_t act_dim, int32_t out_pad, int32_t is_bf16, void* d_dz,
+                  float* d_partial, void* stream);
+
 /* Weight-gradient epilogue (replaces the reduction, tail GEMM and additions PyTorch would run after a split-K batched
  * GEMM dz^T a; torch autograd's accumulation into Linear.weight.grad):
  *   grad[m][k] += sum_{b<n_batches} partial[b][m][k] + sum_{r<tail} dz_tail[r][m] * a_tail[r][k],  m < m_out, k < k_out

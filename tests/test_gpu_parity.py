@@ -1165,3 +1165,36 @@ def test_pendulum_balanced_count_survives_a_split_fused_rollout(tg, dev):
     assert float((out[0][4] == 101).float().mean()) > 0.9
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_bias_and_head_epilogue_kernels(tg, dev, cdt):
+    """tg_head_prep (padded compute-dtype copy of dout + per-workgroup column sums) and tg_colsum_finish (several bias
+    gradients in one launch) against torch."""
+    N = tg._native
+    lib = N.load()
+    st = N.stream_ptr(dev)
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    for rows, A, pad in ((70001, 4, 8), (3, 1, 8), (0, 2, 8), (5000, 8, 16 if cdt == torch.bfloat16 else 8)):
+        dout = torch.randn(rows, A, generator=gen).to(dev)
+        dz = torch.full((rows, pad), 7.0, dtype=cdt, device=dev)
+        part = torch.empty(lib.tg_head_prep_blocks(), A, device=dev)
+        N.check(lib.tg_head_prep(dout.data_ptr(), rows, A, pad, 1 if cdt == torch.bfloat16 else 0, dz.data_ptr(), part.data_ptr(), st))
+        assert torch.equal(dz[:, :A], dout.to(cdt)) and torch.all(dz[:, A:] == 0)
+        g = torch.ones(A, device=dev)
+        ptrs = (N.C.c_void_p * 1)(g.data_ptr())
+        N.check(lib.tg_colsum_finish(part.data_ptr(), part.shape[0], 1, A, ptrs, st))
+        ref = 1.0 + dout.double().sum(0)
+        assert float((g.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    # several vectors at once, deterministic
+    part = torch.randn(256, 5, 256, generator=gen).to(dev)
+    flat = torch.zeros(5 * 256 + 3, device=dev)
+    outs = [flat[3 + 256 * v: 3 + 256 * (v + 1)] for v in range(5)]
+    ptrs = (N.C.c_void_p * 5)(*[o.data_ptr() for o in outs])
+    N.check(lib.tg_colsum_finish(part.data_ptr(), 256, 5, 256, ptrs, st))
+    ref = part.double().sum(0)
+    assert float((torch.stack(outs).double() - ref).abs().max()) < 1e-4 and torch.all(flat[:3] == 0)
+    first = torch.stack(outs).clone()
+    flat.zero_()
+    N.check(lib.tg_colsum_finish(part.data_ptr(), 256, 5, 256, ptrs, st))
+    assert torch.equal(torch.stack(outs), first)

@@ -124,10 +124,13 @@ class _GpuLearner(Algorithm):
             return X
         return m.prepare_input(X, out=self._ws.get("xin", X.shape[0], m.in_pad, m.cd, X.device, cap_rows))
 
-    def _forward(self, net, x, train=False):
-        """fp32 output [rows][out].  train=True keeps what backward needs (activations or the autograd graph)."""
+    def _forward(self, net, x, train=False, view=False):
+        """fp32 output [rows][out].  train=True keeps what backward needs (activations or the autograd graph).
+        view=True: may return a unit-column-stride view of the padded output (row stride > out) instead of a copy."""
         m = self._mlp(net)
         if m is not None:
+            if view:
+                return m.forward(x, keep=train, padded=True)[:, :m.out_dim]
             return m.forward(x, keep=train)
         with torch.set_grad_enabled(train):
             if self.autocast_dtype is not None:
@@ -159,7 +162,7 @@ class _GpuLearner(Algorithm):
         out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
-            mean = self._forward(actor, xin[lo:hi]).contiguous()
+            mean = self._forward(actor, xin[lo:hi], view=True)
             out[lo:hi] = K.gaussian_logp(mean, act[lo:hi], var)
         return out
 
@@ -202,7 +205,7 @@ class GRPO(_GpuLearner):
             sums = torch.zeros(4, dtype=torch.float64, device=X.device)
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
-                mean = self._forward(actor, xin[lo:hi], train=True).contiguous()
+                mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
                 _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
                                                    None, None, var, self.epsilon, coef, 0.0, 0.0)
                 self._backward(actor, mean, g_mean)
@@ -258,7 +261,7 @@ class PPO(_GpuLearner):
         sums = torch.zeros(4, dtype=torch.float64, device=xin.device)
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
-            mean = self._forward(actor, xin[lo:hi], train=True).contiguous()
+            mean = self._forward(actor, xin[lo:hi], train=True, view=True)         # the loss kernel takes a row stride
             vout = self._forward(critic, xin[lo:hi], train=True)
             value = vout.reshape(-1).contiguous()
             _, s, g_mean, g_val = K.surrogate_loss(mean.detach(), value.detach(), act[lo:hi], old_logp[lo:hi], adv[lo:hi],

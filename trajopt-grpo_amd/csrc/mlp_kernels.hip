@@ -206,7 +206,81 @@ __global__ __launch_bounds__(256) void dw_finish_kernel(const float* __restrict_
     grad[(int64_t)m * grad_ld + k] += s;
 }
 
+struct ColsumOut { float* p[8]; };
+
+// out[v][c] += sum_b partial[b][v][c]: the per-workgroup column sums the backward kernels leave (bias gradients), added
+// into up to 8 separate gradient vectors in one launch.  Block = 64 columns x 16 block-groups; every thread sums its
+// group's blocks in order, the 16 group sums are added in order: deterministic.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int n_blocks, int n_vec, int width,
+                                                             ColsumOut out) {
+    __shared__ float sh[16][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;                       // flat (v, c)
+    const int total = n_vec * width;
+    float s = 0.f;
+    if (col < total) {
+        const int per = (n_blocks + 15) / 16;
+        const int b0 = grp * per, b1 = min(b0 + per, n_blocks);
+        for (int b = b0; b < b1; ++b) s += partial[(int64_t)b * total + col];
+    }
+    sh[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && col < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sh[g][cl];
+        const int v = col / width, c = col - v * width;
+        out.p[v][c] += t;
+    }
+}
+
+// Head of the backward pass: dz[r][0..A) = dout[r][:] in the compute dtype, columns A..out_pad-1 zero, and the column
+// sums of dout per workgroup (the head's bias gradient; tg_colsum_finish adds them up).  One thread per row.
+constexpr int kHeadPrepBlocks = 1024;
+template <bool kBf16>
+__global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ dout, int64_t rows, int A, int out_pad,
+                                                        void* __restrict__ dz, float* __restrict__ partial) {
+    __shared__ float sh[4][8];                                  // one row of column sums per wave
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k < A) ? dout[r * A + k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        if (kBf16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v[2 * k], v[2 * k + 1]}, bf16x2));
+            uint16_t* d = static_cast<uint16_t*>(dz) + r * out_pad;
+            *reinterpret_cast<uint4*>(d) = uint4{w[0], w[1], w[2], w[3]};
+            if (out_pad > 8) *reinterpret_cast<uint4*>(d + 8) = uint4{0u, 0u, 0u, 0u};
+        } else {
+            float* d = static_cast<float*>(dz) + r * out_pad;
+            for (int k = 0; k < out_pad; ++k) d[k] = k < 8 ? v[k] : 0.f;
+        }
+    }
+    // wave reduction in a fixed order (xor butterflies), then the 4 waves in order
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float x = acc[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        acc[k] = x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A) partial[blockIdx.x * A + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 }  // namespace tg
+
 
 
 using namespace tg;
@@ -287,6 +361,37 @@ int tg_dw_finish(const float* d_partial, int32_t n_batches, int32_t m_dim, int32
         hipLaunchKernelGGL(dw_finish_kernel<false>, grid, dim3(256), 0, st, d_partial, n_batches, m_dim, k_dim, d_dz_tail, d_a_tail, tail,
                            d_grad, grad_ld, m_out, k_out);
     TG_LAUNCH_CHECK("tg_dw_finish");
+    return TG_OK;
+}
+
+int tg_colsum_finish(const float* d_partial, int32_t n_blocks, int32_t n_vec, int32_t width, float* const* d_out, void* stream) {
+    TG_REQUIRE(d_partial && d_out, "tg_colsum_finish: null pointer");
+    TG_REQUIRE(n_blocks >= 0 && n_vec >= 1 && n_vec <= 8 && width >= 1, "tg_colsum_finish: bad shape [%d][%d][%d] (at most 8 vectors)",
+               n_blocks, n_vec, width);
+    ColsumOut out{};
+    for (int v = 0; v < n_vec; ++v) {
+        TG_REQUIRE(d_out[v], "tg_colsum_finish: output %d is null", v);
+        out.p[v] = d_out[v];
+    }
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)ceil_div((int64_t)n_vec * width, 64)), dim3(1024), 0, (hipStream_t)stream,
+                       d_partial, n_blocks, n_vec, width, out);
+    TG_LAUNCH_CHECK("tg_colsum_finish");
+    return TG_OK;
+}
+
+int tg_head_prep_blocks(void) { return kHeadPrepBlocks; }
+
+int tg_head_prep(const float* d_dout, int64_t rows, int32_t act_dim, int32_t out_pad, int32_t is_bf16, void* d_dz, float* d_partial,
+                 void* stream) {
+    TG_REQUIRE(d_partial && ((d_dout && d_dz) || rows == 0), "tg_head_prep: null pointer");
+    TG_REQUIRE(rows >= 0 && act_dim >= 1 && act_dim <= 8 && out_pad >= 8 && out_pad % 8 == 0 && out_pad <= 16,
+               "tg_head_prep: act_dim %d / out_pad %d unsupported (1..8 outputs, padded to 8 or 16)", act_dim, out_pad);
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16)
+        hipLaunchKernelGGL(head_prep_kernel<true>, dim3(kHeadPrepBlocks), dim3(256), 0, st, d_dout, rows, act_dim, out_pad, d_dz, d_partial);
+    else
+        hipLaunchKernelGGL(head_prep_kernel<false>, dim3(kHeadPrepBlocks), dim3(256), 0, st, d_dout, rows, act_dim, out_pad, d_dz, d_partial);
+    TG_LAUNCH_CHECK("tg_head_prep");
     return TG_OK;
 }
 

@@ -83,7 +83,7 @@ def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var) -> torch.Tensor:
 def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
     """One launch of tg_surrogate_loss: returns (total f32 scalar, sums f64[4], d total/d mean, d total/d value|None)."""
     N.require_cuda(mean, act, logp_old, adv)
-    assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.is_contiguous()
+    assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.stride(1) == 1
     M, A = mean.shape
     a = N.LossArgs()
     a.d_mean, a.mean_row_stride = mean.data_ptr(), mean.stride(0)
@@ -102,7 +102,7 @@ def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilo
         a.var[i] = va[i]
     a.act_dim, a.epsilon = A, float(epsilon)
     a.surr_coef, a.critic_coef, a.kl_coef = float(surr_coef), float(critic_coef), float(kl_coef)
-    grad_mean = torch.empty_like(mean)
+    grad_mean = torch.empty(M, A, dtype=torch.float32, device=mean.device)
     sums = torch.empty(4, dtype=torch.float64, device=mean.device)
     work = torch.empty(4 * N.load().tg_loss_work_blocks(), dtype=torch.float64, device=mean.device)
     a.d_grad_mean, a.d_sums, a.d_work, a.M = grad_mean.data_ptr(), sums.data_ptr(), work.data_ptr(), M

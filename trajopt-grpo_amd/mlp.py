@@ -91,6 +91,7 @@ class GemmMLP:
                 if lib.tg_dx_relu_bias_supported(o, k):
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
+        self._head_partial = None
         # when set to a list, every backward-data launch (tg_mlp_backward_chain or tg_dx_relu_bias) is bracketed by HIP
         # events on the launch stream and (start, end, rows, algorithmic bytes per row, kernel name) is appended
         # (bench.py reads them back for that kernel's roofline)
@@ -197,6 +198,19 @@ class GemmMLP:
             out = tail if out is None else out + tail
         return out
 
+    def _bias_into(self, grads, partial: torch.Tensor):
+        """grads[v] += partial[:, v, :].sum(0) for all v in ONE launch (tg_colsum_finish); partial f32 [blocks][len(grads)][width]
+        or [blocks][width] for a single gradient."""
+        width = partial.shape[-1]
+        if len(grads) > 8 or any(g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != width for g in grads):
+            p3 = partial.view(partial.shape[0], len(grads), width).sum(0)
+            for v, g in enumerate(grads):
+                g.add_(p3[v])
+            return
+        ptrs = (N.C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        N.check(N.load().tg_colsum_finish(partial.data_ptr(), partial.shape[0], len(grads), width, ptrs,
+                                          N.stream_ptr(partial.device)), "tg_colsum_finish")
+
     def _dw_into(self, grad: torch.Tensor, dz: torch.Tensor, a: torch.Tensor):
         """grad += (dz^T a)[:grad.shape[0], :grad.shape[1]].  Big batches: the split-K batched GEMM, then ONE launch of
         tg_dw_finish (partial sums + the < 128-row tail product + the accumulation) instead of a reduction, a tail
@@ -238,12 +252,10 @@ class GemmMLP:
         if ev is not None:
             ev[1].record()
             self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8>"))
-        bgrad = self._bchain_partial.sum(0)                     # [nh][H], chain order
+        self._bias_into([self.linears[L - 2 - j].bias.grad for j in range(nh)], self._bchain_partial)   # chain order: top first
         for j in range(nh):
             i = L - 2 - j
-            lin = self.linears[i]
-            lin.bias.grad.add_(bgrad[j])
-            self._dw_into(lin.weight.grad, dzs[j], acts[i])
+            self._dw_into(self.linears[i].weight.grad, dzs[j], acts[i])
         self._acts = self._bits = None
 
     @torch.no_grad()
@@ -256,10 +268,20 @@ class GemmMLP:
         rows = dout.shape[0]
         L = len(self.linears)
         dout = dout.contiguous()
-        dz = self._ws.get("z_head", rows, self.out_pad, self.cd, dout.device).zero_()
-        dz[:, :self.out_dim].copy_(dout)
+        dz = self._ws.get("z_head", rows, self.out_pad, self.cd, dout.device)
         lin = self.linears[-1]
-        lin.bias.grad.add_(dout.sum(0))
+        if (self.out_dim <= 8 and self.out_pad <= 16 and self.cd in (torch.bfloat16, torch.float32) and dout.dtype == torch.float32
+                and lin.bias.grad.dtype == torch.float32 and lin.bias.grad.is_contiguous()):
+            # padded compute-dtype copy of dout + the head's bias gradient: two launches instead of four
+            if self._head_partial is None:
+                self._head_partial = torch.empty(lib.tg_head_prep_blocks(), self.out_dim, dtype=torch.float32, device=dout.device)
+            N.check(lib.tg_head_prep(dout.data_ptr(), rows, self.out_dim, self.out_pad, 1 if self.cd == torch.bfloat16 else 0,
+                                     dz.data_ptr(), self._head_partial.data_ptr(), N.stream_ptr(dout.device)), "tg_head_prep")
+            self._bias_into([lin.bias.grad], self._head_partial)
+        else:
+            dz.zero_()
+            dz[:, :self.out_dim].copy_(dout)
+            lin.bias.grad.add_(dout.sum(0))
         self._dw_into(lin.weight.grad, dz, acts[L - 1])
         if self._bchain is not None and self._bits is not None:
             self._backward_chain(dz, acts, bits, rows, dout.device)
@@ -309,7 +331,7 @@ class GemmMLP:
                             "tg_relu_bwd_bias")
                 dz = da
             lin = self.linears[i]
-            lin.bias.grad.add_(partial.sum(0))
+            self._bias_into([lin.bias.grad], partial)
             self._dw_into(lin.weight.grad, dz, acts[i])
         self._acts = self._bits = None
 
