@@ -207,7 +207,7 @@ class GRPO(_GpuLearner):
                 hi = min(lo + self.chunk_rows, X.shape[0])
                 mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
                 _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
-                                                   None, None, var, self.epsilon, coef, 0.0, 0.0)
+                                                   None, None, var, self.epsilon, coef, 0.0, 0.0, want_total=False)
                 self._backward(actor, mean, g_mean)
                 sums += s
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
@@ -266,7 +266,7 @@ class PPO(_GpuLearner):
             value = vout.reshape(-1).contiguous()
             _, s, g_mean, g_val = K.surrogate_loss(mean.detach(), value.detach(), act[lo:hi], old_logp[lo:hi], adv[lo:hi],
                                                    ret[lo:hi], None, norm, var, self.epsilon, -1.0 / n_global,
-                                                   self.c1 / n_global, self.kl_coeff / n_global)
+                                                   self.c1 / n_global, self.kl_coeff / n_global, want_total=False)
             self._backward(actor, mean, g_mean)
             self._backward(critic, vout, g_val.view_as(vout))
             sums += s

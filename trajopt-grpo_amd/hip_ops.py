@@ -80,8 +80,10 @@ def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var) -> torch.Tensor:
     return out
 
 
-def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
-    """One launch of tg_surrogate_loss: returns (total f32 scalar, sums f64[4], d total/d mean, d total/d value|None)."""
+def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef,
+                   want_total: bool = True):
+    """One launch of tg_surrogate_loss: returns (total f32 scalar, sums f64[4], d total/d mean, d total/d value|None).
+    want_total=False skips the handful of scalar launches that combine the sums (the learners only use the sums)."""
     N.require_cuda(mean, act, logp_old, adv)
     assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.stride(1) == 1
     M, A = mean.shape
@@ -107,7 +109,7 @@ def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilo
     work = torch.empty(4 * N.load().tg_loss_work_blocks(), dtype=torch.float64, device=mean.device)
     a.d_grad_mean, a.d_sums, a.d_work, a.M = grad_mean.data_ptr(), sums.data_ptr(), work.data_ptr(), M
     N.check(N.load().tg_surrogate_loss(C.byref(a), _st(mean)), "tg_surrogate_loss")
-    total = (surr_coef * sums[0] + critic_coef * sums[1] + kl_coef * sums[2]).float()
+    total = (surr_coef * sums[0] + critic_coef * sums[1] + kl_coef * sums[2]).float() if want_total else None
     return total, sums, grad_mean, grad_value
 
 
