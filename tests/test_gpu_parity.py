@@ -1198,3 +1198,32 @@ def test_bias_and_head_epilogue_kernels(tg, dev, cdt):
     flat.zero_()
     N.check(lib.tg_colsum_finish(part.data_ptr(), 256, 5, 256, ptrs, st))
     assert torch.equal(torch.stack(outs), first)
+
+
+@pytest.mark.parametrize("name,hidden,G,Eps,T,cdt", [("QuadPole", (256,) * 5, 256, 256, 256, torch.bfloat16),      # C3: tg_fused_rollout
+                                                   ("CartPole", (128, 128), 64, 64, 500, None)])               # C2: tg_fused_rollout_f32
+def test_fused_rollouts_at_baseline_sizes(tg, dev, name, hidden, G, Eps, T, cdt):
+    """BASELINE.json's full rollout sizes through size-independent properties: masks are prefixes of length len, padding
+    is zero, the counters agree, the recorded trajectory replays through the teacher-forced step kernel with bit-identical
+    episode lengths and masks for every env (states to rounding: the two kernels contract their FMAs differently), and a
+    second run of the same stream reproduces the same bits."""
+    S, A = DIMS[name]
+    torch.manual_seed(11)
+    pol = tg.GaussianActor_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
+    mk = lambda: tg.environments.ENV_CLASSES[name](max_steps=T)
+    eng = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt)
+    assert eng.fused and eng._fused_f32 == (cdt is None)
+    tr = eng.run()
+    obs, act, rew, mask, ln = (x.clone() for x in (tr.obs, tr.act, tr.rew, tr.mask, tr.len))
+    n = G * Eps
+    assert torch.equal(mask, (torch.arange(T, device=dev)[:, None] < ln[None, :]).to(torch.uint8))
+    assert int(ln.min()) >= 1 and int(ln.max()) <= T and tr.env_steps() == int(ln.sum())
+    m = mask.bool()
+    assert torch.all(rew[~m] == 0) and torch.all(act[:, ~m] == 0) and torch.all(obs[:, :T][:, ~m] == 0)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt, fused=False)
+    replay = plain.run(initial_states=obs[:, 0, :].t().cpu().numpy(), forced_actions=act.permute(2, 1, 0).cpu().numpy())
+    assert torch.equal(replay.len, ln) and torch.equal(replay.mask, mask)
+    assert float((replay.obs - obs).abs().max()) < 2e-3 and float((replay.rew - rew).abs().max()) < 2e-3
+    again = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt).run()
+    assert torch.equal(again.obs, obs) and torch.equal(again.act, act) and torch.equal(again.len, ln)
