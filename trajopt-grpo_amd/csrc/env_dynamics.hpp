@@ -67,6 +67,7 @@ template <typename R> struct CartPoleEnv {
 
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
+#pragma clang fp contract(off)   // every kernel that instantiates this gets the same (unfused) arithmetic: bit-identical states
         using M = Math<R>;
         const float u32 = rn_mul(5.0f, clip1(a[0]));                       // :49
         const R u = (R)u32;                                                   // :60
@@ -137,6 +138,7 @@ template <typename R> struct QuadPole2DEnv {
 
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
+#pragma clang fp contract(off)   // every kernel that instantiates this gets the same (unfused) arithmetic: bit-identical states
         using M = Math<R>;
         const float u1 = rn_add(c.hover32, rn_mul(c.hover32, clip1(a[0])));   // :928 (float32)
         const float u2 = rn_add(c.hover32, rn_mul(c.hover32, clip1(a[1])));
@@ -197,6 +199,7 @@ template <typename R> struct QuadPole2DEnv {
 // quadrotor_env.py:190-228 (quaternion helpers), 409-413, 417-528, 625-713.
 // ---------------------------------------------------------------------------
 template <typename R> __device__ static inline void quat_mult(const R (&q)[4], const R (&r)[4], R (&o)[4]) {
+#pragma clang fp contract(off)
     o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];             // :196-201
     o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
     o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
@@ -228,6 +231,7 @@ template <typename R> struct QuadPoleEnv {
 
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
+#pragma clang fp contract(off)   // every kernel that instantiates this gets the same (unfused) arithmetic: bit-identical states
         using M = Math<R>;
         float u[4];
 #pragma unroll
@@ -392,6 +396,7 @@ template <typename R> struct PendulumEnv {
 
     __device__ static inline StepOut step(const R (&s)[S], const float (&a)[A], const C& c, int steps_after,
                                           R (&o)[S], R& reward) {
+#pragma clang fp contract(off)   // every kernel that instantiates this gets the same (unfused) arithmetic: bit-identical states
         using M = Math<R>;
         const float a32 = clip1(a[0]);                                        // :46 (float32, no scaling)
         const R u = (R)a32;                                                   // promoted by the float64 scalar at :61
