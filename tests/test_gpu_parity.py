@@ -59,8 +59,9 @@ def test_step_fp64_matches_reference_golden(tg, dev, name):
     g = load_golden(f"env_step_{name.lower()}.npz")
     nx, rw, tr, sp, tb = native_step(tg, name, g["state"], g["action"], g["steps"], g["time_balanced"],
                                      int(g["max_steps"]), torch.float64, dev)
-    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-11, atol=1e-12)
-    np.testing.assert_allclose(rw, g["reward"], rtol=1e-11, atol=1e-11)
+    # measured: <= 4.4e-16 on the states (1 ulp; 96 % of the entries bit-identical), <= 7.1e-15 on the rewards
+    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-14, atol=2e-15)
+    np.testing.assert_allclose(rw, g["reward"], rtol=1e-14, atol=5e-14)
     assert np.array_equal(tr, g["truncated"])
     assert np.array_equal(sp, g["steps"] + 1)
     if name != "QuadPole":
@@ -73,8 +74,8 @@ def test_step_with_non_default_constructor_arguments(tg, dev, tag, name):
     kw = {k[len("param_"):]: float(g[k]) for k in g if k.startswith("param_")}
     nx, rw, tr, sp, _ = native_step(tg, name, g["state"], g["action"], g["steps"], g["time_balanced"],
                                     int(g["max_steps"]), torch.float64, dev, **kw)
-    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-11, atol=1e-12)
-    np.testing.assert_allclose(rw, g["reward"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(nx, g["next_state"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(rw, g["reward"], rtol=1e-13, atol=1e-13)
     assert np.array_equal(tr, g["truncated"])
 
 
