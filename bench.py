@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
     ap.add_argument("--no-fused", action="store_true",
                     help="per-step launches (actor GEMMs + tg_rollout_step) instead of the fused persistent rollout kernel")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="do not bracket the rollout / backward-chain launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing the multi-rank path on a single GPU (ranks share the device)")
     args = ap.parse_args()
@@ -222,10 +224,10 @@ def main():
     t_roll = 0.0
     launches = []            # (duration ms, env-steps in that launch)
     launch_units = []
-    if not args.graph:
+    if not args.graph and not args.no_launch_events:
         mgr.engine.step_events = []
     learner_mlps = [m for m in (algo._mlp(policy.actor), algo._mlp(policy.critic)) if m is not None]
-    for m in learner_mlps:
+    for m in (learner_mlps if not args.no_launch_events else []):
         m.dx_events = []                    # HIP-event pairs around every tg_dx_relu_bias launch of the timed steps
     barrier()
     t0 = time.perf_counter()
@@ -248,7 +250,7 @@ def main():
 
     dx_launches = []                        # (ms, algorithmic bytes, rows) per launch, the update's dominant kernel
     for m in learner_mlps:
-        dx_launches += [(a.elapsed_time(b), rows * bpr, rows, name) for a, b, rows, bpr, name in m.dx_events]
+        dx_launches += [(a.elapsed_time(b), rows * bpr, rows, name) for a, b, rows, bpr, name in (m.dx_events or [])]
         m.dx_events = None
     dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
     relu_probe = None
