@@ -57,19 +57,21 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
 // Column sums of a tile over the wave's 32 rows (the bias gradient).  Rows sit on lanes, so a lane-wise reduction costs
 // 5 DPP additions per value (80 per tile: the kernel became VALU-bound).  Instead the matrix core transposes: with the
 // masked outputs as the A operand (lane = row, in-lane = 8 features) and a 0/1 selection matrix as B,
-// T[row][n'] = A[row][k = n'] lands with the ROWS in the accumulator registers of lane n' -- 15 in-lane additions sum
-// them, one cross-half exchange adds the two row subsets.  `sel` = B with B[k][n'] = (k == n'), n' < 16.
-__device__ static inline bf16x8 selection_operand(int lane) {
-    const int np = lane & 31, hb = lane >> 5;
+// T[row][n'] = A[row][k = n' - shift] lands with the ROWS in the accumulator registers of lane n' -- 15 in-lane additions
+// sum them, one cross-half exchange adds the two row subsets.  The tile's two operands (`lo`: slots -> n' 0..15, `hi`:
+// slots -> n' 16..31) accumulate into ONE transposed tile, so the additions run once per tile.
+__device__ static inline bf16x8 selection_operand(int lane, int shift) {
+    const int np = (lane & 31) - shift, hb = lane >> 5;
     bf16x8 b = {};
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = (8 * hb + j == np) ? (__bf16)1.0f : (__bf16)0.0f;
     return b;
 }
-// -> lane n' < 16 (either half) holds the sum over the wave's 32 rows of operand slot k = n'
-__device__ static inline float column_sums(bf16x8 a, bf16x8 sel) {
+// -> lane n' < 32 (either half) holds the sum over the wave's 32 rows of slot n' of `lo` (n' < 16) or slot n' - 16 of `hi`
+__device__ static inline float column_sums(bf16x8 lo, bf16x8 hi, bf16x8 sel_lo, bf16x8 sel_hi) {
     f32x16 t = {};
-    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, sel, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, sel_lo, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, sel_hi, t, 0, 0, 0);
     float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     s += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
@@ -90,28 +92,33 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
 
 // Masked epilogue of one 32-feature tile: round the accumulators pairwise, AND with the keep-masks from the layer's
 // mask word `w` (feature r of this lane: bit (mt&1)*8 + (r>>1) + 16 (r&1)), hand the packed halves on and add their
-// column sums to the wave's bias table (`own` = all ones for a lane with a row of its own, else 0).
+// column sums to the wave's bias table (`own` = all ones for a lane with a row of its own, else 0; `full` = every lane
+// of the wave has one, the case in all rounds but the last).
+struct SelPair { bf16x8 lo, hi; };
 template <int H>
 __device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt, bf16x8& lo, bf16x8& hi, float* __restrict__ btab,
-                                          bool writer, uint32_t own, bf16x8 sel) {
+                                          bool writer, uint32_t own, bool full, const SelPair& sel) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const uint32_t wk = w >> ((mt & 1) * 8);
-    uint32_t o[8], ob[8];
+    uint32_t o[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[2 * k], acc[2 * k + 1]}, bf16x2));
         o[k] = pk & (((wk >> k) & 0x00010001u) * 0xFFFFu);
-        ob[k] = o[k] & own;                           // a lane clamped onto the last row must not count it again
     }
     lo = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
     hi = __builtin_bit_cast(bf16x8, uint4{o[4], o[5], o[6], o[7]});
-    // operand slot k = 8 h + j of `lo` is feature 16 h + j, of `hi` feature 16 h + 8 + j: lane n' = 8 h + j (n' < 16) gets
-    // their sums, i.e. table entries 32 mt + 16 (n'>>3) + (n'&7) and + 8
-    const float s_lo = column_sums(__builtin_bit_cast(bf16x8, uint4{ob[0], ob[1], ob[2], ob[3]}), sel);
-    const float s_hi = column_sums(__builtin_bit_cast(bf16x8, uint4{ob[4], ob[5], ob[6], ob[7]}), sel);
-    bias_accumulate(btab + 32 * mt, s_lo, writer);
-    bias_accumulate(btab + 32 * mt + 8, s_hi, writer);
+    // operand slot k = 8 h + j of `lo` is feature 16 h + j, of `hi` feature 16 h + 8 + j: lane n' (< 16: slot n' of lo,
+    // 16..31: slot n' - 16 of hi) gets their sums, i.e. table entry 32 mt + 16 ((n'&15)>>3) + (n'&7) + 8 (n'>>4)
+    float s;
+    if (full) {
+        s = column_sums(lo, hi, sel.lo, sel.hi);
+    } else {                                          // a lane clamped onto the last row must not count it again
+        s = column_sums(__builtin_bit_cast(bf16x8, uint4{o[0] & own, o[1] & own, o[2] & own, o[3] & own}),
+                        __builtin_bit_cast(bf16x8, uint4{o[4] & own, o[5] & own, o[6] & own, o[7] & own}), sel.lo, sel.hi);
+    }
+    bias_accumulate(btab + 32 * mt, s, writer);
 }
 
 template <int H, int WPW>
@@ -143,9 +150,10 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 
     uint4* my_dzs = dzs + wave * 64;
     uint4* my_mks = mks + wave * 3 * 64;
-    float* my_bacc = bacc + wave * n_layers * H + 16 * (col >> 3) + (col & 7);   // this lane's column-sum entry (lanes 0..15)
-    const bool writer = lane < 16;
-    const bf16x8 sel = selection_operand(lane);
+    // this lane's column-sum entry (lanes 0..31: slots of the tile's first operand in lanes 0..15, of its second in 16..31)
+    float* my_bacc = bacc + wave * n_layers * H + 16 * ((col & 15) >> 3) + (col & 7) + 8 * (col >> 4);
+    const bool writer = lane < 32;
+    const SelPair sel = {selection_operand(lane, 0), selection_operand(lane, 16)};
 
     auto dma_dzh = [&](int64_t round) {
         if (lane < 32) {
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         const int64_t row0 = round * (32 * WPW) + wave * 32;
         int64_t row = row0 + col;
         const uint32_t own = row < rows ? 0xFFFFFFFFu : 0u;
+        const bool full = row0 + 32 <= rows;          // wave-uniform: every lane has a row of its own
         row = row < rows ? row : rows - 1;            // clamped rows recompute and rewrite the last row (identical bytes)
         bf16x8 xin[KS], xout[KS];
         uint32_t mw[WPL];
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, sel);
+                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
                 if (mt & 1)
                     store_pair(stage, ptrs.dz[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, sel);
+                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
                 if (mt & 1)
                     store_pair(stage, ptrs.dz[j] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
