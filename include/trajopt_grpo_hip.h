@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -321,6 +321,37 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
 int  tg_mlp_backward_chain_blocks(void);
 int  tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
                            void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream);
+
+/* ---- MLP weight gradients, every layer in one persistent launch (what `loss.backward()` leaves in Linear.weight.grad /
+ *      .bias.grad: algorithms/ppo.py:181-183, algorithms/grpo.py:143-145) ----
+ *   wgrad[m][n] += sum over rows r of P[r][m] * Q[r][n]   (m < m_out, n < n_out)      bgrad[m] += sum over rows of P[r][m]
+ * one job per Linear; P = the layer's dZ (tg_mlp_backward_chain), Q = the layer's input.  bf16 operands, fp32 sums, every
+ * operand byte read once.  A workgroup keeps one job's whole H x H fp32 gradient in registers for its share of the rows and
+ * leaves it as a partial ("slab") in the workspace; a second kernel adds the slabs in a fixed order into the gradient
+ * windows (e.g. the learner's flat all-reduce bucket): deterministic.
+ *   kind HH: P bf16 [rows][H], Q bf16 [rows][H]          hidden-to-hidden layers
+ *        HX: P bf16 [rows][H], Q bf16 [rows][32]         first layer (Q = the zero-padded net input)
+ *        DH: P bf16 [rows][8], Q bf16 [rows][H]          head (P = d loss / d head output, zero padded; no bias sums:
+ *                                                        tg_head_prep produces them)
+ *        HR: P bf16 [rows][H], Q bf16 [rows][32]         second layer WITHOUT its stored input: the first hidden
+ *                                                        activation relu(W0 x + b0) is recomputed on chip from the net
+ *                                                        input row (d_w0frag = first block of the forward chain's weight
+ *                                                        stream, d_b0 = first-layer bias f32 [H]); bit-identical to
+ *                                                        what tg_mlp_forward_chain would have stored
+ * H in {128, 256}.  d_workspace: tg_mlp_weight_grad_workspace(H) bytes. */
+enum { TG_DW_HH = 0, TG_DW_HX = 1, TG_DW_DH = 2, TG_DW_HR = 3 };
+typedef struct tg_dw_job {
+    const void* d_p;
+    const void* d_q;
+    float*      d_wgrad;      /* f32, row stride wgrad_ld */
+    float*      d_bgrad;      /* f32 [m_out] or NULL */
+    int64_t     wgrad_ld;
+    int32_t     kind;
+    int32_t     m_out, n_out;
+} tg_dw_job;
+int64_t tg_mlp_weight_grad_workspace(int32_t hidden);
+int  tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag,
+                        const float* d_b0, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

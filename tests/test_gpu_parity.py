@@ -1228,3 +1228,72 @@ def test_fused_rollouts_at_baseline_sizes(tg, dev, name, hidden, G, Eps, T, cdt)
     assert torch.equal(replay.rew, rew) and torch.equal(replay.obs, obs)
     again = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt).run()
     assert torch.equal(again.obs, obs) and torch.equal(again.act, act) and torch.equal(again.len, ln)
+
+
+@pytest.mark.parametrize("H", [256, 128])
+@pytest.mark.parametrize("rows", [1, 33, 1000, 70001])
+def test_weight_gradient_kernel_matches_fp64(tg, dev, H, rows):
+    """tg_mlp_weight_grad (torch autograd's dW = dZ^T A and db = sum dZ of every Linear, algorithms/ppo.py:181-183): all
+    job kinds in one launch against fp64 products, ragged row tails, accumulation into windows of a flat bucket with
+    the neighbouring words untouched, bit-identical from run to run."""
+    from trajopt_grpo_amd import mlp as M, _native as N
+    gen = torch.Generator(device="cpu").manual_seed(rows + H)
+
+    def rnd(c, valid=None):
+        t = torch.randn(rows, c, generator=gen)
+        if valid is not None:
+            t[:, valid:] = 0
+        return t.to(torch.bfloat16).to(dev)
+
+    dz1, a0, dz0, x, dh, a2 = rnd(H), rnd(H), rnd(H), rnd(32, 20), rnd(8, 4), rnd(H)
+    sizes = [H * H, H, H * 20, H, 4 * H]
+    ws = M.weight_grad_workspace(H, dev)
+
+    def run():
+        flat = torch.arange(sum(sizes) + 7, dtype=torch.float32, device=dev) * 1e-3
+        o, views = 3, []
+        for n in sizes:
+            views.append(flat[o:o + n])
+            o += n
+        w1, b1, w0, b0, wh = views[0].view(H, H), views[1], views[2].view(H, 20), views[3], views[4].view(4, H)
+        M.weight_grad(H, [(N.TG_DW_HH, dz1, a0, w1, b1), (N.TG_DW_HX, dz0, x, w0, b0), (N.TG_DW_DH, dh, a2, wh, None)], rows, ws)
+        torch.cuda.synchronize()
+        return flat, (w1, b1, w0, b0, wh)
+
+    flat, got = run()
+    base = (torch.arange(sum(sizes) + 7, dtype=torch.float32, device=dev) * 1e-3).double()
+    ref = [dz1.double().t() @ a0.double(), dz1.double().sum(0), (dz0.double().t() @ x.double())[:, :20], dz0.double().sum(0),
+           (dh.double().t() @ a2.double())[:4]]
+    o = 3
+    for r, g, n in zip(ref, got, sizes):
+        want = base[o:o + n].view_as(r) + r
+        scale = float(r.abs().max()) + 1.0
+        assert float((g.double() - want).abs().max()) < 2e-5 * scale * max(1.0, (rows / 1000) ** 0.5), (n, rows)
+        o += n
+    assert torch.equal(flat[:3].double(), base[:3]) and torch.equal(flat[-4:].double(), base[-4:])     # neighbours untouched
+    flat2, _ = run()
+    assert torch.equal(flat, flat2)
+
+
+@pytest.mark.parametrize("H,layers", [(256, 5), (128, 3)])
+@pytest.mark.parametrize("rows", [255, 40000])
+def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, layers, rows):
+    """Kind HR of tg_mlp_weight_grad rebuilds relu(W0 x + b0) on chip from the 64-B input row instead of reading the
+    stored activation: bit-identical to the HH job on what tg_mlp_forward_chain stored."""
+    from trajopt_grpo_amd import mlp as M, _native as N
+    torch.manual_seed(rows + H)
+    net = tg.NeuralNetwork(20, 4, (H,) * layers, "ReLU").to(dev)
+    mlp = M.GemmMLP(net, torch.bfloat16)
+    xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
+    mlp.forward(xp, keep=True)
+    a0 = mlp._acts[1]
+    dz = torch.randn(rows, H, device=dev).to(torch.bfloat16)
+    ws = M.weight_grad_workspace(H, dev)
+    w_a, b_a = torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)
+    w_b, b_b = torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)
+    M.weight_grad(H, [(N.TG_DW_HH, dz, a0, w_a, b_a)], rows, ws)
+    M.weight_grad(H, [(N.TG_DW_HR, dz, xp, w_b, b_b)], rows, ws, mlp._chain.stream, mlp._chain.bias[0])
+    torch.cuda.synchronize()
+    ref = dz.double().t() @ a0.double()
+    assert float((w_a.double() - ref).abs().max()) < 2e-5 * (float(ref.abs().max()) + 1.0) * max(1.0, (rows / 1000) ** 0.5)
+    assert torch.equal(w_a, w_b) and torch.equal(b_a, b_b)

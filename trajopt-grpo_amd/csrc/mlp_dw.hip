@@ -1,0 +1,507 @@
+// Weight gradients of the reference's ReLU MLP -- what `loss.backward()` (algorithms/ppo.py:181-183,
+// algorithms/grpo.py:143-145) leaves in every Linear's weight.grad / bias.grad -- for 10^6..10^7 rows in ONE launch:
+//
+//     dW_l[m][n] = sum over rows r of  dZ_l[r][m] * A_{l-1}[r][n]          db_l[m] = sum over rows r of dZ_l[r][m]
+//
+// Every dZ (written by tg_mlp_backward_chain) and every stored activation (tg_mlp_forward_chain) is read exactly ONCE;
+// the products are HBM-bound (128 flop per byte at H = 256), so the kernel is organised around the byte stream:
+//
+//   * a workgroup (8 waves, one per CU) owns ONE layer ("job") for a share of the rows and keeps that layer's whole
+//     H x H fp32 gradient in its accumulator registers (256 KiB at H = 256: 128 registers per lane in each of the 8
+//     waves) while the rows stream past; the CUs are split between the jobs in proportion to their bytes per row, so
+//     all finish together and there are ~50 partial gradients ("slabs") per layer instead of one per CU and layer;
+//   * 32-row stages of both operands flow HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging) through a
+//     ring of 4 slots with 3 stages in flight (96 KiB per CU): counted `s_waitcnt vmcnt`, raw `s_barrier` (see
+//     mfma_ring.hpp).  Every stage issues the same number of DMA instructions per wave -- stages past the end re-read the
+//     last row -- so the count is a compile-time constant;
+//   * the contraction runs over ROWS, which are the slow axis of both operands in memory: the fragments come out of
+//     LDS through the transposing read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16 lanes, delivered column-major).
+//     The LDS image of a panel is [row / 4][32-column group][row % 4][64 B]: a 32-lane half of a transposed read then
+//     covers 256 contiguous bytes (conflict-free) and every address is lane constant + immediate;
+//   * bias gradients ride along: one extra MFMA per k-step multiplies the dZ fragment with a matrix of ones (the
+//     matrix pipe is ~1/3 busy in this kernel; on the vector ALU the same sums cost the backward chain 10 %);
+//   * the first hidden layer's activations are not read at all (kind HR): they are a function of the 64-B input row,
+//     so the workgroup recomputes the stage's 32 x H tile (2 MFMAs per wave, same instruction sequence as the forward
+//     chain: identical bits) straight into the LDS image -- 576 instead of 1024 B per row for that layer, and the
+//     forward pass no longer has to write them;
+//   * rows past the end: their (clamped, finite) data is multiplied by zeros -- the dZ fragments of the last stage are
+//     masked in registers;
+//   * a second small kernel adds the slabs in a fixed order straight into the gradient windows (the learner's flat
+//     all-reduce bucket): deterministic, no float atomics.
+#include "mfma_ring.hpp"
+
+namespace tg {
+
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+
+constexpr int kDwMaxJobs = 8;
+constexpr int kDwStageRows = 32;
+constexpr int kDwSlots = 4;                 // ring slots; kDwSlots - 1 stages in flight
+
+struct DwJob {
+    const uint16_t* p;        // bf16 [rows][H] (HH, HX, HR) or [rows][8] (DH)
+    const uint16_t* q;        // bf16 [rows][H] (HH, DH) or [rows][32] (HX, HR)
+    int32_t kind;
+    int32_t first_block;      // workgroups [first_block, first_block + n_blocks) work on this job
+    int32_t n_blocks;
+    int32_t slab_len;         // floats per slab
+    int64_t slab_off;         // float offset of this job's slab 0 in the workspace
+};
+struct DwArgs {
+    DwJob job[kDwMaxJobs];
+    int32_t n_jobs;
+    const uint4* w0frag;      // HR: first-layer block of the forward chain's weight stream ([tile][k-step][64 lanes] x 16 B)
+    const float* b0;          // HR: first-layer bias, f32 [H]
+};
+
+// One MFMA operand fragment (8 consecutive ROWS of one column per lane) out of a row-major LDS panel: two transposing
+// reads of 4 rows each.  `__restrict__` on an inlined function's pointer parameter attaches alias-scope metadata to the
+// reads; without it hipcc waits for every outstanding LDS-DMA (vmcnt(0)) before an LDS read (mfma_ring.hpp).
+__device__ static inline bf16x8 tr_frag(const char* __restrict__ base, int off_lo, int off_hi) {
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(base + off_lo));
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(base + off_hi));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ static inline uint4 lds_load16(const char* __restrict__ p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ static inline void lds_store16(char* __restrict__ p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// zero the fragment elements whose row (first row of the lane's 8: `first`) is >= rows
+__device__ static inline bf16x8 mask_rows(bf16x8 f, int64_t first, int64_t rows) {
+    const int64_t left = rows - first;
+    const int nv = left <= 0 ? 0 : (left >= 8 ? 8 : (int)left);
+    uint4 u = __builtin_bit_cast(uint4, f);
+    uint32_t d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] &= (2 * k + 1 < nv) ? 0xFFFFFFFFu : (2 * k < nv ? 0x0000FFFFu : 0u);
+    return __builtin_bit_cast(bf16x8, uint4{d[0], d[1], d[2], d[3]});
+}
+
+template <int H>
+struct DwGeom {
+    static constexpr int CG = H / 32;                 // 32-column groups per row of a wide panel
+    static constexpr int ROWQ = CG * 256;             // bytes per 4-row group of a wide panel
+    static constexpr int PANEL = 8 * ROWQ;            // 32 rows
+    static constexpr int NPW = H / 128;               // 1-KiB DMA pieces per wave and wide panel
+    static constexpr int XOFF = 2 * PANEL;            // the 32 x 64 B input panel behind the two wide ones
+    static constexpr int SLOT = 2 * PANEL + 2048;
+    static constexpr int ZERO = kDwSlots * SLOT;      // 16 zero bytes
+    static constexpr int LDS_BYTES = ZERO + 16;
+    static constexpr int MA = H / 128, NB = H / 64;   // HH: 32-row / 32-column output tiles per wave (4 x 2 waves)
+};
+
+// ---- LDS-DMA of one stage (every call issues the same number of instructions per wave) ----
+template <int H>
+__device__ static inline void dma_wide(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* panel, int wave, int lane) {
+    using G = DwGeom<H>;
+#pragma unroll
+    for (int t = 0; t < G::NPW; ++t) {
+        const int piece = wave * G::NPW + t;
+        const int rquad = piece / (G::CG / 4), ch = piece % (G::CG / 4);
+        int64_t r = row0 + 4 * rquad + ((lane >> 2) & 3);
+        r = r < rows ? r : rows - 1;
+        const uint4* src = reinterpret_cast<const uint4*>(g) + r * (H / 8) + (4 * ch + (lane >> 4)) * 4 + (lane & 3);
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, 0);
+    }
+}
+__device__ static inline void dma_x(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* xpanel, int wave, int lane) {
+    const int pc = wave & 1;                                        // 2 pieces of 16 rows x 64 B; every wave moves one
+    int64_t r = row0 + 16 * pc + (lane >> 2);
+    r = r < rows ? r : rows - 1;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r * 4 + (lane & 3), (lds_void*)(xpanel + pc * 1024), 16, 0, 0);
+}
+__device__ static inline void dma_d8(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* panel, int lane) {
+    if (lane < 32) {                                                // 32 rows x 16 B
+        int64_t r = row0 + lane;
+        r = r < rows ? r : rows - 1;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r, (lds_void*)panel, 16, 0, 0);
+    }
+}
+
+enum : int32_t { DW_HH = 0, DW_HX = 1, DW_DH = 2, DW_HR = 3 };
+
+template <int H, int KIND>
+__device__ static inline void dw_issue(const DwJob& job, int64_t sg, int64_t rows, char* slot, int wave, int lane) {
+    using G = DwGeom<H>;
+    const int64_t row0 = sg * kDwStageRows;
+    if constexpr (KIND == DW_HH) {
+        dma_wide<H>(job.p, row0, rows, slot, wave, lane);
+        dma_wide<H>(job.q, row0, rows, slot + G::PANEL, wave, lane);
+    } else if constexpr (KIND == DW_HX || KIND == DW_HR) {
+        dma_wide<H>(job.p, row0, rows, slot, wave, lane);
+        dma_x(job.q, row0, rows, slot + G::XOFF, wave, lane);
+    } else {
+        dma_d8(job.p, row0, rows, slot, lane);
+        dma_wide<H>(job.q, row0, rows, slot + G::PANEL, wave, lane);
+    }
+}
+
+template <int H, int KIND>
+__device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows, float* __restrict__ ws, char* lds_c) {
+    using G = DwGeom<H>;
+    constexpr int D = kDwSlots, P = D - 1;
+    constexpr int NG = (KIND == DW_HH) ? 2 * G::NPW : G::NPW + 1;     // DMA instructions per wave and stage
+    constexpr int MA = (KIND == DW_HH || KIND == DW_HR) ? G::MA : 1;
+    constexpr int NB = (KIND == DW_HH || KIND == DW_HR) ? G::NB : 1;
+    constexpr int NT = H / 32;                                        // 32-wide tiles across a wide operand
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int my = (int)blockIdx.x - job.first_block, nb = job.n_blocks;
+    const int64_t n_st = (rows + kDwStageRows - 1) / kDwStageRows;
+
+    // wave -> output tiles.  HH / HR: 4 (m) x 2 (n) waves; HX: wave w = m-tile w; DH: wave w = n-tile w
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool active = (KIND == DW_HH || KIND == DW_HR) ? true : wave < NT;
+    // lane part of a transposed fragment read: rows 8h + q (+4), columns 16 g1 + 4 p .. +3 of the tile's 32
+    const int lane_wide = 2 * h * G::ROWQ + q4 * 64 + g1 * 32 + p4 * 8;
+    const int lane_x = 2 * h * 256 + q4 * 64 + g1 * 32 + p4 * 8;
+    int offA, offB;                                                   // + slot base + k-step / tile immediates
+    if constexpr (KIND == DW_HH || KIND == DW_HR) {
+        offA = lane_wide + (MA * wm) * 256;
+        offB = G::PANEL + lane_wide + (NB * wn) * 256;
+    } else if constexpr (KIND == DW_HX) {
+        offA = lane_wide + (wave % NT) * 256;
+        offB = G::XOFF + lane_x;
+    } else {
+        offA = (8 * h + q4) * 16 + 8 * p4;                            // [32 rows][8 columns]: lanes g1 == 0, p < 2
+        offB = G::PANEL + lane_wide + (wave % NT) * 256;
+    }
+    const bool d8_valid = g1 == 0 && p4 < 2;
+
+    f32x16 acc[MA][NB];
+    f32x16 accb = {};
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x16{};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    // HR: this wave's 32 first-layer features (tile `wave`): weight fragments + bias in registers
+    bf16x8 w0[2] = {};
+    f32x16 b0v = {};
+    if constexpr (KIND == DW_HR) {
+        if (wave < NT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) w0[ks] = __builtin_bit_cast(bf16x8, args.w0frag[(wave * 2 + ks) * 64 + lane]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b0v[r] = args.b0[32 * wave + 16 * h + r];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ordinary loads: none may be counted in the ring
+    }
+
+    int64_t sg_issue = my;
+    int slot_issue = 0;
+#pragma unroll 1
+    for (int i = 0; i < P; ++i) {
+        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * G::SLOT, wave, lane);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+    }
+
+    int slot = 0;
+#pragma unroll 1
+    for (int64_t sg = my; sg < n_st; sg += nb) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * G::SLOT, wave, lane);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+
+        char* sb = lds_c + slot * G::SLOT;
+        slot = slot + 1 == D ? 0 : slot + 1;
+        const int64_t row0 = sg * kDwStageRows;
+        const bool partial = row0 + kDwStageRows > rows;              // wave-uniform
+
+        if constexpr (KIND == DW_HR) {
+            // a0 tile = relu(W0 . x^T + b0) for the stage's 32 rows, into the Q panel's image
+            if (wave < NT) {
+                const int row = lane & 31;
+                f32x16 t = b0v;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + G::XOFF + row * 64 + 32 * ks + 16 * h));
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xb, t, 0, 0, 0);
+                }
+                const bf16x8 lo = relu_pack_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+                const bf16x8 hi = relu_pack_bf16(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
+                char* dst = sb + G::PANEL + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 32 * h;
+                lds_store16(dst, __builtin_bit_cast(uint4, lo));
+                lds_store16(dst + 16, __builtin_bit_cast(uint4, hi));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[MA], b[NB];
+                if constexpr (KIND == DW_DH) {
+                    // lanes without a column of their own (columns 8..31 of the padded tile) read the zero word
+                    const int o = d8_valid ? (int)(sb - lds_c) + offA + 256 * ks : G::ZERO;
+                    a[0] = tr_frag(lds_c, o, d8_valid ? o + 64 : o);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MA; ++m) a[m] = tr_frag(sb, offA + 4 * ks * G::ROWQ + m * 256, offA + (4 * ks + 1) * G::ROWQ + m * 256);
+                }
+                if constexpr (KIND == DW_HX) {
+                    b[0] = tr_frag(sb, offB + 4 * ks * 256, offB + (4 * ks + 1) * 256);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) b[n] = tr_frag(sb, offB + 4 * ks * G::ROWQ + n * 256, offB + (4 * ks + 1) * G::ROWQ + n * 256);
+                }
+                if (partial) {
+#pragma unroll
+                    for (int m = 0; m < MA; ++m) a[m] = mask_rows(a[m], row0 + 16 * ks + 8 * h, rows);
+                }
+#pragma unroll
+                for (int m = 0; m < MA; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                // bias gradient of one m-tile per wave: HH / HR at H = 256: tile 2 wm + wn; at H = 128: the wn == 0 waves
+                if constexpr (KIND == DW_HH || KIND == DW_HR) {
+                    if constexpr (MA == 2) {
+                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? a[1] : a[0], ones, accb, 0, 0, 0);
+                    } else {
+                        if (wn == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, accb, 0, 0, 0);
+                    }
+                } else if constexpr (KIND == DW_HX) {
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, accb, 0, 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no LDS-DMA may outlive the workgroup's LDS allocation
+
+    // ---- this workgroup's slab: [M][N] gradient (+ [M] bias sums) ----
+    float* slab = ws + job.slab_off + (int64_t)my * job.slab_len;
+    const int col = lane & 31;
+    if (active) {
+        if constexpr (KIND == DW_HH || KIND == DW_HR) {
+#pragma unroll
+            for (int m = 0; m < MA; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const int m0 = 32 * (MA * wm + m), n0 = 32 * (NB * wn + n);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * H + n0 + col] = acc[m][n][r];
+                }
+            const bool has_bias = (MA == 2) || wn == 0;
+            if (has_bias && col == 0) {
+                const int m0 = 32 * (MA == 2 ? 2 * wm + wn : wm);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[H * H + m0 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+            }
+        } else if constexpr (KIND == DW_HX) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + col] = acc[0][0][r];
+            if (col == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[H * 32 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(r + 4 * h) * H + 32 * wave + col] = acc[0][0][r];    // rows 0..7 of the padded 32
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(512, 2) void dw_kernel(DwArgs args, int64_t rows, float* __restrict__ ws) {
+    extern __shared__ uint4 lds[];
+    char* lds_c = reinterpret_cast<char*>(lds);
+    if (threadIdx.x == 0) lds[DwGeom<H>::ZERO / 16] = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < kDwMaxJobs; ++t)
+        if (t < args.n_jobs && (int)blockIdx.x >= args.job[t].first_block) j = t;
+    const DwJob job = args.job[j];
+    switch (job.kind) {
+        case DW_HH: dw_run<H, DW_HH>(args, job, rows, ws, lds_c); break;
+        case DW_HX: dw_run<H, DW_HX>(args, job, rows, ws, lds_c); break;
+        case DW_DH: dw_run<H, DW_DH>(args, job, rows, ws, lds_c); break;
+        default: dw_run<H, DW_HR>(args, job, rows, ws, lds_c); break;
+    }
+}
+
+// grad[m][n] += sum over the job's slabs, in slab order.  One thread per output element; consecutive threads read
+// consecutive floats of a slab row.
+struct DwFinishDesc {
+    const float* slab;        // slab 0, already offset to the region ([M][N] gradient or [1][M] bias sums)
+    float* grad;
+    int64_t grad_ld;
+    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
+};
+struct DwFinishArgs { DwFinishDesc d[2 * kDwMaxJobs]; int32_t n; int32_t total; };
+
+__global__ __launch_bounds__(256) void dw_finish_all_kernel(DwFinishArgs fa) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= fa.total) return;
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < 2 * kDwMaxJobs; ++t)
+        if (t < fa.n && e >= fa.d[t].first_elem) k = t;
+    const DwFinishDesc d = fa.d[k];
+    const int le = e - d.first_elem;
+    const int m = le / d.n_out, n = le - m * d.n_out;
+    const float* src = d.slab + (int64_t)m * d.N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= d.n_slabs; b += 4) {                    // 4 loads in flight; the sum order stays fixed
+        const float v0 = src[(int64_t)b * d.slab_len], v1 = src[(int64_t)(b + 1) * d.slab_len];
+        const float v2 = src[(int64_t)(b + 2) * d.slab_len], v3 = src[(int64_t)(b + 3) * d.slab_len];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < d.n_slabs; ++b) s0 += src[(int64_t)b * d.slab_len];
+    d.grad[(int64_t)m * d.grad_ld + n] += (s0 + s1) + (s2 + s3);
+}
+
+static int dw_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        n = cus;
+    }
+    return n;
+}
+
+static int64_t dw_bytes_per_row(int H, int kind) {
+    switch (kind) {
+        case DW_HH: return 4 * H;
+        case DW_HX: case DW_HR: return 2 * H + 64;
+        default: return 2 * H + 16;
+    }
+}
+static int dw_slab_len(int H, int kind) {
+    switch (kind) {
+        case DW_HH: case DW_HR: return H * H + H;
+        case DW_HX: return H * 32 + H;
+        default: return 8 * H;
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+template <int H>
+static int launch_dw(const DwArgs& args, int grid, int64_t rows, float* ws, hipStream_t st) {
+    auto kern = dw_kernel<H>;
+    const size_t shmem = DwGeom<H>::LDS_BYTES;
+    static size_t attr_bytes = 0;
+    if (shmem > 64 * 1024 && shmem > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(TG_ERR_HIP, "tg_mlp_weight_grad: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
+        }
+        attr_bytes = shmem;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), shmem, st, args, rows, ws);
+    TG_LAUNCH_CHECK("tg_mlp_weight_grad");
+    return TG_OK;
+}
+
+extern "C" {
+
+int64_t tg_mlp_weight_grad_workspace(int32_t hidden) {
+    if (hidden != 128 && hidden != 256) return 0;
+    return (int64_t)dw_cus() * (hidden * hidden + hidden) * (int64_t)sizeof(float);
+}
+
+int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag, const float* d_b0,
+                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+    TG_REQUIRE(jobs && d_workspace, "tg_mlp_weight_grad: null pointer");
+    TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_weight_grad: hidden width %d unsupported (128, 256)", hidden);
+    TG_REQUIRE(n_jobs >= 1 && n_jobs <= kDwMaxJobs, "tg_mlp_weight_grad: %d jobs outside 1..%d", n_jobs, kDwMaxJobs);
+    TG_REQUIRE(rows >= 0, "tg_mlp_weight_grad: negative row count");
+    TG_REQUIRE(workspace_bytes >= tg_mlp_weight_grad_workspace(hidden), "tg_mlp_weight_grad: workspace of %lld B is smaller than %lld B",
+               (long long)workspace_bytes, (long long)tg_mlp_weight_grad_workspace(hidden));
+    if (rows == 0) return TG_OK;
+    const int H = hidden;
+    int64_t wsum = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const tg_dw_job& jb = jobs[j];
+        TG_REQUIRE(jb.kind >= TG_DW_HH && jb.kind <= TG_DW_HR, "tg_mlp_weight_grad: job %d has kind %d", j, jb.kind);
+        TG_REQUIRE(jb.d_p && jb.d_q && jb.d_wgrad, "tg_mlp_weight_grad: job %d has a null pointer", j);
+        const int M = jb.kind == TG_DW_DH ? 8 : H, N = (jb.kind == TG_DW_HX) ? 32 : H;
+        TG_REQUIRE(jb.m_out >= 1 && jb.m_out <= M && jb.n_out >= 1 && jb.n_out <= N && jb.wgrad_ld >= jb.n_out,
+                   "tg_mlp_weight_grad: job %d: window %d x %d (ld %lld) outside %d x %d", j, jb.m_out, jb.n_out, (long long)jb.wgrad_ld, M, N);
+        TG_REQUIRE(jb.kind != TG_DW_DH || !jb.d_bgrad, "tg_mlp_weight_grad: job %d: the head's bias gradient comes from tg_head_prep", j);
+        TG_REQUIRE(jb.kind != TG_DW_HR || (d_w0frag && d_b0), "tg_mlp_weight_grad: job %d recomputes the first layer: weights / bias missing", j);
+        wsum += dw_bytes_per_row(H, jb.kind);
+    }
+    // workgroups per job in proportion to its bytes per row (largest remainders), at least one, at most one per 4 stages
+    const int64_t n_st = ceil_div(rows, (int64_t)kDwStageRows);
+    const int cap = (int)(n_st < 4 ? 1 : (n_st / 4 > 1 << 20 ? 1 << 20 : n_st / 4));
+    const int cus = dw_cus();
+    int alloc[kDwMaxJobs];
+    int64_t rem[kDwMaxJobs];
+    int used = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int64_t w = dw_bytes_per_row(H, jobs[j].kind) * cus;
+        alloc[j] = (int)(w / wsum);
+        rem[j] = w % wsum;
+        if (alloc[j] < 1) { alloc[j] = 1; rem[j] = 0; }
+        used += alloc[j];
+    }
+    while (used < cus) {
+        int best = 0;
+        for (int j = 1; j < n_jobs; ++j)
+            if (rem[j] > rem[best]) best = j;
+        if (rem[best] == 0) break;
+        ++alloc[best];
+        rem[best] = 0;
+        ++used;
+    }
+    DwArgs args{};
+    args.n_jobs = n_jobs;
+    args.w0frag = (const uint4*)d_w0frag;
+    args.b0 = d_b0;
+    DwFinishArgs fa{};
+    int grid = 0, elems = 0;
+    int64_t off = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const tg_dw_job& jb = jobs[j];
+        DwJob& dj = args.job[j];
+        dj.p = (const uint16_t*)jb.d_p;
+        dj.q = (const uint16_t*)jb.d_q;
+        dj.kind = jb.kind;
+        dj.first_block = grid;
+        dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;
+        dj.slab_len = dw_slab_len(H, jb.kind);
+        dj.slab_off = off;
+        grid += dj.n_blocks;
+        const int N = (jb.kind == TG_DW_HX) ? 32 : H;
+        DwFinishDesc& fd = fa.d[fa.n++];
+        fd = DwFinishDesc{(const float*)d_workspace + off, jb.d_wgrad, jb.wgrad_ld, dj.slab_len, dj.n_blocks, N, jb.m_out, jb.n_out, elems};
+        elems += jb.m_out * jb.n_out;
+        if (jb.d_bgrad) {
+            const int boff = jb.kind == TG_DW_HX ? H * 32 : H * H;
+            DwFinishDesc& fb = fa.d[fa.n++];
+            fb = DwFinishDesc{(const float*)d_workspace + off + boff, jb.d_bgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.m_out, elems};
+            elems += jb.m_out;
+        }
+        off += (int64_t)dj.n_blocks * dj.slab_len;
+    }
+    fa.total = elems;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = hidden == 256 ? launch_dw<256>(args, grid, rows, (float*)d_workspace, st) : launch_dw<128>(args, grid, rows, (float*)d_workspace, st);
+    if (rc != TG_OK) return rc;
+    hipLaunchKernelGGL(dw_finish_all_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, fa);
+    TG_LAUNCH_CHECK("tg_mlp_weight_grad (finish)");
+    return TG_OK;
+}
+
+}  // extern "C"

@@ -27,6 +27,28 @@ _ROW_BLOCK = 8192
 _SPLIT_BATCHES = 128
 
 
+def weight_grad(hidden: int, jobs, rows: int, workspace: torch.Tensor, w0frag: torch.Tensor = None, b0: torch.Tensor = None):
+    """tg_mlp_weight_grad: every job's `wgrad += P^T Q` (and `bgrad += column sums of P`) in one persistent launch + one
+    fixed-order reduction.  jobs = [(kind, P, Q, wgrad, bgrad or None)]; P / Q bf16 row-major [rows][*], wgrad a 2-D
+    fp32 view with unit column stride (e.g. a window of the learner's flat gradient bucket)."""
+    arr = (N.DwJob * len(jobs))()
+    for slot, (kind, p, q, wgrad, bgrad) in zip(arr, jobs):
+        N.require_cuda(p, q, wgrad, bgrad)
+        assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and p.is_contiguous() and q.is_contiguous()
+        assert p.shape[0] >= rows and q.shape[0] >= rows
+        assert wgrad.dtype == torch.float32 and wgrad.dim() == 2 and wgrad.stride(1) == 1
+        assert bgrad is None or (bgrad.dtype == torch.float32 and bgrad.is_contiguous() and bgrad.numel() == wgrad.shape[0])
+        slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wgrad.data_ptr(), N.ptr(bgrad)
+        slot.wgrad_ld, slot.kind, slot.m_out, slot.n_out = wgrad.stride(0), kind, wgrad.shape[0], wgrad.shape[1]
+    N.check(N.load().tg_mlp_weight_grad(hidden, arr, len(jobs), rows, N.ptr(w0frag), N.ptr(b0), workspace.data_ptr(),
+                                        workspace.numel() * workspace.element_size(), N.stream_ptr(workspace.device)),
+            "tg_mlp_weight_grad")
+
+
+def weight_grad_workspace(hidden: int, device) -> torch.Tensor:
+    return torch.empty(N.load().tg_mlp_weight_grad_workspace(hidden) // 4, dtype=torch.float32, device=device)
+
+
 def supports(net) -> bool:
     mods = list(net.network)
     if len(mods) < 3 or len(mods) % 2 == 0:
