@@ -295,7 +295,8 @@ int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act
  *   d_wfrag  bf16 weight stream in MFMA fragment order (trajopt-grpo_amd/mlp.py `FragmentStream(layout="chain")`
  *            documents and builds it), d_bias f32 [n_hidden_layers + 1][H] (natural order, head row zero-padded)
  *   d_acts   HOST array of n_hidden_layers device pointers, bf16 [rows][H] each (post-ReLU outputs of the hidden
- *            layers, row-major), or NULL to skip storing them
+ *            layers, row-major), or NULL to skip storing them.  d_acts[0] alone may be NULL: the first activation is
+ *            then left out (tg_mlp_weight_grad kind HR recomputes it; its mask bits are still written)
  *   d_masks  HOST array of n_hidden_layers device pointers, u32 [rows][H / 32] each, or NULL: the ReLU masks of the
  *            stored activations, 1 bit each (all the backward-data kernels need of them).  Per row: [lane half h = 0, 1]
  *            [H / 64 words]; feature 32 mt + 16 h + r is bit (mt & 1) * 8 + (r >> 1) + 16 * (r & 1) of word mt >> 1
@@ -317,7 +318,8 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
  *   d_dz      HOST array of n_hidden_layers device pointers, bf16 [rows][H]: outputs, TOP hidden layer first
  *   d_masks   HOST array of the same layers' ReLU mask bits (u32 [rows][H/32], as tg_mlp_forward_chain writes them)
  *   d_partial f32 [tg_mlp_backward_chain_blocks()][n_hidden_layers][H]: per-workgroup column sums of the dZ (bias
- *             gradients; the caller sums axis 0).  Deterministic. */
+ *             gradients; the caller sums axis 0).  Deterministic.  NULL: no column sums (tg_mlp_weight_grad forms the
+ *             bias gradients inside its contraction; the kernel is ~10 % shorter without them). */
 int  tg_mlp_backward_chain_blocks(void);
 int  tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
                            void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream);

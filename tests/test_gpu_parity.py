@@ -675,6 +675,7 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     mlp = GemmMLP(net, torch.bfloat16)
     assert mlp._chain is not None
     xp = mlp.prepare_input(torch.randn(rows, S, device=dev))
+    bchain, mlp._bchain = mlp._bchain, None                              # per-layer backward mode: every activation is stored
     out_c = mlp.forward(xp, keep=True, padded=True)
     acts_c = mlp._acts
     assert len(acts_c) == len(hidden) + 1 and acts_c[0] is xp
@@ -682,6 +683,8 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     assert len(mlp._bits) == len(acts_c) and mlp._bits[0] is None
     for a_l, b_l in zip(acts_c[1:], mlp._bits[1:]):
         assert torch.equal(b_l, _pack_mask_bits(a_l))
+    mlp_bits_c = [None if b is None else b.clone() for b in mlp._bits]
+    acts_c = [a if a is xp else a.clone() for a in acts_c]                # the workspace buffers are reused by later passes
     out_nokeep = mlp.forward(xp, keep=False, padded=True)
     assert mlp._acts is None and torch.equal(out_nokeep, out_c)          # same arithmetic with and without the stores
     chain, mlp._chain = mlp._chain, None
@@ -702,6 +705,18 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     np.testing.assert_allclose(out_c[:, :A].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert torch.all(out_c[:, A:] == 0)
     assert float((out_c - out_l).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
+    if bchain is not None:
+        # with the backward chain active the first activation is left out (tg_mlp_weight_grad recomputes it); everything
+        # else -- later activations, ALL mask bits, the output -- is bit-identical
+        bits_c = [None if b is None else b.clone() for b in mlp_bits_c]
+        acts_keep = [None if a is None else a.clone() for a in acts_c]
+        mlp._bchain = bchain
+        out_s = mlp.forward(xp, keep=True, padded=True)
+        assert mlp._acts[1] is None and torch.equal(out_s, out_c)
+        for a_s, a_k in zip(mlp._acts[2:], acts_keep[2:]):
+            assert torch.equal(a_s, a_k)
+        for b_s, b_k in zip(mlp._bits[1:], bits_c[1:]):
+            assert torch.equal(b_s, b_k)
 
 
 @pytest.mark.parametrize("dims,rows", [((20, 4, (256,) * 5), 70001), ((20, 1, (256,) * 3), 257), ((10, 2, (256,) * 4), 1),
@@ -1285,7 +1300,9 @@ def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, laye
     net = tg.NeuralNetwork(20, 4, (H,) * layers, "ReLU").to(dev)
     mlp = M.GemmMLP(net, torch.bfloat16)
     xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
+    keep_chain, mlp._bchain = mlp._bchain, None                   # per-layer backward mode: the forward pass stores a0
     mlp.forward(xp, keep=True)
+    mlp._bchain = keep_chain
     a0 = mlp._acts[1]
     dz = torch.randn(rows, H, device=dev).to(torch.bfloat16)
     ws = M.weight_grad_workspace(H, dev)

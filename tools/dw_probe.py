@@ -22,7 +22,9 @@ for p in net.parameters():
     p.grad = torch.zeros_like(p)
 mlp = M.GemmMLP(net, torch.bfloat16)
 xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
+keep_chain, mlp._bchain = mlp._bchain, None       # store every activation (the GEMM path reads the first one)
 mlp.forward(xp, keep=True)
+mlp._bchain = keep_chain
 acts = mlp._acts
 dzs = [(torch.randn(rows, H, device=dev) * (torch.rand(rows, H, device=dev) > 0.4)).to(torch.bfloat16) for _ in range(nh)]
 dh = torch.zeros(rows, 8, device=dev, dtype=torch.bfloat16)

@@ -71,6 +71,9 @@ __global__ __launch_bounds__(64 * WPW, (NT == 2) ? 1 : 2) void fused_rollout_ker
     constexpr int D = (NT == 1 && WPW == 4) ? 3 : 4, P = D - 1;   // ring slots, blocks in flight (LDS is shared by 2 workgroups at 4 x NT=1)
     static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
     static_assert(S <= 32 && A <= 4, "state must fit one padded 32-feature tile; actions the first 4 head rows");
+    // the compaction staging ([32 * WPW][S + 1] floats) aliases xs (WPW * 64 * 32 bf16 = 4096 * WPW bytes);
+    // per wave: 32 records of S + 1 floats in 64 * 32 bf16; compaction only runs with NT == 1
+    static_assert(NT != 1 || 32 * (S + 1) * 4 <= 64 * 32 * 2, "compaction records must fit the input staging area they alias");
     extern __shared__ uint4 lds[];
     uint4* ring = lds;                                                  // D * KS * 64 uint4
     float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
@@ -337,21 +340,8 @@ static int fused_launch(const tg_env_params* p, const tg_traj* tr, const void* w
     const size_t shmem = (size_t)((NT == 1 && WPW == 4) ? 3 : 4) * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) +
                          (size_t)WPW * 64 * 32 * 2 + 4 * WPW;
     auto kern = fused_rollout_kernel<Env, H, NT, WPW>;
-    if (shmem > 160 * 1024) return set_error(TG_ERR_ARG, "tg_fused_rollout: %zu B of LDS needed (> 160 KiB)", shmem);
-    static size_t attr_bytes = 0;
-    if (shmem > 64 * 1024 && shmem > attr_bytes) {
-        // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            int dev = 0, maxb = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&maxb, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
-            return set_error(TG_ERR_HIP, "tg_fused_rollout: cannot reserve %zu B of LDS (%s; device max per block %d)", shmem,
-                             hipGetErrorString(e), maxb);
-        }
-        attr_bytes = shmem;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_fused_rollout")) return rc;
     const dim3 grid((unsigned)ceil_div(tr->n, 32 * NT * WPW));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WPW), shmem, st, c, (float*)tr->d_obs, tr->d_act, (float*)tr->d_rew, tr->d_mask,
                        tr->d_len, tr->n, tr->horizon, t0, t1, (const uint4*)wfrag, bias, n_hh, sg, rng, env_offset, p->agents);

@@ -52,8 +52,8 @@ __device__ static inline void ring_dma_block(const uint4* __restrict__ gblock, u
 
 // Consume the next block.  Expects in scope: wfrag, ring, n_blocks, wave, lane, the ring state (pre_pos, pre_slot,
 // cur_slot) and the constants KS, WPW, D; declares `cur` (the block's fragments).  WAITN: see above.
-#define TG_RING_ADVANCE(WAITN)                                                                             \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                                           \
+#define TG_RING_WAIT(WAITN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+#define TG_RING_NEXT                                                                                       \
     __builtin_amdgcn_s_barrier();                                                                          \
     asm volatile("" ::: "memory");                                                                         \
     ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);    \
@@ -61,5 +61,6 @@ __device__ static inline void ring_dma_block(const uint4* __restrict__ gblock, u
     pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                                     \
     const uint4* cur = ring + cur_slot * KS * 64;                                                          \
     cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+#define TG_RING_ADVANCE(WAITN) TG_RING_WAIT(WAITN) TG_RING_NEXT
 
 }  // namespace tg

@@ -95,7 +95,7 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
 // column sums to the wave's bias table (`own` = all ones for a lane with a row of its own, else 0; `full` = every lane
 // of the wave has one, the case in all rounds but the last).
 struct SelPair { bf16x8 lo, hi; };
-template <int H>
+template <int H, bool kBias>
 __device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt, bf16x8& lo, bf16x8& hi, float* __restrict__ btab,
                                           bool writer, uint32_t own, bool full, const SelPair& sel) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -109,6 +109,7 @@ __device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt,
     }
     lo = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
     hi = __builtin_bit_cast(bf16x8, uint4{o[4], o[5], o[6], o[7]});
+    if constexpr (!kBias) return;                     // the bias gradients come out of tg_mlp_weight_grad's contraction
     // operand slot k = 8 h + j of `lo` is feature 16 h + j, of `hi` feature 16 h + 8 + j: lane n' (< 16: slot n' of lo,
     // 16..31: slot n' - 16 of hi) gets their sums, i.e. table entry 32 mt + 16 ((n'&15)>>3) + (n'&7) + 8 (n'>>4)
     float s;
@@ -121,7 +122,7 @@ __device__ static inline void masked_tile(const f32x16& acc, uint32_t w, int mt,
     bias_accumulate(btab + 32 * mt, s, writer);
 }
 
-template <int H, int WPW>
+template <int H, int WPW, bool kBias>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4* __restrict__ dzh, const uint4* __restrict__ wfrag,
                                                                     int32_t n_layers, int64_t rows, BwdChainPtrs ptrs,
                                                                     float* __restrict__ partial) {
@@ -145,7 +146,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     const int n_blocks = (n_layers - 1) * MT + 1;
     constexpr int WPL = MT / 2;                                         // mask words per lane and layer
 
-    for (int q = threadIdx.x; q < WPW * n_layers * H; q += 64 * WPW) bacc[q] = 0.f;
+    if constexpr (kBias) {
+        for (int q = threadIdx.x; q < WPW * n_layers * H; q += 64 * WPW) bacc[q] = 0.f;
+    }
     __syncthreads();
 
     uint4* my_dzs = dzs + wave * 64;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
+                masked_tile<H, kBias>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
                 if (mt & 1)
                     store_pair(stage, ptrs.dz[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
                 }
-                masked_tile<H>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
+                masked_tile<H, kBias>(acc, mw[mt >> 1], mt, xout[2 * mt], xout[2 * mt + 1], bt, writer, own, full, sel);
                 if (mt & 1)
                     store_pair(stage, ptrs.dz[j] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
     __syncthreads();
+    if constexpr (!kBias) return;
     for (int c = threadIdx.x; c < n_layers * H; c += 64 * WPW) {
         float s = 0.f;
 #pragma unroll
@@ -278,31 +282,21 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     }
 }
 
-static int bwd_chain_blocks() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        n = cus;
-    }
-    return n;
-}
+static int bwd_chain_blocks() { return device_cus(); }
 
 }  // namespace tg
 
 using namespace tg;
 
-template <int H>
+template <int H, bool kBias>
 static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_hidden_layers, int64_t rows, void* const* d_dz,
                             const void* const* d_masks, float* d_partial, hipStream_t st) {
     constexpr int WPW = 8, KS = H / 16;
     const int grid_max = bwd_chain_blocks();
+    const size_t partial_bytes = (size_t)grid_max * n_hidden_layers * H * sizeof(float);
     if (rows == 0) {
-        hipError_t e = hipMemsetAsync(d_partial, 0, (size_t)grid_max * n_hidden_layers * H * sizeof(float), st);
+        if (!kBias) return TG_OK;
+        hipError_t e = hipMemsetAsync(d_partial, 0, partial_bytes, st);
         return e == hipSuccess ? TG_OK : set_error(TG_ERR_HIP, "tg_mlp_backward_chain: memset failed (%s)", hipGetErrorString(e));
     }
     BwdChainPtrs ptrs{};
@@ -311,22 +305,15 @@ static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_
         ptrs.dz[j] = (uint16_t*)d_dz[j];
         ptrs.mask[j] = (const uint32_t*)d_masks[j];
     }
-    const size_t shmem = (size_t)3 * KS * 1024 + (size_t)WPW * 32 * 128 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024 + (size_t)WPW * n_hidden_layers * H * sizeof(float);
-    TG_REQUIRE(shmem <= 160 * 1024, "tg_mlp_backward_chain: %zu B of LDS needed (> 160 KiB)", shmem);
-    auto kern = mlp_bwd_chain_kernel<H, WPW>;
-    static size_t attr_bytes = 0;
-    if (shmem > 64 * 1024 && shmem > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return set_error(TG_ERR_HIP, "tg_mlp_backward_chain: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
-        }
-        attr_bytes = shmem;
-    }
+    const size_t shmem = (size_t)3 * KS * 1024 + (size_t)WPW * 32 * 128 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024 +
+                         (kBias ? (size_t)WPW * n_hidden_layers * H * sizeof(float) : 0);
+    auto kern = mlp_bwd_chain_kernel<H, WPW, kBias>;
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_backward_chain")) return rc;
     const int64_t n_rounds = ceil_div(rows, (int64_t)32 * WPW);
     const unsigned grid = (unsigned)(n_rounds < grid_max ? n_rounds : grid_max);
-    if ((int)grid < grid_max) {      // workgroups that do not run leave their partial rows untouched: clear them
-        hipError_t e = hipMemsetAsync(d_partial, 0, (size_t)grid_max * n_hidden_layers * H * sizeof(float), st);
+    if (kBias && (int)grid < grid_max) {      // workgroups that do not run leave their partial rows untouched: clear them
+        hipError_t e = hipMemsetAsync(d_partial, 0, partial_bytes, st);
         if (e != hipSuccess) return set_error(TG_ERR_HIP, "tg_mlp_backward_chain: memset failed (%s)", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint4*)d_dout8, (const uint4*)d_wfrag, n_hidden_layers, rows,
@@ -341,14 +328,16 @@ int tg_mlp_backward_chain_blocks(void) { return bwd_chain_blocks(); }
 
 int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
                           void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream) {
-    TG_REQUIRE(d_dout8 && d_wfrag && d_dz && d_masks && d_partial, "tg_mlp_backward_chain: null pointer");
+    TG_REQUIRE(d_dout8 && d_wfrag && d_dz && d_masks, "tg_mlp_backward_chain: null pointer");
     TG_REQUIRE(hidden == 256 || hidden == 128, "tg_mlp_backward_chain: hidden width %d unsupported (128, 256)", hidden);
     TG_REQUIRE(n_hidden_layers >= 3 && n_hidden_layers <= kBwdMaxLayers, "tg_mlp_backward_chain: %d hidden layers outside 3..%d",
                n_hidden_layers, kBwdMaxLayers);
     TG_REQUIRE(rows >= 0, "tg_mlp_backward_chain: negative row count");
     hipStream_t st = (hipStream_t)stream;
-    return hidden == 256 ? launch_bwd_chain<256>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st)
-                         : launch_bwd_chain<128>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st);
+#define TG_BWD_ARGS d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st
+    if (d_partial) return hidden == 256 ? launch_bwd_chain<256, true>(TG_BWD_ARGS) : launch_bwd_chain<128, true>(TG_BWD_ARGS);
+    return hidden == 256 ? launch_bwd_chain<256, false>(TG_BWD_ARGS) : launch_bwd_chain<128, false>(TG_BWD_ARGS);
+#undef TG_BWD_ARGS
 }
 
 }  // extern "C"

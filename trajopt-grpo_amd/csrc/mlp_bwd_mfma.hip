@@ -196,34 +196,15 @@ __global__ __launch_bounds__(64 * kDxWaves, 1) void dx_relu_bias_kernel(const ui
     }
 }
 
-static int dx_blocks() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        n = cus;
-    }
-    return n;
-}
+static int dx_blocks() { return device_cus(); }
 
 template <int M, int K, int NT, int kDxWaves, bool kBits>
 static int dx_launch(const void* dz_in, const void* wfrag, const void* act, const void* maskbits, void* dz_out, int64_t rows,
                      float* partial, hipStream_t st) {
     const size_t shmem = (size_t)M * K * 2;
     auto kern = dx_relu_bias_kernel<M, K, NT, kDxWaves, kBits>;
-    static bool attr_done = false;
-    if (shmem > 64 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return set_error(TG_ERR_HIP, "tg_dx_relu_bias: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
-        }
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_dx_relu_bias")) return rc;
     hipLaunchKernelGGL(kern, dim3(dx_blocks()), dim3(64 * kDxWaves), shmem, st, (const uint16_t*)dz_in, (const uint4*)wfrag,
                        (const uint16_t*)act, (const uint32_t*)maskbits, (uint16_t*)dz_out, rows, partial);
     TG_LAUNCH_CHECK("tg_dx_relu_bias");

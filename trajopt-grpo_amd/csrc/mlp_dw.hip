@@ -28,6 +28,8 @@
 //     masked in registers;
 //   * a second small kernel adds the slabs in a fixed order straight into the gradient windows (the learner's flat
 //     all-reduce bucket): deterministic, no float atomics.
+#include <stdlib.h>
+
 #include "mfma_ring.hpp"
 
 namespace tg {
@@ -38,7 +40,6 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 
 constexpr int kDwMaxJobs = 8;
 constexpr int kDwStageRows = 32;
-constexpr int kDwSlots = 4;                 // ring slots; kDwSlots - 1 stages in flight
 
 struct DwJob {
     const uint16_t* p;        // bf16 [rows][H] (HH, HX, HR) or [rows][8] (DH)
@@ -78,17 +79,35 @@ __device__ static inline bf16x8 mask_rows(bf16x8 f, int64_t first, int64_t rows)
     return __builtin_bit_cast(bf16x8, uint4{d[0], d[1], d[2], d[3]});
 }
 
+enum : int32_t { DW_HH = 0, DW_HX = 1, DW_DH = 2, DW_HR = 3 };
+
 template <int H>
 struct DwGeom {
     static constexpr int CG = H / 32;                 // 32-column groups per row of a wide panel
     static constexpr int ROWQ = CG * 256;             // bytes per 4-row group of a wide panel
     static constexpr int PANEL = 8 * ROWQ;            // 32 rows
     static constexpr int NPW = H / 128;               // 1-KiB DMA pieces per wave and wide panel
-    static constexpr int XOFF = 2 * PANEL;            // the 32 x 64 B input panel behind the two wide ones
-    static constexpr int SLOT = 2 * PANEL + 2048;
-    static constexpr int ZERO = kDwSlots * SLOT;      // 16 zero bytes
-    static constexpr int LDS_BYTES = ZERO + 16;
     static constexpr int MA = H / 128, NB = H / 64;   // HH: 32-row / 32-column output tiles per wave (4 x 2 waves)
+    static constexpr int LDS_BYTES = 160 * 1024;      // the whole CU: one workgroup per CU
+    static constexpr int ZERO = LDS_BYTES - 16;       // 16 zero bytes
+};
+
+// LDS ring of one job kind.  A CU's share of the HBM stream is (bytes it keeps in flight) / (latency under load, 2-3 us):
+// the narrow kinds (18 KB per stage) get deeper rings so that every kind keeps ~100 KB in flight.
+//   slot = [P panel][second operand]; HR keeps its recomputed Q tiles (2: the stage in use, the next one) behind the ring.
+template <int H, int KIND>
+struct DwRing {
+    using G = DwGeom<H>;
+    static constexpr int P_OFF = 0;
+    static constexpr int Q_OFF = (KIND == DW_DH) ? 1024 : G::PANEL;          // DH: the [32][8] panel takes 512 B
+    static constexpr int SLOT = (KIND == DW_HH) ? 2 * G::PANEL : (KIND == DW_DH ? G::PANEL + 1024 : G::PANEL + 2048);
+    static constexpr int QTILES = (KIND == DW_HR) ? 2 * G::PANEL : 0;
+    static constexpr int D_FIT = (G::ZERO - QTILES) / SLOT;
+    static constexpr int D = D_FIT > 8 ? 8 : D_FIT;                          // slots; D - 1 stages in flight
+    static constexpr int QT_OFF = D * SLOT;
+    static constexpr int NG = (KIND == DW_HH) ? 2 * G::NPW : G::NPW + 1;     // DMA instructions per wave and stage
+    static_assert(D >= 4 && QT_OFF + QTILES <= G::ZERO, "ring does not fit the LDS");
+    static_assert((D - 1) * NG <= 63, "vmcnt is a 6-bit counter");
 };
 
 // ---- LDS-DMA of one stage (every call issues the same number of instructions per wave) ----
@@ -119,29 +138,27 @@ __device__ static inline void dma_d8(const uint16_t* __restrict__ g, int64_t row
     }
 }
 
-enum : int32_t { DW_HH = 0, DW_HX = 1, DW_DH = 2, DW_HR = 3 };
-
 template <int H, int KIND>
 __device__ static inline void dw_issue(const DwJob& job, int64_t sg, int64_t rows, char* slot, int wave, int lane) {
-    using G = DwGeom<H>;
+    using R = DwRing<H, KIND>;
     const int64_t row0 = sg * kDwStageRows;
     if constexpr (KIND == DW_HH) {
-        dma_wide<H>(job.p, row0, rows, slot, wave, lane);
-        dma_wide<H>(job.q, row0, rows, slot + G::PANEL, wave, lane);
+        dma_wide<H>(job.p, row0, rows, slot + R::P_OFF, wave, lane);
+        dma_wide<H>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
     } else if constexpr (KIND == DW_HX || KIND == DW_HR) {
-        dma_wide<H>(job.p, row0, rows, slot, wave, lane);
-        dma_x(job.q, row0, rows, slot + G::XOFF, wave, lane);
+        dma_wide<H>(job.p, row0, rows, slot + R::P_OFF, wave, lane);
+        dma_x(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
     } else {
-        dma_d8(job.p, row0, rows, slot, lane);
-        dma_wide<H>(job.q, row0, rows, slot + G::PANEL, wave, lane);
+        dma_d8(job.p, row0, rows, slot + R::P_OFF, lane);
+        dma_wide<H>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
     }
 }
 
 template <int H, int KIND>
 __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows, float* __restrict__ ws, char* lds_c) {
     using G = DwGeom<H>;
-    constexpr int D = kDwSlots, P = D - 1;
-    constexpr int NG = (KIND == DW_HH) ? 2 * G::NPW : G::NPW + 1;     // DMA instructions per wave and stage
+    using R = DwRing<H, KIND>;
+    constexpr int D = R::D, P = D - 1, NG = R::NG;
     constexpr int MA = (KIND == DW_HH || KIND == DW_HR) ? G::MA : 1;
     constexpr int NB = (KIND == DW_HH || KIND == DW_HR) ? G::NB : 1;
     constexpr int NT = H / 32;                                        // 32-wide tiles across a wide operand
@@ -156,16 +173,19 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
     // lane part of a transposed fragment read: rows 8h + q (+4), columns 16 g1 + 4 p .. +3 of the tile's 32
     const int lane_wide = 2 * h * G::ROWQ + q4 * 64 + g1 * 32 + p4 * 8;
     const int lane_x = 2 * h * 256 + q4 * 64 + g1 * 32 + p4 * 8;
-    int offA, offB;                                                   // + slot base + k-step / tile immediates
-    if constexpr (KIND == DW_HH || KIND == DW_HR) {
-        offA = lane_wide + (MA * wm) * 256;
-        offB = G::PANEL + lane_wide + (NB * wn) * 256;
+    int offA, offB;                                                   // + slot (or Q tile) base + k-step / tile immediates
+    if constexpr (KIND == DW_HH) {
+        offA = R::P_OFF + lane_wide + (MA * wm) * 256;
+        offB = R::Q_OFF + lane_wide + (NB * wn) * 256;
+    } else if constexpr (KIND == DW_HR) {
+        offA = R::P_OFF + lane_wide + (MA * wm) * 256;
+        offB = lane_wide + (NB * wn) * 256;                           // relative to the stage's recomputed Q tile
     } else if constexpr (KIND == DW_HX) {
-        offA = lane_wide + (wave % NT) * 256;
-        offB = G::XOFF + lane_x;
+        offA = R::P_OFF + lane_wide + (wave % NT) * 256;
+        offB = R::Q_OFF + lane_x;
     } else {
-        offA = (8 * h + q4) * 16 + 8 * p4;                            // [32 rows][8 columns]: lanes g1 == 0, p < 2
-        offB = G::PANEL + lane_wide + (wave % NT) * 256;
+        offA = R::P_OFF + (8 * h + q4) * 16 + 8 * p4;                 // [32 rows][8 columns]: lanes g1 == 0, p < 2
+        offB = R::Q_OFF + lane_wide + (wave % NT) * 256;
     }
     const bool d8_valid = g1 == 0 && p4 < 2;
 
@@ -196,45 +216,60 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
     int slot_issue = 0;
 #pragma unroll 1
     for (int i = 0; i < P; ++i) {
-        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * G::SLOT, wave, lane);
+        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * R::SLOT, wave, lane);
         sg_issue += nb;
         slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+    }
+
+    // HR: a0 tile = relu(W0 . x^T + b0) for a stage's 32 rows (x panel of slot `sb`), written as the image of a Q panel into
+    // tile buffer `qt`.  It runs ONE stage ahead, beside the products of the current stage (the two are independent, so
+    // the recompute's dependent chain -- LDS read, 2 MFMAs, pack, LDS write -- hides behind them; no second barrier)
+    auto recompute_a0 = [&](const char* sb, char* qt) {
+        if (wave < NT) {
+            const int row = lane & 31;
+            f32x16 t = b0v;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + R::Q_OFF + row * 64 + 32 * ks + 16 * h));
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xb, t, 0, 0, 0);
+            }
+            const bf16x8 lo = relu_pack_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+            const bf16x8 hi = relu_pack_bf16(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
+            char* dst = qt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 32 * h;
+            lds_store16(dst, __builtin_bit_cast(uint4, lo));
+            lds_store16(dst + 16, __builtin_bit_cast(uint4, hi));
+        }
+    };
+    // stages that must have landed at the top of an iteration: the current one; HR also the next (its x panel is read)
+    constexpr int kWait = (KIND == DW_HR ? P - 2 : P - 1) * NG;
+    int parity = 0;                                                   // HR: Q tile of the current stage
+    if constexpr (KIND == DW_HR) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");      // the first stage
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        recompute_a0(lds_c, lds_c + R::QT_OFF);
     }
 
     int slot = 0;
 #pragma unroll 1
     for (int64_t sg = my; sg < n_st; sg += nb) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
+        if constexpr (KIND == DW_HR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's a0 writes are done
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWait) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * G::SLOT, wave, lane);
+        dw_issue<H, KIND>(job, sg_issue, rows, lds_c + slot_issue * R::SLOT, wave, lane);
         sg_issue += nb;
         slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
 
-        char* sb = lds_c + slot * G::SLOT;
+        const char* sb = lds_c + slot * R::SLOT;
         slot = slot + 1 == D ? 0 : slot + 1;
         const int64_t row0 = sg * kDwStageRows;
         const bool partial = row0 + kDwStageRows > rows;              // wave-uniform
-
+        const char* qb = sb;                                          // base of the B operand's panel
         if constexpr (KIND == DW_HR) {
-            // a0 tile = relu(W0 . x^T + b0) for the stage's 32 rows, into the Q panel's image
-            if (wave < NT) {
-                const int row = lane & 31;
-                f32x16 t = b0v;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + G::XOFF + row * 64 + 32 * ks + 16 * h));
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xb, t, 0, 0, 0);
-                }
-                const bf16x8 lo = relu_pack_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
-                const bf16x8 hi = relu_pack_bf16(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
-                char* dst = sb + G::PANEL + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 32 * h;
-                lds_store16(dst, __builtin_bit_cast(uint4, lo));
-                lds_store16(dst + 16, __builtin_bit_cast(uint4, hi));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            qb = lds_c + R::QT_OFF + parity * G::PANEL;
+            parity ^= 1;
+            if (sg + nb < n_st) recompute_a0(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);   // the next stage's tile
         }
 
         if (active) {
@@ -250,10 +285,10 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
                     for (int m = 0; m < MA; ++m) a[m] = tr_frag(sb, offA + 4 * ks * G::ROWQ + m * 256, offA + (4 * ks + 1) * G::ROWQ + m * 256);
                 }
                 if constexpr (KIND == DW_HX) {
-                    b[0] = tr_frag(sb, offB + 4 * ks * 256, offB + (4 * ks + 1) * 256);
+                    b[0] = tr_frag(qb, offB + 4 * ks * 256, offB + (4 * ks + 1) * 256);
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NB; ++n) b[n] = tr_frag(sb, offB + 4 * ks * G::ROWQ + n * 256, offB + (4 * ks + 1) * G::ROWQ + n * 256);
+                    for (int n = 0; n < NB; ++n) b[n] = tr_frag(qb, offB + 4 * ks * G::ROWQ + n * 256, offB + (4 * ks + 1) * G::ROWQ + n * 256);
                 }
                 if (partial) {
 #pragma unroll
@@ -362,26 +397,25 @@ __global__ __launch_bounds__(256) void dw_finish_all_kernel(DwFinishArgs fa) {
     d.grad[(int64_t)m * d.grad_ld + n] += (s0 + s1) + (s2 + s3);
 }
 
-static int dw_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        n = cus;
-    }
-    return n;
-}
+static int dw_cus() { return device_cus(); }
 
-static int64_t dw_bytes_per_row(int H, int kind) {
-    switch (kind) {
-        case DW_HH: return 4 * H;
-        case DW_HX: case DW_HR: return 2 * H + 64;
-        default: return 2 * H + 16;
+// Relative cost of a row of each job kind = its bytes, times a per-kind factor for the kinds that are not purely
+// byte-bound (HR recomputes a tile per stage).  The workgroups are split between the jobs in proportion to it.
+// TG_DW_COST="hh,hx,dh,hr" (percent of the byte count) overrides the factors: a tuning knob, read once.
+static int64_t dw_row_cost(int H, int kind) {
+    static int pct[4] = {0, 0, 0, 0};
+    if (pct[0] == 0) {
+        int v[4] = {100, 100, 100, 280};   // HR: measured optimum 270-300 (tools/dw_probe.py, 2^22 rows)
+        if (const char* e = getenv("TG_DW_COST")) (void)sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+        for (int k = 0; k < 4; ++k) pct[k] = v[k] > 0 ? v[k] : 100;
     }
+    int64_t bytes;
+    switch (kind) {
+        case DW_HH: bytes = 4 * H; break;
+        case DW_HX: case DW_HR: bytes = 2 * H + 64; break;
+        default: bytes = 2 * H + 16; break;
+    }
+    return bytes * pct[kind];
 }
 static int dw_slab_len(int H, int kind) {
     switch (kind) {
@@ -399,15 +433,8 @@ template <int H>
 static int launch_dw(const DwArgs& args, int grid, int64_t rows, float* ws, hipStream_t st) {
     auto kern = dw_kernel<H>;
     const size_t shmem = DwGeom<H>::LDS_BYTES;
-    static size_t attr_bytes = 0;
-    if (shmem > 64 * 1024 && shmem > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return set_error(TG_ERR_HIP, "tg_mlp_weight_grad: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
-        }
-        attr_bytes = shmem;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_weight_grad")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), shmem, st, args, rows, ws);
     TG_LAUNCH_CHECK("tg_mlp_weight_grad");
     return TG_OK;
@@ -440,7 +467,7 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
                    "tg_mlp_weight_grad: job %d: window %d x %d (ld %lld) outside %d x %d", j, jb.m_out, jb.n_out, (long long)jb.wgrad_ld, M, N);
         TG_REQUIRE(jb.kind != TG_DW_DH || !jb.d_bgrad, "tg_mlp_weight_grad: job %d: the head's bias gradient comes from tg_head_prep", j);
         TG_REQUIRE(jb.kind != TG_DW_HR || (d_w0frag && d_b0), "tg_mlp_weight_grad: job %d recomputes the first layer: weights / bias missing", j);
-        wsum += dw_bytes_per_row(H, jb.kind);
+        wsum += dw_row_cost(H, jb.kind);
     }
     // workgroups per job in proportion to its bytes per row (largest remainders), at least one, at most one per 4 stages
     const int64_t n_st = ceil_div(rows, (int64_t)kDwStageRows);
@@ -450,7 +477,7 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
     int64_t rem[kDwMaxJobs];
     int used = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        const int64_t w = dw_bytes_per_row(H, jobs[j].kind) * cus;
+        const int64_t w = dw_row_cost(H, jobs[j].kind) * cus;
         alloc[j] = (int)(w / wsum);
         rem[j] = w % wsum;
         if (alloc[j] < 1) { alloc[j] = 1; rem[j] = 0; }
@@ -496,6 +523,7 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
     fa.total = elems;
+    TG_REQUIRE(grid <= cus, "tg_mlp_weight_grad: %d workgroups for %d CUs (the workspace holds one slab per CU)", grid, cus);
     hipStream_t st = (hipStream_t)stream;
     int rc = hidden == 256 ? launch_dw<256>(args, grid, rows, (float*)d_workspace, st) : launch_dw<128>(args, grid, rows, (float*)d_workspace, st);
     if (rc != TG_OK) return rc;

@@ -132,7 +132,7 @@ __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
 
 // x [rows][32] bf16 (features >= in_dim zero); acts.p[l] [rows][H] bf16 for hidden layer l (kStore); out f32
 // [rows][out_cols], out_cols in {8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
-template <int H, int WPW, bool kStore, int D>
+template <int H, int WPW, bool kStore, int D, bool kA0>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                                     const float* __restrict__ bias, int32_t n_hh, int64_t rows,
                                                                     ChainActs acts, float* __restrict__ out, int32_t out_cols) {
@@ -145,6 +145,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     static_assert(P % 2 == 1 && P >= 3, "the store counts below are for a window of an odd number of blocks");
     constexpr int kWaitEven = (P - 1) * (KS / WPW) + (kStore ? 4 * ((P + 1) / 2) : 0);
     constexpr int kWaitOdd = (P - 1) * (KS / WPW) + (kStore ? 4 * ((P - 1) / 2) : 0);
+    // kA0 == false: the first hidden activation is not stored (tg_mlp_weight_grad recomputes it, kind HR), so the
+    // first-layer block has no stores behind it; the three sites whose window would count them wait for the DMAs alone
+    constexpr int kWaitMin = (P - 1) * (KS / WPW);
     static_assert(KS % WPW == 0, "every wave moves the same number of 1-KiB pieces per block");
     extern __shared__ uint4 lds[];
     uint4* ring = lds;                                                  // D * KS * 64 uint4
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                 for (int sh = 0; sh < 2; ++sh)
                     xout[2 * mt + sh] = relu_pack_bf16(acc[8 * sh], acc[8 * sh + 1], acc[8 * sh + 2], acc[8 * sh + 3], acc[8 * sh + 4],
                                                        acc[8 * sh + 5], acc[8 * sh + 6], acc[8 * sh + 7]);
-                if (kStore && (mt & 1))
+                if (kStore && kA0 && (mt & 1))
                     store_pair(stage, acts.p[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
                                xout[2 * mt + 1]);
             }
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                 // (the mask bits of this layer's INPUT, activation l: one word per tile for the first MT/2 tiles, after the
                 // barrier so that the arithmetic sits beside the tile's MFMAs)
                 if (mt & 1) {
-                    TG_CHAIN_ADVANCE(kWaitOdd)
+                    if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitOdd) }
+                    TG_RING_NEXT
                     if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
                     chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
                     // (with the mask store one more store sits behind this tile than the wait sites count: stricter, never weaker)
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                         store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1],
                                    xout[2 * mt], xout[2 * mt + 1]);
                 } else {
-                    TG_CHAIN_ADVANCE(kWaitEven)
+                    if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitEven) }
+                    TG_RING_NEXT
                     if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
                     chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
                 }
@@ -273,31 +278,16 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <int H, bool kStore, int D>
+template <int H, bool kStore, int D, bool kA0>
 static int chain_launch(const void* x, const void* wfrag, const float* bias, int n_hh, int64_t rows, const ChainActs& acts, float* out,
                         int out_cols, hipStream_t st) {
     constexpr int WPW = 8, KS = H / 16;
     const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048 +
                          (size_t)WPW * 32 * 128;
-    auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D>;
-    static size_t attr_bytes = 0;
-    if (shmem > 64 * 1024 && shmem > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return set_error(TG_ERR_HIP, "tg_mlp_forward_chain: cannot reserve %zu B of LDS (%s)", shmem, hipGetErrorString(e));
-        }
-        attr_bytes = shmem;
-    }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-    }
+    auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D, kA0>;
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_forward_chain")) return rc;
+    const int cus = device_cus();
     const int64_t n_rounds = ceil_div(rows, (int64_t)32 * WPW);
     const unsigned grid = (unsigned)(n_rounds < cus ? n_rounds : cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint16_t*)x, (const uint4*)wfrag, bias, n_hh, rows, acts, out,
@@ -324,7 +314,7 @@ int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bi
     ChainActs acts{};
     if (d_acts)
         for (int l = 0; l < n_hidden_layers; ++l) {
-            TG_REQUIRE(d_acts[l], "tg_mlp_forward_chain: activation buffer %d is null", l);
+            TG_REQUIRE(d_acts[l] || l == 0, "tg_mlp_forward_chain: activation buffer %d is null", l);
             acts.p[l] = (uint16_t*)d_acts[l];
             acts.m[l] = d_masks ? (uint32_t*)d_masks[l] : nullptr;
         }
@@ -333,8 +323,12 @@ int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bi
     const int n_hh = n_hidden_layers - 1;
 #define TG_CHAIN_ARGS d_x, d_wfrag, d_bias, n_hh, rows, acts, d_out, out_cols, st
     // ring of 4 slots, 3 blocks in flight (6 slots / 5 in flight measured the same: 2.94 vs 2.96 ms)
-    if (hidden == 256) return d_acts ? chain_launch<256, true, 4>(TG_CHAIN_ARGS) : chain_launch<256, false, 4>(TG_CHAIN_ARGS);
-    return d_acts ? chain_launch<128, true, 4>(TG_CHAIN_ARGS) : chain_launch<128, false, 4>(TG_CHAIN_ARGS);
+    const bool a0 = d_acts && d_acts[0];             // the first activation may be left out (recomputed by tg_mlp_weight_grad)
+    if (hidden == 256)
+        return !d_acts ? chain_launch<256, false, 4, true>(TG_CHAIN_ARGS)
+                       : (a0 ? chain_launch<256, true, 4, true>(TG_CHAIN_ARGS) : chain_launch<256, true, 4, false>(TG_CHAIN_ARGS));
+    return !d_acts ? chain_launch<128, false, 4, true>(TG_CHAIN_ARGS)
+                   : (a0 ? chain_launch<128, true, 4, true>(TG_CHAIN_ARGS) : chain_launch<128, true, 4, false>(TG_CHAIN_ARGS));
 #undef TG_CHAIN_ARGS
 }
 

@@ -48,6 +48,45 @@ __device__ static inline float rn_div(float a, float b) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Per-DEVICE launch state (one process may drive several GPUs): the device ordinal of the calling thread, its CU count,
+// and the opt-in to more than 64 KiB of dynamic LDS per kernel (gfx950 has 160 KiB per CU), cached per device.
+constexpr int kMaxDevices = 16;
+static inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        d = 0;
+    }
+    return (d < 0 || d >= kMaxDevices) ? 0 : d;
+}
+static inline int device_cus() {
+    static int n[kMaxDevices] = {};
+    const int d = current_device();
+    if (n[d] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        n[d] = cus;
+    }
+    return n[d];
+}
+struct LdsOptIn { size_t bytes[kMaxDevices] = {}; };
+static inline int reserve_dynamic_lds(const void* kernel, size_t bytes, LdsOptIn& cache, const char* what) {
+    if (bytes > 160 * 1024) return set_error(TG_ERR_ARG, "%s: %zu B of LDS needed (> 160 KiB)", what, bytes);
+    const int d = current_device();
+    if (bytes > 64 * 1024 && bytes > cache.bytes[d]) {
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(TG_ERR_HIP, "%s: cannot reserve %zu B of LDS (%s)", what, bytes, hipGetErrorString(e));
+        }
+        cache.bytes[d] = bytes;
+    }
+    return TG_OK;
+}
+
 // Swarm termination: lanes [k*agents, (k+1)*agents) of a wavefront are the bodies of one environment; the env
 // truncates when any of them does.  One 64-bit ballot, then each lane tests its own segment of the mask.
 __device__ static inline bool any_in_segment(bool flag, int agents) {

@@ -114,6 +114,9 @@ class GemmMLP:
                     self._dxfrag[i] = torch.empty(o * k, dtype=torch.bfloat16, device=dev)
         self._dx_partial = None
         self._head_partial = None
+        self._dw_ws = None
+        # like dx_events, for every tg_mlp_weight_grad launch
+        self.dw_events = None
         # when set to a list, every backward-data launch (tg_mlp_backward_chain or tg_dx_relu_bias) is bracketed by HIP
         # events on the launch stream and (start, end, rows, algorithmic bytes per row, kernel name) is appended
         # (bench.py reads them back for that kernel's roofline)
@@ -127,7 +130,6 @@ class GemmMLP:
             # ... and the backward-data pass as one launch too (tg_mlp_backward_chain): dZ stays on chip from the head down
             if H in (128, 256) and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 6:     # 6: the kernel's LDS budget
                 self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
-                self._bchain_partial = None
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
         self.refresh()
 
@@ -173,11 +175,15 @@ class GemmMLP:
         if self._chain is not None and xp.shape[0] > 0:
             self._fresh("chain")
             rows, H = xp.shape[0], self._chain.H
-            hid = [self._ws.get(f"a{i}", rows, H, self.cd, xp.device) for i in range(L - 1)] if keep else []
+            # with the backward chain active the first hidden activation is never read again: tg_mlp_weight_grad
+            # recomputes it from the input row (kind HR), so it is not written either (its mask bits still are)
+            skip_a0 = keep and self._bchain is not None and L - 1 >= 2
+            hid = [None if (i == 0 and skip_a0) else self._ws.get(f"a{i}", rows, H, self.cd, xp.device)
+                   for i in range(L - 1)] if keep else []
             # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
             bits = [self._ws.get(f"m{i}", rows, H // 32, torch.int32, xp.device) for i in range(L - 1)] if keep else []
             out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
-            ptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in hid]) if keep else None
+            ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid]) if keep else None
             mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
             N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
                                                   L - 1, rows, ptrs, mptrs, out.data_ptr(), self.out_pad,
@@ -254,15 +260,14 @@ class GemmMLP:
                 "tg_dw_finish")
 
     def _backward_chain(self, dz_head, acts, bits, rows, device):
-        """All hidden layers' dZ in one launch (tg_mlp_backward_chain), then the weight gradients layer by layer."""
+        """All hidden layers' dZ in one launch (tg_mlp_backward_chain), then every weight and hidden bias gradient in one
+        more (tg_mlp_weight_grad: each dZ and activation is read once; the bias sums ride in the same contraction)."""
         lib = N.load()
         self._fresh("bchain")
         L = len(self.linears)
         nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
         H = self._bchain.H
         dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) for j in range(nh)]
-        if self._bchain_partial is None:
-            self._bchain_partial = torch.empty(lib.tg_mlp_backward_chain_blocks(), nh, H, dtype=torch.float32, device=device)
         dz_ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
         m_ptrs = (N.C.c_void_p * nh)(*[bits[L - 1 - j].data_ptr() for j in range(nh)])     # bits[i + 1] masks hidden layer i
         ev = None
@@ -270,14 +275,30 @@ class GemmMLP:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         N.check(lib.tg_mlp_backward_chain(dz_head.data_ptr(), self._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
-                                          self._bchain_partial.data_ptr(), N.stream_ptr(device)), "tg_mlp_backward_chain")
+                                          None, N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8>"))
-        self._bias_into([self.linears[L - 2 - j].bias.grad for j in range(nh)], self._bchain_partial)   # chain order: top first
-        for j in range(nh):
-            i = L - 2 - j
-            self._dw_into(self.linears[i].weight.grad, dzs[j], acts[i])
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8,false>"))
+        if self._dw_ws is None:
+            self._dw_ws = weight_grad_workspace(H, device)
+        lin = self.linears
+        jobs = [(N.TG_DW_DH, dz_head, acts[L - 1], lin[L - 1].weight.grad, None)]             # head (bias: tg_head_prep)
+        for j in range(nh - 1):
+            i = L - 2 - j                                                                      # hidden-to-hidden layer i
+            if acts[i] is None:                                                                # i == 1: input not stored
+                jobs.append((N.TG_DW_HR, dzs[j], acts[0], lin[i].weight.grad, lin[i].bias.grad))
+            else:
+                jobs.append((N.TG_DW_HH, dzs[j], acts[i], lin[i].weight.grad, lin[i].bias.grad))
+        jobs.append((N.TG_DW_HX, dzs[nh - 1], acts[0], lin[0].weight.grad, lin[0].bias.grad))
+        ev = None
+        if self.dw_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0])
+        if ev is not None:
+            ev[1].record()
+            per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16}[jb[0]] for jb in jobs)
+            self.dw_events.append((ev[0], ev[1], rows, per_row, f"tg::dw_kernel<{H}>"))
         self._acts = self._bits = None
 
     @torch.no_grad()
@@ -304,10 +325,13 @@ class GemmMLP:
             dz.zero_()
             dz[:, :self.out_dim].copy_(dout)
             lin.bias.grad.add_(dout.sum(0))
-        self._dw_into(lin.weight.grad, dz, acts[L - 1])
-        if self._bchain is not None and self._bits is not None:
+        if (self._bchain is not None and self._bits is not None and all(l.weight.grad.dtype == torch.float32 and
+                                                                        l.weight.grad.stride(1) == 1 and l.bias.grad.is_contiguous()
+                                                                        for l in self.linears)):
             self._backward_chain(dz, acts, bits, rows, dout.device)
             return
+        assert all(a is not None for a in acts), "forward() left out the first activation: the backward chain must run"
+        self._dw_into(lin.weight.grad, dz, acts[L - 1])
         self._fresh("dx")
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0
         nblk = lib.tg_relu_bwd_bias_blocks()
