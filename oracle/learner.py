@@ -321,8 +321,11 @@ def ppo_loss(policy, obs, act, adv, ret, old_lp, *, epsilon, c1, kl_coeff, entro
 
 
 def ppo_learn(policy, optimizer, obs, act, rew, masks, *, epsilon, gamma, lam=0.95, c1=0.5,
-              kl_coeff=0.5, entropy_coeff=0.01, updates_per_iter=1, monte_carlo=True):
-    """algorithms/ppo.py:64-186 with batch_size=None (full batch, every shipped factory)."""
+              kl_coeff=0.5, entropy_coeff=0.01, updates_per_iter=1, monte_carlo=True, batch_size=None,
+              permutations=None):
+    """algorithms/ppo.py:64-186.  batch_size=None: one full-batch step per update (every shipped factory);
+    otherwise the valid rows are permuted once per update and walked in steps of batch_size (:147-157).
+    `permutations` (one index vector per update) replaces torch.randperm (fixtures carry the reference's draws)."""
     S, A = obs.shape[-1], act.shape[-1]
     with torch.no_grad():
         values = policy.value(obs.reshape(-1, S)).reshape(rew.shape)
@@ -333,12 +336,19 @@ def ppo_learn(policy, optimizer, obs, act, rew, masks, *, epsilon, gamma, lam=0.
     with torch.no_grad():
         old_lp, _ = policy.log_prob(o, a)                     # ppo.py:142-143 (current policy)
     logs = []
-    for _ in range(updates_per_iter):
-        total, parts = ppo_loss(policy, o, a, adv, ret, old_lp, epsilon=epsilon, c1=c1,
-                                kl_coeff=kl_coeff, entropy_coeff=entropy_coeff)
-        optimizer.zero_grad()
-        total.backward()
-        optimizer.step()
-        parts["total"] = float(total.detach())
-        logs.append(parts)
+    n = o.shape[0]
+    for u in range(updates_per_iter):
+        if batch_size is None:
+            batches = [slice(None)]
+        else:
+            perm = torch.randperm(n) if permutations is None else torch.as_tensor(permutations[u], dtype=torch.long)
+            batches = [perm[lo:lo + batch_size] for lo in range(0, n, batch_size)]
+        for b in batches:
+            total, parts = ppo_loss(policy, o[b], a[b], adv[b], ret[b], old_lp[b], epsilon=epsilon, c1=c1,
+                                    kl_coeff=kl_coeff, entropy_coeff=entropy_coeff)
+            optimizer.zero_grad()
+            total.backward()
+            optimizer.step()
+            parts["total"] = float(total.detach())
+            logs.append(parts)
     return logs

@@ -495,6 +495,127 @@ def gen_pendulum():
     np.savez_compressed(os.path.join(OUT, "rollout_pendulum.npz"), **out)
 
 
+
+# ---------------------------------------------------------------------------
+# 5. learn() at the shapes the chain kernels run (256 x 5, 128 x 4), minibatch PPO, trajectory export
+# ---------------------------------------------------------------------------
+def _sample(t, cap=2048):
+    """Every stride-th element of a tensor (at most `cap` values): big nets are pinned by samples + whole-tensor sums,
+    not by megabytes of weights.  The test rebuilds the initial weights from `seed` (the reference's constructors
+    draw them from torch's CPU generator) and checks them against the same samples."""
+    flat = t.detach().reshape(-1)
+    stride = max(1, -(-flat.numel() // cap))
+    return flat[::stride].numpy().copy(), stride
+
+
+def _pin(out, prefix, named):
+    for k, t in named:
+        smp, stride = _sample(t)
+        out[f"{prefix}.{k}"] = smp
+        out[f"{prefix}_stride.{k}"] = stride
+        out[f"{prefix}_sum.{k}"] = float(t.detach().double().sum())
+        out[f"{prefix}_l2.{k}"] = float(t.detach().double().norm())
+
+
+def gen_chain_shape_steps():
+    cfgs = [("ppo", "h256", 20, 4, (256,) * 5, 0.3, 0.999, 3e-4, 400), ("grpo", "h256", 20, 4, (256,) * 5, 0.3, 0.5, 3e-4, 401),
+            ("ppo", "h128", 5, 1, (128,) * 4, 0.5, 0.99, 2e-4, 402), ("grpo", "h128", 5, 1, (128,) * 4, 0.5, 0.5, 3e-4, 403)]
+    for kind, tag, S, A, hidden, cov, gamma, lr, seed in cfgs:
+        G, Eps, T = 8, 16, 64                                   # ~4,200 valid rows
+        buf = ragged_buffer(np.random.default_rng(seed), G, Eps, T, S, A)
+        torch.manual_seed(seed)
+        if kind == "ppo":
+            pol = GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=cov)
+            nets = ("actor", "critic")
+        else:
+            pol = GaussianActor_NeuralNetwork(S, A, hidden, cov=cov)
+            nets = ("actor",)
+        named = lambda: [(f"{n}.{k}", p) for n in nets for k, p in getattr(pol, n).named_parameters()]
+        out = dict(obs=buf.group_observations.numpy(), act=buf.group_actions.numpy(), rew=buf.group_rewards.numpy(),
+                   mask=buf.group_masks.numpy(), seed=seed, lr=lr, gamma=gamma, cov=cov, updates_per_iter=2,
+                   hidden=np.array(hidden), n_valid=int(buf.group_masks.sum()))
+        _pin(out, "init", named())
+        init = {k: p.detach().clone() for k, p in named()}
+        opt = torch.optim.Adam(pol.parameters(), lr=lr)
+        sink = []
+        if kind == "ppo":
+            algo = PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=0.5, kl_coeff=0.5,
+                       gamma=gamma, lam=0.95, entropy=0.01, batch_size=None)
+            hook_frame_locals(opt, "zero_grad", ["total_loss", "actor_loss", "critic_loss", "kl_div"], sink)
+        else:
+            algo = GRPO(epsilon=0.15, beta=0.5, gamma=gamma, policy=pol, optimizer=opt, updates_per_iter=2)
+            with torch.no_grad():                               # old_policy != policy: the ratio is not identically 1
+                g = torch.Generator().manual_seed(seed)
+                for p_ in algo.old_policy.parameters():
+                    p_.add_(0.01 * torch.randn(p_.shape, generator=g))
+            out["old_policy_perturbation"] = 0.01
+            hook_frame_locals(opt, "zero_grad", ["J"], sink)
+        algo.learn(buf)
+        for name in sink[0]:
+            out[name] = np.array([float(r[name]) for r in sink])
+        _pin(out, "final", named())
+        _pin(out, "delta", [(k, p.detach() - init[k]) for k, p in named()])
+        _pin(out, "lastgrad", [(k, p.grad) for k, p in named()])
+        np.savez_compressed(os.path.join(OUT, f"{kind}_step_{tag}.npz"), **out)
+        print(kind, tag, "rows", out["n_valid"], {n: out[n] for n in sink[0]})
+
+
+def gen_ppo_minibatch():
+    """PPO with batch_size = 64 (algorithms/ppo.py:147-157): the permutations torch.randperm returned are recorded as
+    data (indices into the reference's valid rows, (g, e, t) order)."""
+    G, Eps, T, S, A = 3, 4, 16, 10, 2
+    buf = ragged_buffer(np.random.default_rng(500), G, Eps, T, S, A)
+    torch.manual_seed(24)
+    pol = GaussianActorCritic_NeuralNetwork(S, A, (32, 32), cov=0.5)
+    init = sd_to_np(pol.state_dict())
+    opt = torch.optim.Adam(pol.parameters(), lr=2e-4)
+    ppo = PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=0.5, kl_coeff=0.5, gamma=0.99,
+              lam=0.95, entropy=0.01, batch_size=64)
+    perms, sink = [], []
+    orig = torch.randperm
+
+    def recording_randperm(n, *a, **k):
+        p_ = orig(n, *a, **k)
+        perms.append(p_.numpy().copy())
+        return p_
+
+    torch.randperm = recording_randperm
+    try:
+        hook_frame_locals(opt, "zero_grad", ["total_loss", "actor_loss", "critic_loss", "kl_div"], sink)
+        ppo.learn(buf)
+    finally:
+        torch.randperm = orig
+    out = dict(obs=buf.group_observations.numpy(), act=buf.group_actions.numpy(), rew=buf.group_rewards.numpy(),
+               mask=buf.group_masks.numpy(), lr=2e-4, epsilon=0.2, gamma=0.99, cov=0.5, c1=0.5, kl_coeff=0.5, entropy_coeff=0.01,
+               batch_size=64, updates_per_iter=2, permutations=np.stack(perms))
+    for name in ("total_loss", "actor_loss", "critic_loss", "kl_div"):
+        out[name] = np.array([float(r[name]) for r in sink])
+    for k, v in init.items():
+        out[f"init.{k}"] = v
+    for k, v in sd_to_np(pol.state_dict()).items():
+        out[f"final.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "ppo_minibatch.npz"), **out)
+    print("PPO minibatch: steps", len(sink), "perms", len(perms), "total", out["total_loss"])
+
+
+def gen_trajectory_csv():
+    """Rollout_Buffer.save_trajectory (buffers/rollout_buffer.py:72-102) on the golden CartPole rollout: the CSV the
+    reference writes is the fixture (data: episode ids, observations, actions)."""
+    import tempfile
+    from buffers import Rollout_Buffer
+    g = np.load(os.path.join(OUT, "rollout_cartpole.npz"))
+    buf = Rollout_Buffer.__new__(Rollout_Buffer)
+    buf.avg_reward = []
+    buf.store(torch.from_numpy(g["reset_obs"]), torch.from_numpy(g["reset_act"]), torch.from_numpy(g["reset_rew"]),
+              torch.from_numpy(g["reset_len"]), torch.from_numpy(g["reset_mask"]))
+    with tempfile.TemporaryDirectory() as d:
+        buf.save_trajectory(d)
+        text = open(os.path.join(d, "trajectory.csv")).read()
+    with open(os.path.join(OUT, "trajectory_cartpole_reset.csv"), "w") as f:
+        f.write(text)
+    print("trajectory.csv:", text.count("\n"), "lines")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20250613)
@@ -504,6 +625,9 @@ def main():
     gen_learner(rng)
     gen_ppo_gae_step()
     gen_pendulum()
+    gen_chain_shape_steps()
+    gen_ppo_minibatch()
+    gen_trajectory_csv()
     print("fixtures written to", OUT)
 
 

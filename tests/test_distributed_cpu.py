@@ -153,3 +153,78 @@ def test_shard_groups_and_bucket_single_process():
     b.allreduce()                            # world 1: no-op
     m, s = D.unbiased_moments(4.0, 10.0, 30.0)
     assert m == 2.5 and s == pytest.approx(np.std([1, 2, 3, 4], ddof=1))
+
+
+def _minibatch_worker(rank, world, port, out):
+    """Minibatch PPO's schedule (algorithms/ppo.py:147-157) with UNEQUAL numbers of valid rows per rank: every rank must
+    take the same number of optimizer steps (each one is a gradient all-reduce), the rank that runs out of rows joins
+    the remaining ones with an empty slice, and each step's gradient must equal the single-process mean over the union
+    of the ranks' slices."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        S, A = 5, 2
+        m_local = (11, 3)[rank]                                  # rank 1 runs out after 2 of 6 steps
+        g = torch.Generator().manual_seed(10 + rank)
+        o = torch.randn(m_local, S, generator=g)
+        a = torch.randn(m_local, A, generator=g) * 0.5
+        adv, ret = torch.randn(m_local, generator=g), torch.randn(m_local, generator=g)
+        torch.manual_seed(1)
+        pol = L.OraclePolicy(S, A, (16, 16), cov=0.4, critic=True)
+        with torch.no_grad():
+            old_lp, _ = pol.log_prob(o, a)
+            old_lp = old_lp + 0.05 * torch.sin(torch.arange(m_local, dtype=torch.float32) + rank)
+        perm = torch.randperm(m_local, generator=g)
+        local_bs, n_steps, sizes = D.minibatch_schedule(m_local, 4, None, None)
+        assert (local_bs, n_steps, sizes) == (2, 6, [4, 3, 2, 2, 2, 1])
+        bucket = D.GradBucket(pol.parameters())
+        grads, slices = [], []
+        for k in range(n_steps):
+            b = perm[k * local_bs:(k + 1) * local_bs]
+            bucket.zero_()
+            if b.numel():
+                lp, _ = pol.log_prob(o[b], a[b])
+                ratio = torch.exp(lp - old_lp[b])
+                total = (-torch.min(ratio * adv[b], torch.clamp(ratio, 0.8, 1.2) * adv[b]).sum()
+                         + 0.5 * ((pol.value(o[b]) - ret[b]) ** 2).sum()
+                         + 0.5 * (torch.exp(old_lp[b]) * (old_lp[b] - lp)).sum()) / sizes[k]
+                total.backward()
+            bucket.allreduce()                                   # EVERY rank, EVERY step (a missing one would hang)
+            grads.append(bucket.flat.clone().numpy())
+            slices.append(b.numpy())
+        out[rank] = dict(grads=grads, slices=slices, o=o.numpy(), a=a.numpy(), adv=adv.numpy(), ret=ret.numpy(),
+                         old_lp=old_lp.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_minibatch_schedule_with_unequal_shards():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_minibatch_worker, args=(2, port, out), nprocs=2, join=True)
+        res = {k: out[k] for k in (0, 1)}
+    torch.set_num_threads(1)
+    torch.manual_seed(1)
+    pol = L.OraclePolicy(5, 2, (16, 16), cov=0.4, critic=True)
+    seen = [np.concatenate(res[r]["slices"]) for r in (0, 1)]
+    assert sorted(seen[0].tolist()) == list(range(11)) and sorted(seen[1].tolist()) == list(range(3))   # every row once
+    for k in range(6):
+        np.testing.assert_array_equal(res[0]["grads"][k], res[1]["grads"][k])
+        # single process: the union of both ranks' slices as one minibatch, mean losses (ppo.py:165-179)
+        parts = [{n: torch.from_numpy(res[r][n][res[r]["slices"][k]]) for n in ("o", "a", "adv", "ret", "old_lp")} for r in (0, 1)]
+        cat = {n: torch.cat([p[n] for p in parts]) for n in parts[0]}
+        for p in pol.parameters():
+            p.grad = None
+        lp, _ = pol.log_prob(cat["o"], cat["a"])
+        ratio = torch.exp(lp - cat["old_lp"])
+        total = (-torch.min(ratio * cat["adv"], torch.clamp(ratio, 0.8, 1.2) * cat["adv"]).mean()
+                 + 0.5 * ((pol.value(cat["o"]) - cat["ret"]) ** 2).mean()
+                 + 0.5 * (torch.exp(cat["old_lp"]) * (cat["old_lp"] - lp)).mean())
+        total.backward()
+        flat = torch.cat([p.grad.reshape(-1) for p in pol.parameters()])
+        np.testing.assert_allclose(res[0]["grads"][k], flat.numpy(), rtol=2e-4, atol=2e-6)
+    # world size 1: the reference's own walk over the permutation
+    assert D.minibatch_schedule(10, 4) == (4, 3, [4, 4, 2]) and D.minibatch_schedule(0, 64) == (64, 0, [])

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import check_pinned, load_golden
 from oracle import envs as E
 from oracle import learner as L
 
@@ -882,7 +882,7 @@ def test_fused_rollout_matches_unfused_path(tg, dev, name, hidden):
     # (3) invariants
     m = fm.bool()
     assert torch.equal(fm.sum(0, dtype=torch.int32), fl) and tf.env_steps() == int(fm.sum())
-    assert torch.all(fr[~m] == 0) and torch.all(fa[:, ~m] == 0) and torch.all(fo[:, 1:][:, ~m[: T]][..., :] == 0) or True
+    assert torch.all(fr[~m] == 0) and torch.all(fa[:, ~m] == 0)
     assert torch.all(fo[:, :T][:, ~m] == 0)
     eps = (fa[:, 0, :] - tp.act[:, 0, :])                                       # noise cancels: pure mean difference
     assert float(eps.abs().max()) < 0.05
@@ -1314,3 +1314,208 @@ def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, laye
     ref = dz.double().t() @ a0.double()
     assert float((w_a.double() - ref).abs().max()) < 2e-5 * (float(ref.abs().max()) + 1.0) * max(1.0, (rows / 1000) ** 0.5)
     assert torch.equal(w_a, w_b) and torch.equal(b_a, b_b)
+
+
+# --------------------------------------------------------------------------------------------
+# learn() at the shapes the hot learner kernels run, minibatch PPO, the configs' shard sizes
+# --------------------------------------------------------------------------------------------
+def _seeded_policy(tg, dev, g, kind, S, A):
+    """The fixture's initial weights rebuilt from its seed (the constructors draw them from torch's CPU generator in the
+    reference's order), checked against the fixture's samples, then moved to the GPU."""
+    hidden = tuple(int(h) for h in g["hidden"])
+    torch.manual_seed(int(g["seed"]))
+    cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
+    pol = cls(S, A, hidden, cov=float(g["cov"]), device="cpu")
+    nets = ("actor", "critic") if kind == "ppo" else ("actor",)
+    named = lambda: [(f"{n}.{k}", p) for n in nets for k, p in getattr(pol, n).named_parameters()]
+    check_pinned(g, "init", named(), atol=0.0, sum_rtol=1e-9)
+    return pol.to(dev), named
+
+
+@pytest.mark.parametrize("cdt", [None, torch.bfloat16])
+@pytest.mark.parametrize("kind,tag,S,A", [("ppo", "h256", 20, 4), ("grpo", "h256", 20, 4), ("ppo", "h128", 5, 1), ("grpo", "h128", 5, 1)])
+def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A, cdt):
+    """PPO.learn / GRPO.learn at 20-256x5 and 5-128x4 on ~4,000 rows, 2 updates, against the reference's loss scalars,
+    last gradients and post-step weights (pipelines/quadpole_pipeline_ppo.py:55-58, algorithms/grpo.py:106-148).
+    fp32 (per-layer GemmMLP path): weights <= 1e-5 (<= 0.5 % Adam-amplified outliers), like the oracle itself.
+    bf16 (tg_mlp_forward_chain / tg_mlp_backward_chain / tg_mlp_weight_grad): bf16 operands carry 2^-9 relative rounding per
+    product, so the tolerance is on norms: losses within 2e-3, every gradient tensor within 5 % in L2, the weight update of
+    every tensor within 35 % in L2 of the reference's (Adam turns a sign flip of a noise-level gradient entry into a full
+    +-lr step, so an element-wise bound is not meaningful at bf16)."""
+    g = load_golden(f"{kind}_step_{tag}.npz")
+    pol, named = _seeded_policy(tg, dev, g, kind, S, A)
+    init = {k: p.detach().clone() for k, p in named()}
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    if kind == "ppo":
+        algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=0.5, kl_coeff=0.5,
+                      gamma=float(g["gamma"]), lam=0.95, entropy=0.01, batch_size=None, autocast_dtype=cdt)
+    else:
+        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=float(g["gamma"]), policy=pol, optimizer=opt, updates_per_iter=2,
+                       autocast_dtype=cdt)
+        gen = torch.Generator().manual_seed(int(g["seed"]))
+        with torch.no_grad():
+            for p_ in algo.old_policy.parameters():
+                p_.add_((float(g["old_policy_perturbation"]) * torch.randn(p_.shape, generator=gen)).to(dev))
+    algo.learn(_buffer_from_golden(g))
+    if cdt is not None:                                           # the chain kernels really ran
+        m = algo._mlp(pol.actor)
+        assert m._chain is not None and m._bchain is not None and m._dw_ws is not None
+    st = algo.last_stats
+    assert st["n_valid"] == int(g["n_valid"])
+    lt, gt = (2e-5, 1e-3) if cdt is None else (2e-3, 5e-2)
+    if kind == "ppo":
+        np.testing.assert_allclose(st["total_loss"], g["total_loss"], rtol=lt, atol=lt)
+        np.testing.assert_allclose(st["critic_loss"], g["critic_loss"], rtol=lt, atol=lt)
+    else:
+        np.testing.assert_allclose(st["J"], g["J"], rtol=10 * lt, atol=10 * lt)
+    check_pinned(g, "lastgrad", [(k, p.grad) for k, p in named()], norm_rel=gt, atol=1e-7)
+    if cdt is None:
+        check_pinned(g, "final", named(), atol=1e-5, outlier_frac=0.005, outlier_atol=4 * float(g["lr"]), sum_rtol=1e-3)
+    else:
+        check_pinned(g, "delta", [(k, p.detach() - init[k]) for k, p in named()], norm_rel=0.35, atol=1e-7)
+
+
+def test_ppo_minibatch_learn_matches_reference(tg, dev):
+    """Minibatch PPO (algorithms/ppo.py:147-157) with the reference's own torch.randperm draws fed back as data.  The
+    reference indexes its valid rows in (g, e, t) order, the device trajectory in (t, n) order: the recorded indices are
+    mapped through the mask."""
+    g = load_golden("ppo_minibatch.npz")
+    pol = tg.GaussianActorCritic_NeuralNetwork(10, 2, (32, 32), cov=float(g["cov"]), device=dev)
+    sd = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    pol.load_state_dict({"actor": {k[6:]: v for k, v in sd.items() if k.startswith("actor.")},
+                         "critic": {k[7:]: v for k, v in sd.items() if k.startswith("critic.")}})
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    algo = tg.PPO(epsilon=float(g["epsilon"]), policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=float(g["c1"]),
+                  kl_coeff=float(g["kl_coeff"]), gamma=float(g["gamma"]), lam=0.95, entropy=float(g["entropy_coeff"]),
+                  batch_size=int(g["batch_size"]))
+    mask = torch.from_numpy(g["mask"]).bool()                    # (G, E, T)
+    G, E, T = mask.shape
+    ref_pos = torch.full((G * E, T), -1, dtype=torch.long)
+    ref_pos[mask.reshape(G * E, T)] = torch.arange(int(mask.sum()))           # reference: env-major, time-minor
+    ours = torch.full((int(mask.sum()),), -1, dtype=torch.long)
+    tm = mask.reshape(G * E, T).t()                                           # device trajectory: time-major
+    ours[ref_pos.t()[tm]] = torch.arange(int(mask.sum()))
+    perms = iter([ours[torch.from_numpy(p)] for p in g["permutations"]])
+    algo.permutation_fn = lambda n, device: next(perms).to(device)
+    algo.learn(_buffer_from_golden(g))
+    st = algo.last_stats
+    assert len(st["total_loss"]) == len(g["total_loss"]) == 4
+    np.testing.assert_allclose(st["total_loss"], g["total_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(st["critic_loss"], g["critic_loss"], rtol=2e-5, atol=2e-6)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-5)
+
+
+def test_lazy_reference_view_copies_only_what_a_visualiser_reads(tg, dev):
+    """with `limit_reference_view(max_episodes=k)` the group_* attributes are (G, k, T, .) slices cut on the
+    device (visualize/dashboard.py:206-217 reads group_observations[i, ep < k, frame]); retrieve() / save_trajectory()
+    still see everything."""
+    T, G, Eps = 24, 3, 16
+    torch.manual_seed(12)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (32, 32), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=T), pol, num_workers=G, num_episodes_per_worker=Eps, seed=3)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    full = [t.clone() for t in buf.retrieve()]
+    buf.sample()                                                     # a new rollout drops the cached view
+    buf.limit_reference_view(max_episodes=4)
+    full = buf.device_traj.to_reference()
+    assert buf.group_observations.shape == (G, 4, T, 5) and buf.group_lengths.shape == (G, 4)
+    for name, ref in zip(tg.Rollout_Buffer._REF_FIELDS, full):
+        assert torch.equal(getattr(buf, name), ref[:, :4])
+    assert all(torch.equal(a, b) for a, b in zip(buf.retrieve(), full))
+    assert buf.group_observations.shape == (G, Eps, T, 5)            # the full copy, once made, serves everyone
+    sub = buf.device_traj.to_reference(max_groups=2, max_episodes=3)
+    assert sub[0].shape == (2, 3, T, 5) and torch.equal(sub[2], full[2][:2, :3])
+
+
+CONFIG_SHARDS = [
+    # C4: QuadPole GRPO, 262,144 envs over 8 GPUs -> one rank: 128 restart groups x 256 episodes, bf16 (BASELINE configs[3])
+    ("C4", "QuadPole", 1, 128, 256, True),
+    # C5: swarm, 32,768 envs x 8 agents over 8 GPUs -> one rank: 4,096 envs x 8 bodies = 64 groups x 64 episodes x 8 (configs[4])
+    ("C5", "QuadPoleSwarm", 8, 64, 64, True),
+]
+
+
+@pytest.mark.parametrize("cfg,env_name,agents,G,Eps,restart", CONFIG_SHARDS)
+def test_grpo_configs_at_their_per_gpu_shard_size(tg, dev, cfg, env_name, agents, G, Eps, restart):
+    """BASELINE.json configs[3] / configs[4] at ONE rank's shard size, end to end (rollout + GRPO.learn, bf16 policy):
+    restart groups share their initial state, masks are prefixes of len, padding is zero, the group-relative advantages
+    have zero mean / unit (unbiased) std per group over the valid steps, learn() is finite, moves the weights and is
+    bit-reproducible from the same seeds."""
+    T = 256
+    mk = (lambda: tg.QuadPoleSwarm(n_agents=agents, max_steps=T)) if agents > 1 else (lambda: tg.QuadPole(max_steps=T))
+
+    def run():
+        torch.manual_seed(13)
+        pol = tg.GaussianActor_NeuralNetwork(20, 4, (256,) * 5, cov=0.3, device=dev)
+        mgr = tg.RolloutManager(mk, pol, restart=restart, num_workers=G, num_episodes_per_worker=Eps, seed=41,
+                                compute_dtype=torch.bfloat16)
+        assert mgr.engine.fused
+        buf = tg.Rollout_Buffer(mgr)
+        buf.sample()
+        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.99, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4),
+                       updates_per_iter=2, autocast_dtype=torch.bfloat16)
+        algo.learn(buf)
+        torch.cuda.synchronize()
+        return pol, buf, algo
+
+    pol, buf, algo = run()
+    tr = buf.device_traj
+    n = G * Eps * agents
+    assert tr.n == n and tr.G == G and tr.E == Eps * agents and tr.T == T
+    ln, mask = tr.len, tr.mask
+    assert torch.equal(mask, (torch.arange(T, device=dev)[:, None] < ln[None, :]).to(torch.uint8))
+    assert int(ln.min()) >= 1 and int(ln.max()) <= T and tr.env_steps() == int(ln.sum()) == int(mask.sum())
+    m = mask.bool()
+    assert torch.all(tr.rew[~m] == 0) and torch.all(tr.act[:, ~m] == 0) and torch.all(tr.obs[:, :T][:, ~m] == 0)
+    first = tr.obs[:, 0, :].t().reshape(G, Eps * agents, 20)
+    if agents == 1:
+        assert torch.equal(first, first[:, :1].expand_as(first))                 # restart: one initial state per group
+    else:
+        per_env = ln.view(-1, agents)
+        assert torch.equal(per_env, per_env[:, :1].expand_as(per_env))           # the bodies of an env stop together
+    rtg = tg.hip_ops.rtg_scan(tr.rew, tr.mask, 0.99)
+    adv = tg.hip_ops.group_normalize(rtg, tr.mask, tg.hip_ops.masked_moments(rtg, tr.mask, tr.E), 0, tr.E)
+    a, mm = adv.t().reshape(G, -1), mask.t().reshape(G, -1).bool()
+    for gi in range(0, G, max(1, G // 8)):
+        v = a[gi][mm[gi]].double()
+        assert abs(float(v.mean())) < 1e-3 and abs(float(v.std()) - 1) < 1e-3
+    assert np.isfinite(algo.last_stats["J"]).all() and algo.last_stats["n_valid"] == tr.env_steps()
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    pol2, buf2, algo2 = run()
+    assert torch.equal(buf2.device_traj.obs, tr.obs) and algo2.last_stats["J"] == algo.last_stats["J"]
+    for p, q in zip(pol.parameters(), pol2.parameters()):
+        assert torch.equal(p, q)
+
+
+def test_ppo_learn_at_c3_size_is_finite_and_deterministic(tg, dev):
+    """BASELINE configs[2] at full size: 65,536 QuadPole envs x 256 steps, bf16 actor-critic 20-256x5-{4,1}, PPO.learn
+    (4 updates here; the factory's 32 repeat the same step): finite losses and weights, n_valid = sum of the mask,
+    bit-identical weights and statistics from two runs with the same seeds."""
+    T, G, Eps = 256, 256, 256
+
+    def run():
+        torch.manual_seed(14)
+        pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, (256,) * 5, cov=0.3, device=dev)
+        mgr = tg.RolloutManager(lambda: tg.QuadPole(max_steps=T), pol, num_workers=G, num_episodes_per_worker=Eps, seed=51,
+                                compute_dtype=torch.bfloat16)
+        buf = tg.Rollout_Buffer(mgr)
+        buf.sample()
+        algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), ref_model=None,
+                      updates_per_iter=4, gamma=0.999, batch_size=None, autocast_dtype=torch.bfloat16)
+        algo.learn(buf)
+        torch.cuda.synchronize()
+        return pol, buf, algo
+
+    pol, buf, algo = run()
+    st = algo.last_stats
+    assert st["n_valid"] == float(buf.device_traj.mask.sum()) == buf.device_traj.env_steps()
+    assert np.isfinite(st["total_loss"]).all() and np.isfinite(st["critic_loss"]).all() and len(st["total_loss"]) == 4
+    assert abs(st["actor_loss"][0]) < 1e-3 and st["kl_div"][0] == 0.0             # first pass: ratio == 1 (ppo.py:142-143)
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    pol2, buf2, algo2 = run()
+    assert algo2.last_stats["total_loss"] == st["total_loss"]
+    for p, q in zip(pol.parameters(), pol2.parameters()):
+        assert torch.equal(p, q)

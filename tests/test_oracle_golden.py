@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import check_pinned, load_golden
 from oracle import envs as E
 from oracle import learner as L
 
@@ -185,6 +185,55 @@ def test_ppo_step_with_gae_and_per_dimension_covariance():
                        entropy_coeff=float(g["entropy_coeff"]), updates_per_iter=2, monte_carlo=False)
     np.testing.assert_allclose([l["total"] for l in logs], g["total_loss"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose([l["critic"] for l in logs], g["critic_loss"], rtol=1e-5, atol=1e-6)
+    for net in ("actor", "critic"):
+        for k, p in getattr(pol, net).named_parameters():
+            np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind,tag,S,A", [("ppo", "h128", 5, 1), ("grpo", "h128", 5, 1), ("ppo", "h256", 20, 4), ("grpo", "h256", 20, 4)])
+def test_learn_at_chain_kernel_shapes(kind, tag, S, A):
+    """learn() at the net shapes the hot learner kernels run (128 x 4, 256 x 5; ~4,000 rows, 2 updates).  The initial
+    weights are rebuilt from the fixture's seed (the constructors draw them from torch's CPU generator, as the
+    reference's do) and checked against the fixture's samples before anything else."""
+    g = load_golden(f"{kind}_step_{tag}.npz")
+    hidden = tuple(int(h) for h in g["hidden"])
+    torch.manual_seed(int(g["seed"]))
+    pol = L.OraclePolicy(S, A, hidden, cov=float(g["cov"]), critic=kind == "ppo")
+    nets = ("actor", "critic") if kind == "ppo" else ("actor",)
+    named = lambda: [(f"{n}.{k}", p) for n in nets for k, p in getattr(pol, n).named_parameters()]
+    check_pinned(g, "init", named(), atol=0.0, sum_rtol=1e-9)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    t = lambda k: torch.from_numpy(g[k])
+    if kind == "ppo":
+        logs = L.ppo_learn(pol, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=0.2, gamma=float(g["gamma"]), c1=0.5, kl_coeff=0.5,
+                           entropy_coeff=0.01, updates_per_iter=2)
+        np.testing.assert_allclose([l["total"] for l in logs], g["total_loss"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose([l["critic"] for l in logs], g["critic_loss"], rtol=1e-5, atol=1e-6)
+    else:
+        old = L.OraclePolicy(S, A, hidden, cov=float(g["cov"]), critic=False)
+        old.load_state_dict(pol.state_dict())
+        gen = torch.Generator().manual_seed(int(g["seed"]))
+        with torch.no_grad():
+            for p_ in old.parameters():
+                p_.add_(float(g["old_policy_perturbation"]) * torch.randn(p_.shape, generator=gen))
+        Js = L.grpo_learn(pol, old, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=0.15, gamma=float(g["gamma"]), updates_per_iter=2)
+        np.testing.assert_allclose(Js, g["J"], rtol=2e-4, atol=1e-5)
+    # <= 1e-5 (north_star: fp32 within 1e-5); <= 0.5 % of the entries may be Adam-amplified rounding noise (up to 2 lr steps)
+    check_pinned(g, "final", named(), atol=1e-5, outlier_frac=0.005, outlier_atol=4 * float(g["lr"]), sum_rtol=1e-3)
+    check_pinned(g, "lastgrad", [(k, p.grad) for k, p in named()], norm_rel=1e-3, atol=1e-7)
+
+
+def test_ppo_minibatch_step():
+    """Minibatch PPO (algorithms/ppo.py:147-157), the reference's recorded torch.randperm draws fed back as data."""
+    g = load_golden("ppo_minibatch.npz")
+    pol = _policy_from_golden(g, "init.", 10, 2, (32, 32), [float(g["cov"])] * 2, True)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    t = lambda k: torch.from_numpy(g[k])
+    logs = L.ppo_learn(pol, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=float(g["epsilon"]), gamma=float(g["gamma"]),
+                       c1=float(g["c1"]), kl_coeff=float(g["kl_coeff"]), entropy_coeff=float(g["entropy_coeff"]), updates_per_iter=2,
+                       batch_size=int(g["batch_size"]), permutations=g["permutations"])
+    assert len(logs) == len(g["total_loss"]) == 4                      # 2 updates x ceil(n_valid / 64) steps
+    np.testing.assert_allclose([l["total"] for l in logs], g["total_loss"], rtol=1e-5, atol=1e-6)
     for net in ("actor", "critic"):
         for k, p in getattr(pol, net).named_parameters():
             np.testing.assert_allclose(p.detach().numpy(), g[f"final.{net}.{k}"], rtol=0, atol=2e-6)

@@ -98,6 +98,12 @@ class _GpuLearner(Algorithm):
         with torch.cuda.device(self.policy.device):
             self._learn(buffer)
 
+    def sync_old_policy(self) -> None:
+        """old_policy <- policy.  The constructors deep-copy the policy BEFORE a checkpoint is loaded into it
+        (pipelines/pipeline.py:93-100 loads after construction), so a resume must re-synchronise the copy -- GRPO's
+        first learn() would otherwise form its ratios against the random-init weights."""
+        self.old_policy.load_state_dict(self.policy.state_dict())
+
     @property
     def bucket(self) -> D.GradBucket:
         if self._bucket is None:
@@ -246,6 +252,9 @@ class PPO(_GpuLearner):
         self.old_policy = copy.deepcopy(self.policy)                        # ppo.py:62 (never read in learn)
         self._seed = seed
         self._gen = None
+        # minibatch mode: callable (n_rows, device) -> int64 permutation of this rank's valid rows (time-major order);
+        # None = torch.randperm on the device from `seed` (the reference draws torch.randperm on the CPU, ppo.py:148)
+        self.permutation_fn = None
 
     def _values_nograd(self, xin):
         out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
@@ -306,24 +315,26 @@ class PPO(_GpuLearner):
         ret = rtg.reshape(-1).index_select(0, idx)
         old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)
         M = X.shape[0]
-        _, world = D.rank_world(self.process_group)
         all_sums = []
         for _ in range(self.updates_per_iter):
             if self.batch_size is None:
                 # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
                 self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums)
             else:
-                if self._gen is None:
-                    self._gen = torch.Generator(device=X.device)
-                    self._gen.manual_seed(self._seed)
-                perm = torch.randperm(M, device=X.device, generator=self._gen)
-                local_bs = max(1, math.ceil(self.batch_size / world))
-                for lo in range(0, M, local_bs):
-                    b = perm[lo:lo + local_bs]
-                    nb = torch.tensor([float(b.numel())], dtype=torch.float64, device=X.device)
-                    D.allreduce_sum_(nb, self.process_group)
+                if self.permutation_fn is not None:
+                    perm = self.permutation_fn(M, X.device)
+                else:
+                    if self._gen is None:
+                        self._gen = torch.Generator(device=X.device)
+                        self._gen.manual_seed(self._seed)
+                    perm = torch.randperm(M, device=X.device, generator=self._gen)
+                # every rank takes the same number of optimizer steps (each one is a collective); a rank that has run
+                # out of rows joins the remaining ones with an empty slice
+                local_bs, n_steps, sizes = D.minibatch_schedule(M, self.batch_size, self.process_group, X.device)
+                for k in range(n_steps):
+                    b = perm[k * local_bs:(k + 1) * local_bs]
                     self._step(xin.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
-                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(nb.item()), all_sums)
+                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums)
         self.old_policy.load_state_dict(self.policy.state_dict())           # ppo.py:186
         if all_sums:
             S = torch.stack(all_sums)

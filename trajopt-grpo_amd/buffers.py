@@ -33,16 +33,30 @@ class Rollout_Buffer(Buffer):
         self.rtg = rtg                       # stored, never used -- as in the reference (:14,19)
         self.device_traj = None              # DeviceTrajectory of the last sample()
         self._ref = None                     # cached reference-layout CPU tensors
+        self._ref_limits = (None, None)      # (max_groups, max_episodes) of the lazy reference view; None = everything
+        self._ref_is_full = False
         self.avg_reward = []
         self.fig = None
         self.axs = None
 
     # ---- lazy reference-layout attributes ------------------------------------------
-    def _materialise(self):
-        if self._ref is None:
-            if self.device_traj is None:
-                return None
-            self._ref = dict(zip(self._REF_FIELDS, self.device_traj.to_reference()))
+    def limit_reference_view(self, max_groups=None, max_episodes=None):
+        """Restrict what the lazy `group_*` attributes copy from the device to the first `max_groups` groups and the
+        first `max_episodes` episodes of each group: a visualiser that renders `max_episodes_per_render`
+        episodes per group (visualize/dashboard.py:206-217) then costs a few MB per render instead of the whole
+        trajectory (1.7 GB at C3).  `retrieve()` and `save_trajectory()` always use the full trajectory."""
+        self._ref_limits = (max_groups, max_episodes)
+        if not self._ref_is_full:
+            self._ref = None
+
+    def _materialise(self, full: bool = False):
+        if self._ref is not None and (self._ref_is_full or not full):
+            return self._ref
+        if self.device_traj is None:
+            return self._ref                  # tensors handed to store(): always complete
+        limits = (None, None) if full else self._ref_limits
+        self._ref = dict(zip(self._REF_FIELDS, self.device_traj.to_reference(*limits)))
+        self._ref_is_full = limits == (None, None)
         return self._ref
 
     def __getattr__(self, name):
@@ -60,7 +74,7 @@ class Rollout_Buffer(Buffer):
         mgr = self.rollout_manager
         if hasattr(mgr, "rollout_device"):
             traj = mgr.rollout_device()
-            self.device_traj, self._ref = traj, None
+            self.device_traj, self._ref, self._ref_is_full = traj, None, False
             total = traj.rew.sum(dtype=torch.float64).reshape(1)
             stats = torch.cat([total, torch.tensor([float(traj.n)], dtype=torch.float64, device=total.device)])
             D.allreduce_sum_(stats, getattr(mgr, "process_group", None))
@@ -74,19 +88,21 @@ class Rollout_Buffer(Buffer):
         self.device_traj = None
         self._ref = dict(zip(self._REF_FIELDS, (group_observations, group_actions, group_rewards, group_lengths,
                                                 group_masks)))
+        self._ref_is_full = True
         self.avg_reward.append(group_rewards.sum(2).mean().detach().numpy())
 
     def retrieve(self):
         """The reference reads attributes that are never set (:107-108); return the five stored tensors."""
-        r = self._materialise()
+        r = self._materialise(full=True)
         return tuple(r[k] for k in self._REF_FIELDS)
 
     def save_trajectory(self, path: str):
         """trajectory.csv: episode_id, observation_i..., action_j...  (rollout_buffer.py:72-102)."""
         import pandas as pd
-        obs = self.group_observations.numpy()
-        act = self.group_actions.numpy()
-        lens = self.group_lengths.numpy().astype(int)
+        ref = self._materialise(full=True)
+        obs = ref["group_observations"].numpy()
+        act = ref["group_actions"].numpy()
+        lens = ref["group_lengths"].numpy().astype(int)
         rows_o, rows_a, eid = [], [], []
         for i in range(lens.shape[0]):
             for j in range(lens.shape[1]):

@@ -39,6 +39,26 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def minibatch_schedule(m_local: int, batch_size: int, group=None, device=None):
+    """Minibatch PPO over sharded rows (algorithms/ppo.py:147-157 permutes the global batch and walks it in steps of
+    `batch_size`): every rank walks its own permuted rows in steps of ceil(batch_size / world).  Ranks hold different
+    numbers of valid rows (episodes end at different times), but every optimizer step issues collectives, so ALL
+    ranks must take the same number of steps: the count is derived from the all-gathered row counts, and a rank that
+    has run out of rows takes the remaining steps with an empty slice (zero gradient, still in every all-reduce).
+    -> (local_bs, n_steps, global_sizes): global_sizes[k] = rows of ALL ranks in step k (the loss normaliser)."""
+    _, world = rank_world(group)
+    local_bs = max(1, -(-int(batch_size) // world))
+    counts = [int(m_local)]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=device)
+        t[dist.get_rank(group)] = int(m_local)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)          # an all-gather of one integer per rank
+        counts = [int(v) for v in t.tolist()]
+    n_steps = max(-(-c // local_bs) for c in counts)
+    sizes = [sum(min(max(c - k * local_bs, 0), local_bs) for c in counts) for k in range(n_steps)]
+    return local_bs, n_steps, sizes
+
+
 class GradBucket:
     """All parameter gradients as views into ONE flat buffer, so an optimizer step costs exactly one
     all-reduce (0.2-2.2 MB for the reference's policies: latency-bound, so one bucket, not many)."""

@@ -18,6 +18,7 @@ import torch
 
 from .algorithms import GRPO, PPO
 from .buffers import Rollout_Buffer
+from .distributed import rank_world
 from .environments import CartPole, QuadPole, QuadPole2D
 from .policies import GaussianActor_NeuralNetwork, GaussianActorCritic_NeuralNetwork
 from .rollout import RolloutManager, RolloutWorker
@@ -49,6 +50,11 @@ class Pipeline:
             self.load_metadata(os.path.join(self.load_path, "metadata.json"))
         metadata = self.get_metadata()
         if self.visualizer is not None:
+            # the reference's Dashboard reads only the first max_episodes_per_render episodes of each group
+            # (visualize/dashboard.py:206-217): copy just those from the device when it renders
+            k = getattr(self.visualizer, "max_episodes_per_render", None)
+            if k is not None and hasattr(self.buffer, "limit_reference_view"):
+                self.buffer.limit_reference_view(max_episodes=int(k))
             self.visualizer.initialize(metadata)
 
     def load(self) -> None:
@@ -56,13 +62,22 @@ class Pipeline:
             self.algorithm.load(self.load_path)
             self.policy.load(self.load_path)
             self.buffer.load(self.load_path)
+            sync = getattr(self.algorithm, "sync_old_policy", None)
+            if sync is not None:
+                sync()                      # the algorithm copied the policy before the checkpoint was loaded into it
 
     def save(self, path: str) -> None:
-        self.algorithm.save(path)
-        self.policy.save(path)
-        self.buffer.save(path)
-        with open(os.path.join(path, "metadata.json"), "w") as f:
-            json.dump(self.get_metadata(), f, indent=4)
+        """One process per GPU: the weights are identical on every rank after the gradient all-reduce, so rank 0
+        alone writes the checkpoint (torch.save is not atomic); the others wait for it."""
+        rank, world = rank_world()
+        if rank == 0:
+            self.algorithm.save(path)
+            self.policy.save(path)
+            self.buffer.save(path)
+            with open(os.path.join(path, "metadata.json"), "w") as f:
+                json.dump(self.get_metadata(), f, indent=4)
+        if world > 1:
+            torch.distributed.barrier()
 
     def get_metadata(self) -> Dict[str, Any]:
         return {

@@ -58,13 +58,23 @@ class DeviceTrajectory:
         return int(self.counters[0].item())
 
     # ---- reference layout (CPU float32), rollout_manager.py:86-90 -------------------
-    def to_reference(self):
+    def to_reference(self, max_groups=None, max_episodes=None):
+        """The reference's (G, E, T, .) CPU float32 5-tuple.  max_groups / max_episodes: only the first groups and the
+        first episodes of each group are sliced out ON THE DEVICE and copied -- what the reference's Dashboard reads
+        (`group_observations[i, ep, frame]` for ep < max_episodes_per_render, visualize/dashboard.py:206-217,
+        visualize/visualizer.py:120-140) is a few MB, the whole C3 trajectory 1.7 GB."""
         G, E, T = self.G, self.E, self.T
-        obs = self.obs[:, :T, :].permute(2, 1, 0).reshape(G, E, T, self.S).float().cpu()
-        act = self.act.permute(2, 1, 0).reshape(G, E, T, self.A).float().cpu()
-        rew = self.rew.t().reshape(G, E, T).float().cpu()
-        mask = self.mask.t().reshape(G, E, T).float().cpu()
-        ln = self.len.reshape(G, E).float().cpu()          # float32, like the manager's torch.zeros (:89)
+        g = G if max_groups is None else max(0, min(G, int(max_groups)))
+        e = E if max_episodes is None else max(0, min(E, int(max_episodes)))
+
+        def cut(x, lead):                        # x [lead...][n] -> [lead...][g][e]
+            return x.reshape(*lead, G, E)[..., :g, :e]
+
+        obs = cut(self.obs[:, :T, :], (self.S, T)).permute(2, 3, 1, 0).float().cpu().contiguous()
+        act = cut(self.act, (self.A, T)).permute(2, 3, 1, 0).float().cpu().contiguous()
+        rew = cut(self.rew, (T,)).permute(1, 2, 0).float().cpu().contiguous()
+        mask = cut(self.mask, (T,)).permute(1, 2, 0).float().cpu().contiguous()
+        ln = cut(self.len, ()).float().cpu().contiguous()          # float32, like the manager's torch.zeros (:89)
         return obs, act, rew, ln, mask
 
 
@@ -176,6 +186,9 @@ class DeviceRollout:
         """One rollout.  `initial_states` (N,S) and `forced_actions` (N,T,A) or (G,E,T,A)
         replace the RNG draws (teacher-forced parity runs)."""
         self.params = self.env.native_params()
+        # the policy's covariance is read fresh every rollout (the reference reads self.cov in every forward,
+        # actor_critic.py:131-136; the learner reads policy.var in every learn())
+        self._sigma = (C.c_float * self.A)(*[float(v) for v in torch.sqrt(self.policy.var)])
         if not hasattr(self, "_stream_host"):
             self._seed_host, self._stream_host = int(self.rng[0].item()), 0
         sample = forced_actions is None
