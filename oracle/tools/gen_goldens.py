@@ -537,6 +537,18 @@ def gen_chain_shape_steps():
         _pin(out, "init", named())
         init = {k: p.detach().clone() for k, p in named()}
         opt = torch.optim.Adam(pol.parameters(), lr=lr)
+        # the gradients of the FIRST update (taken on the initial weights: they isolate the arithmetic of one
+        # forward / backward pass from the path the training takes afterwards) are still in .grad when the second
+        # update calls zero_grad()
+        first = {}
+        plain_zero = opt.zero_grad
+
+        def zero_grad_keeping_first(*a, **k):
+            if not first and all(p.grad is not None for _, p in named()):
+                first.update({k_: p.grad.detach().clone() for k_, p in named()})
+            return plain_zero(*a, **k)
+
+        opt.zero_grad = zero_grad_keeping_first
         sink = []
         if kind == "ppo":
             algo = PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, c1=0.5, kl_coeff=0.5,
@@ -553,6 +565,7 @@ def gen_chain_shape_steps():
         algo.learn(buf)
         for name in sink[0]:
             out[name] = np.array([float(r[name]) for r in sink])
+        _pin(out, "firstgrad", list(first.items()))
         _pin(out, "final", named())
         _pin(out, "delta", [(k, p.detach() - init[k]) for k, p in named()])
         _pin(out, "lastgrad", [(k, p.grad) for k, p in named()])

@@ -54,3 +54,16 @@ def check_pinned(g, prefix, named, rtol=0.0, atol=2e-6, sum_rtol=1e-4, norm_rel=
             np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=f"{prefix}.{k}")
         ref_sum, ref_l2 = float(g[f"{prefix}_sum.{k}"]), float(g[f"{prefix}_l2.{k}"])
         assert abs(float(flat.sum()) - ref_sum) <= sum_rtol * (ref_l2 * flat.numel() ** 0.5 + 1e-12) + atol * flat.numel() ** 0.5, f"{prefix}_sum.{k}"
+
+
+def keep_first_step_gradients(opt, named):
+    """Wrap opt.step so that the gradients present at its FIRST call are kept: -> dict filled in place."""
+    first, plain = {}, opt.step
+
+    def step(*a, **k):
+        if not first:
+            first.update({key: p.grad.detach().clone() for key, p in named()})
+        return plain(*a, **k)
+
+    opt.step = step
+    return first

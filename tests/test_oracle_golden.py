@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_pinned, load_golden
+from conftest import check_pinned, keep_first_step_gradients, load_golden
 from oracle import envs as E
 from oracle import learner as L
 
@@ -203,6 +203,7 @@ def test_learn_at_chain_kernel_shapes(kind, tag, S, A):
     named = lambda: [(f"{n}.{k}", p) for n in nets for k, p in getattr(pol, n).named_parameters()]
     check_pinned(g, "init", named(), atol=0.0, sum_rtol=1e-9)
     opt = torch.optim.Adam(pol.parameters(), lr=float(g["lr"]))
+    first = keep_first_step_gradients(opt, named)
     t = lambda k: torch.from_numpy(g[k])
     if kind == "ppo":
         logs = L.ppo_learn(pol, opt, t("obs"), t("act"), t("rew"), t("mask"), epsilon=0.2, gamma=float(g["gamma"]), c1=0.5, kl_coeff=0.5,
@@ -220,6 +221,7 @@ def test_learn_at_chain_kernel_shapes(kind, tag, S, A):
         np.testing.assert_allclose(Js, g["J"], rtol=2e-4, atol=1e-5)
     # <= 1e-5 (north_star: fp32 within 1e-5); <= 0.5 % of the entries may be Adam-amplified rounding noise (up to 2 lr steps)
     check_pinned(g, "final", named(), atol=1e-5, outlier_frac=0.005, outlier_atol=4 * float(g["lr"]), sum_rtol=1e-3)
+    check_pinned(g, "firstgrad", list(first.items()), norm_rel=1e-4, atol=1e-8)
     check_pinned(g, "lastgrad", [(k, p.grad) for k, p in named()], norm_rel=1e-3, atol=1e-7)
 
 
