@@ -1,36 +1,44 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: GPU-resident rollout + PPO update on QuadPole ("quadrotor_env.py").
+"""Benchmark of the hot path: GPU-resident rollout + PPO / GRPO update on QuadPole ("quadrotor_env.py").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3|c4|c5] [--scaling weak|strong]
 
-One "step" = one pass of the hot path over one batch: a 65,536-env x 256-step QuadPole rollout (one persistent
-kernel: actor MLP on the matrix cores + sampling + dynamics + recording) followed by PPO.learn on that buffer with
-the reference factory's hyper-parameters (pipelines/quadpole_pipeline_ppo.py: 20-256x5-{4,1} actor-critic, cov 0.3,
-gamma 0.999, 32 full-batch updates, Adam 3e-4), i.e. BASELINE.json configs[2] (C3).  Metric: env-steps/s, where an
-env-step is one valid (mask == 1) Env.step.  Weak scaling: every rank runs 65,536 envs; gradients are all-reduced
-once per optimizer step (RCCL).
+One "step" = one pass of the hot path over one batch: a rollout of every env of this rank's shard (one persistent kernel:
+actor MLP on the matrix cores + sampling + dynamics + recording) followed by `learn` on that buffer.
 
-Besides the contract fields, the JSON line carries
-  roofline         the kernel with the most GPU time in the step (29 %): tg_mlp_backward_chain, the backward-data pass of
-                   all hidden layers in one launch.  HBM-bound (writes); algorithmic bytes per row = 16 (dOut) +
-                   5 x 32 (1-bit ReLU masks) + 5 x 512 (the dZ it must write for the weight gradients) = 2736 B at
-                   20-256x5-4; EVERY launch of the timed steps is bracketed by HIP events on the launch stream.
-                   (Shapes without that kernel report tg_dx_relu_bias; with an fp32 policy `roofline` is the rollout
-                   kernel's.)
-  rollout_kernel   the fused rollout kernel against the MFMA roofline: 2 x actor parameters flop per valid env-step
-                   (539 kflop), HIP events around each rollout's launch; `all_alive` = the same kernel with
-                   nobody terminating.  With --no-fused: the per-step dynamics kernel against the HBM roofline (189 B
-                   per env-step, SURVEY 8d state-in-trajectory variant).
-  dynamics_kernel  the stand-alone dynamics kernel (tg_rollout_step) at this env count, HBM roofline, timed after the run;
-  learner_kernel   tg_dx_relu_bias (the per-layer form of the backward-data pass) on random data at 2^22 rows, timed after
-                   the run;
-  cpu_baseline     the CPU port of the reference path (oracle/: scalar fp64 env + batch-1 torch policy per step in
-                   forked worker processes, then PPO.learn on CPU) timed on this box's host cores over a bounded
-                   sample of the same workload.
+  --config c3 (default)  BASELINE.json configs[2]: QuadPole PPO, 65,536 envs x 256 steps, the reference factory's
+                         hyper-parameters (pipelines/quadpole_pipeline_ppo.py: 20-256x5-{4,1} actor-critic, cov 0.3,
+                         gamma 0.999, 32 full-batch updates, Adam 3e-4), bf16 policy.  The metric is quoted on this one.
+  --config c4            configs[3]: QuadPole GRPO, restart groups (E episodes share the group's initial state),
+                         32,768 envs per GPU (128 groups x 256; 262,144 = 1,024 groups on 8 GPUs), actor 20-256x5-4.
+  --config c5            configs[4]: QuadPoleSwarm (8 bodies per env), GRPO with the group statistics across the bodies,
+                         4,096 envs x 8 agents per GPU (64 groups x 64 episodes; 32,768 envs on 8 GPUs).
+  --scaling weak         (default) the per-GPU shard above on every rank;  strong: the config's TOTAL env count (c3: 65,536;
+                         c4: 262,144; c5: 32,768) divided over the ranks.
+
+Metric: env-steps/s, an env-step being one valid (mask == 1) Env.step.  Gradients are all-reduced once per optimizer step
+(RCCL); the rollout needs no collective.
+
+`--gpus N` with N > 1 from a bare invocation (WORLD_SIZE unset): this process -- which never touches the GPU -- starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and exits with its code; rank 0 of the child
+prints the JSON line.  Under torchrun (WORLD_SIZE set) the process is a rank.
+
+Besides the contract fields the JSON line carries
+  roofline          the hand-written kernel FAMILY with the most GPU time in the step (weight gradients, backward-data chain
+                    or forward chain), algorithmic bytes of every launch of the timed steps / its duration by HIP events on
+                    the launch stream; `kernels` has the same figures for all three families.
+  rollout_kernel    the fused rollout kernel against the MFMA roofline (2 x actor parameters flop per valid env-step).
+  dynamics_kernel   the stand-alone dynamics kernel (tg_rollout_step) at this env count, HBM roofline, timed after the run.
+  fixed work        `update_ns_per_valid_row` (learn time per valid row: does not depend on how long the policy survives) and
+                    `fixed_work_ms_per_step` (one step with the bounds opened: every env runs the full horizon, 16.8 M rows).
+  cpu_baseline      the CPU port of the reference path (oracle/) timed on this box's host cores over bounded samples:
+                    all cores (<= 16), exactly 8 cores (sched_setaffinity, comparable with BASELINE.md section 2), and C1 exactly.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,8 +47,15 @@ sys.path.insert(0, REPO)
 
 HIDDEN = (256, 256, 256, 256, 256)
 ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
-BWD_PMC_BYTES_PER_ROW = 11481697627 / 4194304                        # profiles/r01_bwd_chain_probe_pmc.json
 HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+# PMC traffic per row of the three learner kernels at 2^22 rows (profiles/r02_*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE)
+PMC_JSON = {"dw": "r02_dw_probe_pmc.json", "bwd": "r02_bwd_chain_probe_pmc.json", "fwd": "r02_fwd_chain_probe_pmc.json"}
+CONFIGS = {
+    #        env           algo    groups/GPU  episodes  agents  restart  total envs (strong scaling)
+    "c3": ("QuadPole",      "ppo",  256,        256,      1,      False,   65536),
+    "c4": ("QuadPole",      "grpo", 128,        256,      1,      True,    262144),
+    "c5": ("QuadPoleSwarm", "grpo", 64,         64,       8,      True,    32768),
+}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -60,12 +75,12 @@ def _cpu_worker(args):
         return L.run_episodes(env, pol, episodes, restart=False)
 
 
-def cpu_baseline(T, updates, budget_workers=None, episodes=32):
+def _cpu_leg(T, updates, workers, episodes):
+    """Reduced C3: `workers` forked rollout processes (1 thread each, like OMP_NUM_THREADS=1 in BASELINE.md section 2), then
+    PPO.learn on the CPU with `workers` threads."""
     import multiprocessing as mp
     import torch
     from oracle import learner as L
-    cores = len(os.sched_getaffinity(0))
-    workers = budget_workers or max(1, min(cores, 16))
     torch.manual_seed(0)
     pol = L.OraclePolicy(20, 4, HIDDEN, cov=0.3, critic=True)
     sd = pol.state_dict()
@@ -87,6 +102,53 @@ def cpu_baseline(T, updates, budget_workers=None, episodes=32):
                       f"256x5 actor-critic, PPO {updates} full-batch updates; rollout {t_roll:.1f}s "
                       f"({steps / t_roll:.0f} env-steps/s) + learn {t_learn:.1f}s",
             "rollout_value": steps / t_roll}
+
+
+def _cpu_leg_pinned(q, T, updates, cores, episodes):
+    os.sched_setaffinity(0, cores)
+    q.put(_cpu_leg(T, updates, len(cores), episodes))
+
+
+def _cpu_leg_c1():
+    """BASELINE.json configs[0] exactly: CartPole GRPO, 4 envs (2 workers x 2 episodes), 128-step horizon, the GRPO factory's
+    hyper-parameters (pipelines/cartpole_pipeline_grpo.py:54-76: 5-128x4-1 actor, cov 0.5, eps 0.15, gamma 0.5, 1 update),
+    in-process like the reference's `use_multiprocessing=False` path; 10 iterations."""
+    import numpy as np
+    import torch
+    from oracle import learner as L
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    pol = L.OraclePolicy(5, 1, (128,) * 4, cov=0.5)
+    old = L.OraclePolicy(5, 1, (128,) * 4, cov=0.5)
+    old.load_state_dict(pol.state_dict())
+    opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+    mk = lambda: L.OracleEnv("CartPole", max_steps=128, rng=np.random.default_rng(0))
+    steps, t0 = 0, time.perf_counter()
+    for _ in range(10):
+        with torch.no_grad():
+            obs, act, rew, ln, mask = L.rollout(mk, pol, 2, 2, restart=False)
+        L.grpo_learn(pol, old, opt, obs, act, rew, mask, epsilon=0.15, gamma=0.5, updates_per_iter=1)
+        steps += int(mask.sum())
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"C1 exactly: CartPole GRPO, 2 workers x 2 episodes x 128 steps in-process, 10 iterations ({steps} env-steps)"}
+
+
+def cpu_baseline(T, updates):
+    import multiprocessing as mp
+    cores = sorted(os.sched_getaffinity(0))
+    main_leg = _cpu_leg(T, updates, max(1, min(len(cores), 16)), 32)
+    legs = {}
+    if len(cores) >= 8:
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        p = ctx.Process(target=_cpu_leg_pinned, args=(q, T, updates, set(cores[:8]), 16))
+        p.start()
+        legs["pinned_8_cores"] = q.get()
+        p.join()
+    legs["c1_exact"] = _cpu_leg_c1()
+    main_leg["legs"] = legs
+    return main_leg
 
 
 def dynamics_kernel_probe(tg, dev, n, launches=64):
@@ -137,37 +199,76 @@ def dynamics_kernel_probe(tg, dev, n, launches=64):
             "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per launch)"}
 
 
+def _pmc_bytes_per_row(family):
+    """HBM traffic per row by the PMC counters of this family's 2^22-row probe (profiles/), or None."""
+    try:
+        with open(os.path.join(REPO, "profiles", PMC_JSON[family])) as f:
+            d = json.load(f)
+        return d["traffic_bytes_per_launch"] / d["rows"], PMC_JSON[family]
+    except Exception:
+        return None, None
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (groups of 256)")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (whole groups); default: the config's shard")
     ap.add_argument("--horizon", type=int, default=256)
-    ap.add_argument("--updates", type=int, default=32, help="PPO updates_per_iter (reference factory: 32)")
+    ap.add_argument("--updates", type=int, default=None,
+                    help="updates_per_iter (c3: the PPO factory's 32; c4 / c5: GRPO's constructor default 10, grpo.py:26-35)")
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fixed-work", action="store_true", help="skip the all-alive (bounds opened) step after the timed region")
     ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
     ap.add_argument("--no-fused", action="store_true",
                     help="per-step launches (actor GEMMs + tg_rollout_step) instead of the fused persistent rollout kernel")
     ap.add_argument("--no-launch-events", action="store_true",
-                    help="do not bracket the rollout / backward-chain launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
+                    help="do not bracket the rollout / learner launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing the multi-rank path on a single GPU (ranks share the device)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare invocation: one child process per GPU through torchrun.  This parent has made no GPU call (torch is not
+        # even imported) and only waits; it never replaces itself.
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    env_name, algo_name, G_shard, E, agents, restart, total_envs = CONFIGS[args.config]
+    if args.envs is not None:
+        G_local = args.envs // E
+    elif args.scaling == "strong":
+        if (total_envs // E) % world:
+            raise SystemExit(f"{total_envs // E} groups do not divide over {world} ranks")
+        G_local = total_envs // E // world
+    else:
+        G_local = G_shard
+    envs_local = G_local * E
+    updates = args.updates if args.updates is not None else (32 if algo_name == "ppo" else 10)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.horizon, args.updates)
+        cpu = cpu_baseline(args.horizon, 32)
 
     import torch
     import torch.distributed as dist
@@ -184,33 +285,43 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
-    E = 256
-    G_local = args.envs // E
     G_global = G_local * world
     T = args.horizon
     cdt = torch.bfloat16 if args.policy_dtype == "bf16" else None
     torch.manual_seed(0)                                      # identical random-init weights on every rank
-    policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
-    mk = lambda: tg.QuadPole(max_steps=T)
-    mgr = tg.RolloutManager(mk, policy, num_workers=G_global, num_episodes_per_worker=E, dtype=torch.float32,
-                            seed=1234, compute_dtype=cdt, use_graph=bool(args.graph), fused=False if args.no_fused else None)
+    if algo_name == "ppo":
+        policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
+    else:
+        policy = tg.GaussianActor_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
+
+    def make_env(open_bounds=False):
+        env = tg.QuadPoleSwarm(n_agents=agents, max_steps=T) if agents > 1 else tg.QuadPole(max_steps=T)
+        if open_bounds:
+            env.spatial_bounds = tuple((-1e9, 1e9) for _ in env.spatial_bounds)
+        return env
+
+    mgr = tg.RolloutManager(make_env, policy, restart=restart, num_workers=G_global, num_episodes_per_worker=E,
+                            dtype=torch.float32, seed=1234, compute_dtype=cdt, use_graph=bool(args.graph),
+                            fused=False if args.no_fused else None)
     buf = tg.Rollout_Buffer(mgr)
-    algo = tg.PPO(epsilon=0.2, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4), ref_model=None,
-                  updates_per_iter=args.updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,
-                  batch_size=None, autocast_dtype=cdt)
+    if algo_name == "ppo":
+        algo = tg.PPO(epsilon=0.2, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4), ref_model=None,
+                      updates_per_iter=updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,
+                      batch_size=None, autocast_dtype=cdt)
+    else:
+        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.99, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4),
+                       updates_per_iter=updates, autocast_dtype=cdt)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
+    for _ in range(args.warmup):
         buf.sample()
         algo.learn(buf)
-
-    for _ in range(args.warmup):
-        one_step()
     # event-pair overhead (no kernel in between), for the per-launch timing below
     pairs = []
     for _ in range(200):
@@ -221,20 +332,22 @@ def main():
     ev_overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
 
     env_steps = 0
-    t_roll = 0.0
+    t_roll = t_learn = 0.0
     launches = []            # (duration ms, env-steps in that launch)
     launch_units = []
     if not args.graph and not args.no_launch_events:
         mgr.engine.step_events = []
-    learner_mlps = [m for m in (algo._mlp(policy.actor), algo._mlp(policy.critic)) if m is not None]
+    nets = [policy.actor] + ([policy.critic] if algo_name == "ppo" else [])
+    learner_mlps = [m for m in (algo._mlp(n_) for n_ in nets) if m is not None]
     for m in (learner_mlps if not args.no_launch_events else []):
-        m.dx_events = []                    # HIP-event pairs around every tg_dx_relu_bias launch of the timed steps
+        m.dx_events, m.dw_events, m.fwd_events = [], [], []     # HIP-event pairs around every learner-kernel launch
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r0 = time.perf_counter()
         buf.sample()                        # ends with a host read of avg_reward -> rollout is complete here
-        t_roll += time.perf_counter() - r0
+        r1 = time.perf_counter()
+        t_roll += r1 - r0
         env_steps += buf.device_traj.env_steps()
         if mgr.engine.step_events:
             if mgr.engine.fused:
@@ -245,54 +358,37 @@ def main():
                 launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
             mgr.engine.step_events = []
         algo.learn(buf)
+        torch.cuda.synchronize()            # (learn's last kernels; the next rollout would wait for them anyway)
+        t_learn += time.perf_counter() - r1
     barrier()
     dt = time.perf_counter() - t0
 
-    dx_launches = []                        # (ms, algorithmic bytes, rows) per launch, the update's dominant kernel
+    fam_launches = {"bwd": [], "dw": [], "fwd": []}     # (ms, algorithmic bytes, rows, kernel name) per launch
     for m in learner_mlps:
-        dx_launches += [(a.elapsed_time(b), rows * bpr, rows, name) for a, b, rows, bpr, name in (m.dx_events or [])]
-        m.dx_events = None
-    dyn = dynamics_kernel_probe(tg, dev, args.envs) if rank == 0 else None
-    relu_probe = None
-    if rank == 0 and cdt is not None:
-        # the hand-written kernel with the most GPU time in the update: a hidden layer's backward-data product fused
-        # with the ReLU backward + bias gradient below it (tg_dx_relu_bias), on random data at the learner's chunk size.
-        # Algorithmic traffic as the learner runs it: read dZ (512 B) and the 1-bit ReLU masks (32 B), write dZ_below
-        # (512 B) per row at 256 bf16 features.
-        N_ = tg._native
-        lib_ = N_.load()
-        rows, cols = 1 << 22, 256
-        dZ = (torch.randn(rows, cols, device=dev) * 0.5).to(cdt)
-        bits_ = torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, cols // 32), dtype=torch.int32, device=dev)
-        W_ = (torch.randn(cols, cols, device=dev) / 16).to(cdt)
-        frag = torch.empty(cols * cols, dtype=cdt, device=dev)
-        out_ = torch.empty_like(dZ)
-        part = torch.empty(lib_.tg_dx_relu_bias_blocks(), cols, dtype=torch.float32, device=dev)
-        st = N_.stream_ptr(dev)
-        N_.check(lib_.tg_dx_pack_weights(W_.data_ptr(), frag.data_ptr(), cols, cols, st))
-        run = lambda: N_.check(lib_.tg_dx_relu_bias(dZ.data_ptr(), frag.data_ptr(), None, bits_.data_ptr(), out_.data_ptr(), rows, cols,
-                                                    cols, part.data_ptr(), st))
-        for _ in range(3):
-            run()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            run()
-        b.record()
-        torch.cuda.synchronize()
-        us = a.elapsed_time(b) * 1e3 / 10
-        bpr = 2 * cols * 2 + cols // 8
-        gbs = float(bpr) * rows / us / 1e3
-        relu_probe = {"kernel": "tg::dx_relu_bias_kernel<256,256,1,8,bits>", "bound": "hbm", "rows": rows, "cols": cols,
-                      "us_per_launch": us, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                      "bytes_per_row": bpr, "TFLOPs": 2.0 * rows * cols * cols / us / 1e6}
-        del dZ, bits_, W_, frag, out_, part
+        for fam, attr in (("bwd", "dx_events"), ("dw", "dw_events"), ("fwd", "fwd_events")):
+            fam_launches[fam] += [(a.elapsed_time(b), rows * bpr, rows, name) for a, b, rows, bpr, name in (getattr(m, attr) or [])]
+            setattr(m, attr, None)
+
+    # ---- fixed work: one step with nobody terminating (every env runs the whole horizon) ----
+    fixed = None
+    if not args.no_fixed_work and hasattr(make_env(), "spatial_bounds"):
+        mgr_open = tg.RolloutManager(lambda: make_env(True), policy, restart=restart, num_workers=G_global,
+                                     num_episodes_per_worker=E, dtype=torch.float32, seed=4321, compute_dtype=cdt,
+                                     fused=False if args.no_fused else None)
+        buf_open = tg.Rollout_Buffer(mgr_open)
+        buf_open.sample(); algo.learn(buf_open)                 # grows the workspaces to the full row count
+        barrier()
+        f0 = time.perf_counter()
+        buf_open.sample(); algo.learn(buf_open)
+        barrier()
+        fixed = (time.perf_counter() - f0, buf_open.device_traj.env_steps())
+        del mgr_open, buf_open
+
+    dyn = dynamics_kernel_probe(tg, dev, envs_local * agents) if rank == 0 and agents == 1 else None
     fused_all_alive = None
-    if rank == 0 and mgr.engine.fused:
+    if rank == 0 and mgr.engine.fused and agents == 1:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
-        env_open = tg.QuadPole(max_steps=T)
-        env_open.spatial_bounds = tuple((-1e9, 1e9) for _ in env_open.spatial_bounds)
-        eng = tg.DeviceRollout(env_open, policy, G_local, E, seed=7, compute_dtype=cdt, fused=True)
+        eng = tg.DeviceRollout(make_env(True), policy, G_local, E, restart=restart, seed=7, compute_dtype=cdt, fused=True)
         eng.run()
         eng.step_events = []
         eng.run()
@@ -305,30 +401,46 @@ def main():
                            "achieved_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9,
                            "frac_of_2500_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9 / 2500.0}
         del eng
-    tot = torch.tensor([float(env_steps), dt, t_roll], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(env_steps), dt, t_roll, t_learn, fixed[0] if fixed else 0.0, float(fixed[1]) if fixed else 0.0],
+                       dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_steps, dt, t_roll = float(tot[0]), float(mx[1]), float(mx[2])
+        total_steps, dt, t_roll, t_learn = float(tot[0]), float(mx[1]), float(mx[2]), float(mx[3])
+        fixed = (float(mx[4]), float(tot[5])) if fixed else None
     else:
         total_steps = float(env_steps)
 
     if rank == 0:
+        n_nets = len(nets)
+        workload = {"c3": f"C3: QuadPole (quadrotor_env.py) PPO, {envs_local} envs/GPU x {T}-step horizon, natural termination, "
+                          f"actor-critic 20-256x5-{{4,1}}, {updates} full-batch updates/iter, {args.policy_dtype} policy",
+                    "c4": f"C4: QuadPole GRPO, {envs_local} envs/GPU ({G_local} restart groups x {E}) x {T}-step horizon, actor "
+                          f"20-256x5-4, {updates} updates/iter, {args.policy_dtype} policy",
+                    "c5": f"C5: QuadPoleSwarm GRPO, {envs_local} envs x {agents} agents per GPU ({G_local} groups x {E} episodes) x "
+                          f"{T}-step horizon, shared actor 20-256x5-4, {updates} updates/iter, {args.policy_dtype} policy"}[args.config]
         out = {
-            "metric": "env-steps/sec at 65k parallel quadrotor envs (rollout + PPO update)",
+            "metric": "env-steps/sec at 65k parallel quadrotor envs (rollout + PPO update)" if args.config == "c3" else
+                      f"env-steps/sec, {args.config} (rollout + GRPO update)",
             "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "policy_dtype": args.policy_dtype, "data": "synthetic",
-            "config": {"workload": f"C3: QuadPole (quadrotor_env.py) PPO, {args.envs} envs/GPU x {T}-step horizon, "
-                                   f"natural termination, actor-critic 20-256x5-{{4,1}}, {args.updates} full-batch "
-                                   f"updates/iter, {args.policy_dtype} policy",
-                       "envs_per_gpu": args.envs, "horizon": T, "updates_per_iter": args.updates,
-                       "parallelism": f"env-shard x{world}, 1 grad all-reduce per optimizer step"},
+            "n_ranks_seen": n_ranks_seen,
+            "config": {"workload": workload, "name": args.config, "envs_per_gpu": envs_local, "agents_per_env": agents,
+                       "envs_total": envs_local * world, "horizon": T, "updates_per_iter": updates,
+                       "parallelism": f"env-shard x{world} (whole groups per rank), 1 grad all-reduce per optimizer step"},
             "rollout_only_env_steps_per_s": total_steps / t_roll if t_roll > 0 else None,
             "rollout_ms": 1e3 * t_roll / args.steps,
             "env_steps_per_step": total_steps / args.steps,
+            # fixed work: independent of how long the policy survives (the number of valid rows grows as it learns)
+            "update_ns_per_valid_row": 1e9 * t_learn * world / total_steps if total_steps else None,
+            "update_ns_per_row_update_net": 1e9 * t_learn * world / total_steps / updates / n_nets if total_steps else None,
         }
+        if fixed:
+            out["fixed_work_ms_per_step"] = 1e3 * fixed[0]
+            out["fixed_work_env_steps_per_s"] = fixed[1] / fixed[0]
+            out["fixed_work_note"] = "one step with the spatial bounds opened: every env runs the whole horizon (all ranks' rows)"
         fused = mgr.engine.fused
         out["rollout_path"] = "fused persistent kernel (tg_fused_rollout)" if fused else "per-step launches (GEMMs + tg_rollout_step)"
         if launches and fused:
@@ -338,54 +450,55 @@ def main():
             dur = sum(d for d, _ in launches) * 1e-3
             ach = 2.0 * n_par * sum(launch_units) / dur / 1e12
             out["rollout_kernel"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                               "traffic": 1706642656 if args.envs == 65536 else None,
-                               "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
-                                                 "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
-                               "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
-                               "flops_per_env_step": 2 * n_par, "launches": len(launches),
-                               "avg_launch_ms": 1e3 * dur / len(launches),
-                               "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
-                               "all_alive": fused_all_alive}
+                                     "traffic": 1706642656 if envs_local == 65536 and agents == 1 else None,
+                                     "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
+                                                       "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
+                                     "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
+                                     "flops_per_env_step": 2 * n_par, "launches": len(launches),
+                                     "avg_launch_ms": 1e3 * dur / len(launches),
+                                     "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
+                                     "all_alive": fused_all_alive}
         elif launches:
             dur = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in launches) * 1e-3
             units = sum(u for _, u in launches)
-            full = [(d, u) for d, u in launches if u == args.envs]
             ach = ALGO_BYTES["QuadPole"] * units / dur / 1e9
-            traffic = 14334976 if args.envs == 65536 else None
             out["rollout_kernel"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (all-alive launch)",
-                               "kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>",
-                               "bytes_per_env_step": ALGO_BYTES["QuadPole"], "launches": len(launches),
-                               "avg_launch_us": 1e6 * dur / len(launches),
-                               "event_pair_overhead_us": 1e3 * ev_overhead_ms}
-            if full:
-                d_full = sum(max(d - ev_overhead_ms, 1e-4) for d, _ in full) * 1e-3 / len(full)
-                out["rollout_kernel"]["full_launch_us"] = 1e6 * d_full
-                out["rollout_kernel"]["full_launch_GBs"] = ALGO_BYTES["QuadPole"] * args.envs / d_full / 1e9
-        if dx_launches:
-            # the kernel with the most GPU time in the step (29 %, profiles/r01_learner_bench_kernel_stats.csv): the
-            # backward-data pass (tg_mlp_backward_chain; per-layer tg_dx_relu_bias for shapes without it).  Algorithmic
-            # bytes per row come with each event record (mlp.GemmMLP.dx_events).
-            dur = sum(d for d, _, _, _ in dx_launches) * 1e-3
-            nbytes = sum(b for _, b, _, _ in dx_launches)
-            nrows = sum(r for _, _, r, _ in dx_launches)
+                                     "frac": ach / HBM_PEAK_GBS, "traffic": 14334976 if envs_local == 65536 else None,
+                                     "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (all-alive launch)",
+                                     "kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>",
+                                     "bytes_per_env_step": ALGO_BYTES["QuadPole"], "launches": len(launches),
+                                     "avg_launch_us": 1e6 * dur / len(launches), "event_pair_overhead_us": 1e3 * ev_overhead_ms}
+        # ---- the three hand-written learner kernel families: every launch of the timed steps, HIP events on the launch stream ----
+        kernels = {}
+        notes = {"dw": "tg_mlp_weight_grad: every weight + hidden bias gradient of a net in one launch; algorithmic bytes = each dZ "
+                       "and stored activation read once (the first activation is recomputed from the 64-B input row)",
+                 "bwd": "tg_mlp_backward_chain: the dZ of all hidden layers in one launch; 16 B + per layer 32 B of mask bits read "
+                        "and 512 B of dZ written",
+                 "fwd": "tg_mlp_forward_chain (training passes): 64 B read; per stored layer 512 B of activations + 32 B of mask "
+                        "bits written (the first activation is not stored)"}
+        for fam, ls in fam_launches.items():
+            if not ls:
+                continue
+            dur = sum(d for d, _, _, _ in ls) * 1e-3
+            nbytes = sum(b for _, b, _, _ in ls)
+            nrows = sum(r for _, _, r, _ in ls)
             ach = nbytes / dur / 1e9
-            # PMC traffic of the 2^22-row probe launch (profiles/r01_dx_kernel_probe_pmc.json), scaled to the average launch
-            traffic = BWD_PMC_BYTES_PER_ROW * nrows / len(dx_launches) if "bwd_chain" in dx_launches[0][3] else None
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic,
-                               "traffic_source": "profiles/r01_bwd_chain_probe_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE = 2737 B/row "
-                                                 "(1.001 x algorithmic), times this run's average rows per launch",
-                               "kernel": dx_launches[0][3], "bytes_per_row": nbytes / nrows,
-                               "launches": len(dx_launches), "avg_launch_ms": 1e3 * dur / len(dx_launches),
-                               "avg_rows_per_launch": nrows / len(dx_launches),
-                               "TFLOPs": 2.0 * 256 * 256 * nrows / dur / 1e12,
-                               "note": "dominant kernel by GPU time; every launch of the timed steps, HIP events on the launch stream"}
+            pmc, src = _pmc_bytes_per_row(fam)
+            kernels[fam] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": pmc * nrows / len(ls) if pmc else None,
+                            "traffic_source": f"profiles/{src}: 2 x FETCH_SIZE + WRITE_SIZE per row of the 2^22-row probe, times "
+                                              "this run's average rows per launch" if pmc else None,
+                            "kernel": ls[0][3], "bytes_per_row": nbytes / nrows, "launches": len(ls),
+                            "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
+                            "total_ms_per_step": 1e3 * dur / args.steps, "note": notes[fam]}
+        if kernels:
+            top = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
+            out["roofline"] = dict(kernels[top], family=top,
+                                   why="the hand-written kernel family with the most GPU time in the step")
+            out["kernels"] = kernels
         elif "rollout_kernel" in out:
             out["roofline"] = out["rollout_kernel"]
         out["dynamics_kernel"] = dyn
-        out["learner_kernel"] = relu_probe
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

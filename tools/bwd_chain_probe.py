@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the learner's backward pass on the bench's actor shape: tg_mlp_backward_chain (all hidden layers' dZ in one
-launch) against the per-layer kernels (tg_head_bwd_relu_bias + tg_dx_relu_bias), weight gradients excluded."""
+launch), as the learner runs it: no bias column sums (tg_mlp_weight_grad forms them); --bias times the variant with them."""
 import argparse
 import json
 import os
@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, nargs="+", default=[1 << 20, 1 << 22])
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--bias", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = N.load()
@@ -38,7 +39,7 @@ def main():
         m_ptrs = (N.C.c_void_p * nh)(*[bits[nh - j].data_ptr() for j in range(nh)])
         st = N.stream_ptr(dev)
         run = lambda: N.check(lib.tg_mlp_backward_chain(dzh.data_ptr(), mlp._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
-                                                        part.data_ptr(), st))
+                                                        part.data_ptr() if a.bias else None, st))
         for _ in range(2):
             run()
         torch.cuda.synchronize()
@@ -50,7 +51,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / a.iters * 1e3
         bpr = 16 + nh * (H // 8 + 2 * H)
-        res.append({"rows": rows, "chain_us": us, "bytes_per_row": bpr, "GBps": bpr * rows / us / 1e3,
+        res.append({"rows": rows, "bias_sums": bool(a.bias), "chain_us": us, "bytes_per_row": bpr, "GBps": bpr * rows / us / 1e3,
                     "frac_of_8TBps": bpr * rows / us / 1e3 / 8000, "TFLOPs": 2.0 * rows * (32 * H + (nh - 1) * H * H) / us / 1e6})
     print(json.dumps(res))
 

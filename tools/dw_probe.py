@@ -1,5 +1,7 @@
 """Times tg_mlp_weight_grad (all weight gradients of one net in one launch) at the C3 shape against the split-K batched
-GEMM path it replaces.  Prints one JSON line.  usage: python tools/dw_probe.py [rows] [H] [hidden layers] [recompute]"""
+GEMM path it replaces.  Prints one JSON line.
+usage: python tools/dw_probe.py [--rows N] [--hidden H] [--layers L] [--no-recompute] [--iters K] [--no-gemm]"""
+import argparse
 import json
 import os
 import sys
@@ -11,10 +13,15 @@ import trajopt_grpo_amd as tg
 from trajopt_grpo_amd import _native as N
 from trajopt_grpo_amd import mlp as M
 
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
-H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-nh = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-recompute = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1 << 22)
+ap.add_argument("--hidden", type=int, default=256)
+ap.add_argument("--layers", type=int, default=5)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--no-recompute", action="store_true", help="read the stored first activation (kind HH) instead of recomputing it (HR)")
+ap.add_argument("--no-gemm", action="store_true", help="skip the split-K GEMM comparison (profiling runs)")
+a_ = ap.parse_args()
+rows, H, nh, recompute = a_.rows, a_.hidden, a_.layers, 0 if a_.no_recompute else 1
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = tg.NeuralNetwork(20, 4, (H,) * nh, "ReLU").to(dev)
@@ -51,7 +58,7 @@ def gemms():
         mlp._dw_into(lin[i].weight.grad, dzs[i], acts[i])
 
 
-def timeit(fn, n=10):
+def timeit(fn, n=a_.iters):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -68,7 +75,8 @@ def timeit(fn, n=10):
 t = {"tg_mlp_weight_grad": [], "split_k_gemms": []}
 for _ in range(2):
     t["tg_mlp_weight_grad"].append(timeit(ours))
-    t["split_k_gemms"].append(timeit(gemms))
+    if not a_.no_gemm:
+        t["split_k_gemms"].append(timeit(gemms))
 # correctness at this size: one layer against an fp32 GEMM of the same operands
 for p in net.parameters():
     p.grad.zero_()
@@ -78,5 +86,5 @@ err = float((lin[2].weight.grad - ref).norm() / ref.norm())
 ms = min(t["tg_mlp_weight_grad"])
 print(json.dumps({"rows": rows, "H": H, "hidden_layers": nh, "recompute_first_activation": bool(recompute), "bytes_per_row": bytes_per_row,
                   "ms": t, "GBps": bytes_per_row * rows / ms / 1e6, "frac_of_8TBps": bytes_per_row * rows / ms / 1e6 / 8000.0,
-                  "gemm_GBps": (bytes_per_row + (448 if recompute else 0)) * rows / min(t["split_k_gemms"]) / 1e6,
+                  "gemm_GBps": (bytes_per_row + (448 if recompute else 0)) * rows / min(t["split_k_gemms"]) / 1e6 if t["split_k_gemms"] else None,
                   "rel_err_layer2_vs_fp32_gemm": err}))

@@ -51,7 +51,12 @@ def main():
             out[f"chain_{k}_us"], out[f"layers_{k}_us"] = t_c, t_l
             out[f"chain_{k}_TFLOPs"] = flop_row * rows / t_c / 1e6
             if keep:
-                out["chain_keep_write_GBps"] = rows * (L * H * 2 + 32) / t_c / 1e3
+                # as the learner runs it: the first activation is not stored (tg_mlp_weight_grad recomputes it)
+                stored = sum(1 for t in mlp._acts[1:] if t is not None)
+                bpr = 64 + stored * 2 * H + L * (H // 8) + 32
+                out["bytes_per_row"], out["stored_activations"] = bpr, stored
+                out["chain_keep_GBps"] = rows * bpr / t_c / 1e3
+                out["chain_keep_frac_of_8TBps"] = rows * bpr / t_c / 1e3 / 8000
         res.append(out)
     print(json.dumps(res))
 

@@ -115,8 +115,9 @@ class GemmMLP:
         self._dx_partial = None
         self._head_partial = None
         self._dw_ws = None
-        # like dx_events, for every tg_mlp_weight_grad launch
+        # like dx_events, for every tg_mlp_weight_grad launch / every training (keep=True) tg_mlp_forward_chain launch
         self.dw_events = None
+        self.fwd_events = None
         # when set to a list, every backward-data launch (tg_mlp_backward_chain or tg_dx_relu_bias) is bracketed by HIP
         # events on the launch stream and (start, end, rows, algorithmic bytes per row, kernel name) is appended
         # (bench.py reads them back for that kernel's roofline)
@@ -185,9 +186,18 @@ class GemmMLP:
             out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
             ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid]) if keep else None
             mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
+            ev = None
+            if keep and self.fwd_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
                                                   L - 1, rows, ptrs, mptrs, out.data_ptr(), self.out_pad,
                                                   N.stream_ptr(xp.device)), "tg_mlp_forward_chain")
+            if ev is not None:
+                ev[1].record()
+                stored = sum(1 for t in hid if t is not None)
+                self.fwd_events.append((ev[0], ev[1], rows, 2 * self.in_pad + stored * 2 * H + (L - 1) * (H // 8) + 4 * self.out_pad,
+                                        f"tg::mlp_fwd_chain_kernel<{H},8,true,4,{'true' if stored == L - 1 else 'false'}>"))
             self._acts = [xp] + hid if keep else None
             self._bits = [None] + bits if keep else None
             return out if padded else out[:, :self.out_dim].contiguous()
