@@ -104,9 +104,24 @@ def _cpu_leg(T, updates, workers, episodes):
             "rollout_value": steps / t_roll}
 
 
-def _cpu_leg_pinned(q, T, updates, cores, episodes):
-    os.sched_setaffinity(0, cores)
-    q.put(_cpu_leg(T, updates, len(cores), episodes))
+def _in_child(q, fn, cores, *a):
+    if cores is not None:
+        os.sched_setaffinity(0, cores)
+    q.put(fn(*a))
+
+
+def _run_in_forked_child(fn, cores, *a):
+    """A leg that runs multi-threaded torch code must not share a process with a later fork (a forked child of a
+    process whose OpenMP pool is up deadlocks in its first parallel region): every secondary leg gets a child of its
+    own, forked while this process is still single-threaded."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_in_child, args=(q, fn, cores) + a)
+    p.start()
+    out = q.get()
+    p.join()
+    return out
 
 
 def _cpu_leg_c1():
@@ -135,18 +150,12 @@ def _cpu_leg_c1():
 
 
 def cpu_baseline(T, updates):
-    import multiprocessing as mp
     cores = sorted(os.sched_getaffinity(0))
-    main_leg = _cpu_leg(T, updates, max(1, min(len(cores), 16)), 32)
     legs = {}
     if len(cores) >= 8:
-        ctx = mp.get_context("fork")
-        q = ctx.Queue()
-        p = ctx.Process(target=_cpu_leg_pinned, args=(q, T, updates, set(cores[:8]), 16))
-        p.start()
-        legs["pinned_8_cores"] = q.get()
-        p.join()
-    legs["c1_exact"] = _cpu_leg_c1()
+        legs["pinned_8_cores"] = _run_in_forked_child(_cpu_leg, set(cores[:8]), T, updates, 8, 16)
+    legs["c1_exact"] = _run_in_forked_child(_cpu_leg_c1, None)
+    main_leg = _cpu_leg(T, updates, max(1, min(len(cores), 16)), 32)      # last: it brings up this process's thread pool
     main_leg["legs"] = legs
     return main_leg
 
@@ -266,9 +275,15 @@ def main():
     envs_local = G_local * E
     updates = args.updates if args.updates is not None else (32 if algo_name == "ppo" else 10)
 
+    def progress(msg):                       # stderr only: the JSON line is the one thing on stdout
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
+        progress("cpu baseline (3 legs, ~40 s) ...")
         cpu = cpu_baseline(args.horizon, 32)
+        progress(f"cpu baseline: {cpu['value']:.0f} env-steps/s on {cpu['cores']} cores")
 
     import torch
     import torch.distributed as dist
@@ -319,9 +334,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         buf.sample()
         algo.learn(buf)
+        progress(f"warm-up step {i + 1}/{args.warmup}")
     # event-pair overhead (no kernel in between), for the per-launch timing below
     pairs = []
     for _ in range(200):
@@ -360,6 +376,8 @@ def main():
         algo.learn(buf)
         torch.cuda.synchronize()            # (learn's last kernels; the next rollout would wait for them anyway)
         t_learn += time.perf_counter() - r1
+        if (_ + 1) % 5 == 0:
+            progress(f"step {_ + 1}/{args.steps}")
     barrier()
     dt = time.perf_counter() - t0
 
@@ -370,6 +388,7 @@ def main():
             setattr(m, attr, None)
 
     # ---- fixed work: one step with nobody terminating (every env runs the whole horizon) ----
+    progress(f"timed region done: {1e3 * dt / args.steps:.0f} ms/step")
     fixed = None
     if not args.no_fixed_work and hasattr(make_env(), "spatial_bounds"):
         mgr_open = tg.RolloutManager(lambda: make_env(True), policy, restart=restart, num_workers=G_global,

@@ -44,6 +44,7 @@ def main():
         for keep in (True, False):
             chain = mlp._chain
             t_c = timed(lambda: mlp.forward(xp, keep=keep, padded=True), a.iters)
+            stored = sum(1 for t in (mlp._acts or [None])[1:] if t is not None)
             mlp._chain = None
             t_l = timed(lambda: mlp.forward(xp, keep=keep, padded=True), a.iters)
             mlp._chain = chain
@@ -52,7 +53,6 @@ def main():
             out[f"chain_{k}_TFLOPs"] = flop_row * rows / t_c / 1e6
             if keep:
                 # as the learner runs it: the first activation is not stored (tg_mlp_weight_grad recomputes it)
-                stored = sum(1 for t in mlp._acts[1:] if t is not None)
                 bpr = 64 + stored * 2 * H + L * (H // 8) + 32
                 out["bytes_per_row"], out["stored_activations"] = bpr, stored
                 out["chain_keep_GBps"] = rows * bpr / t_c / 1e3
