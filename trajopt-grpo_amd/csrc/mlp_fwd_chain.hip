@@ -73,19 +73,28 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
 // (feature r in dword r>>1, half r&1); the result has bit k (even features 2k) and bit 16+k (odd features 2k+1), k < 8.
 __device__ static inline uint32_t tile_mask_bits(bf16x8 lo, bf16x8 hi) {
     const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
-    const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const uint32_t one = 0x00010001u;
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit, shifted
-        // into place and merged by one v_lshl_or_b32.  (Inline assembly: from the C form hipcc makes two compares +
-        // selects per dword and separate shift / or instructions.)
-        uint32_t y, mo;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(d[k]), "v"(one));
-        asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(mo) : "v"(y), "n"(k), "v"(m));
-        m = mo;
-    }
+    // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit, shifted into place
+    // and merged by one v_lshl_or_b32: 16 instructions per tile.  ONE asm statement: hipcc pads every statement boundary with
+    // an s_nop (8 statements per tile cost as many issue slots as the arithmetic: the mask bits were 16 % of this kernel),
+    // and from the C form it makes two compares + selects per dword.  Plain VALU -> VALU dependences need no wait states.
+    uint32_t m, t0, t1;
+    asm("v_pk_min_u16 %0, %3, %11\n\t"
+        "v_pk_min_u16 %1, %4, %11\n\t"
+        "v_pk_min_u16 %2, %5, %11\n\t"
+        "v_lshl_or_b32 %0, %1, 1, %0\n\t"
+        "v_pk_min_u16 %1, %6, %11\n\t"
+        "v_lshl_or_b32 %0, %2, 2, %0\n\t"
+        "v_pk_min_u16 %2, %7, %11\n\t"
+        "v_lshl_or_b32 %0, %1, 3, %0\n\t"
+        "v_pk_min_u16 %1, %8, %11\n\t"
+        "v_lshl_or_b32 %0, %2, 4, %0\n\t"
+        "v_pk_min_u16 %2, %9, %11\n\t"
+        "v_lshl_or_b32 %0, %1, 5, %0\n\t"
+        "v_pk_min_u16 %1, %10, %11\n\t"
+        "v_lshl_or_b32 %0, %2, 6, %0\n\t"
+        "v_lshl_or_b32 %0, %1, 7, %0"
+        : "=&v"(m), "=&v"(t0), "=&v"(t1)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(0x00010001u));
     return m;
 }
 
