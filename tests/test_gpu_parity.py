@@ -890,6 +890,29 @@ def test_fused_rollout_matches_unfused_path(tg, dev, name, hidden):
     mean0 = pol.actor(fo[:, 0, :].t()).detach()
     z = ((fa[:, 0, :].t() - mean0) / std).cpu().numpy()
     assert abs(z.mean()) < 0.15 and 0.8 < z.std() < 1.2
+    # (5) the actor at LATER steps, on the states the fused kernel itself reached: its recorded action must be the GEMM path's
+    #     mean of the recorded observation plus sigma x the Philox draw of (env, t).  The draw is read back from the step kernel
+    #     (mean 0, sigma 1 on a scratch engine with the same seed and stream id: the action it records IS eps).
+    import ctypes as C
+    Nn = tg._native
+    scratch = tg.DeviceRollout(mk(), pol, G, Eps, seed=21, compute_dtype=torch.bfloat16, fused=False)
+    scratch._seed_host, scratch._stream_host = 21, 0
+    zeros, ones = torch.zeros(G * Eps, A, device=dev), (C.c_float * A)(*([1.0] * A))
+    from trajopt_grpo_amd.mlp import GemmMLP
+    mlp = GemmMLP(pol.actor, torch.bfloat16)
+    for t in (1, 7, T // 2, T - 1):
+        alive = fm[t].bool()
+        if int(alive.sum()) == 0:
+            continue
+        scratch._enqueue_prepare(None)
+        Nn.check(Nn.load().tg_rollout_step(C.byref(scratch.params), C.byref(scratch.traj.native()), t, zeros.data_ptr(), A, ones,
+                                           scratch.rng.data_ptr(), 0, Nn.stream_ptr(dev)), "tg_rollout_step")
+        eps_t = scratch.traj.act[:, t, :].t()                                   # [n][A]
+        mean_t = mlp.forward(mlp.prepare_input(fo[:, t, :].t()), keep=False)    # GEMM-path actor on the fused kernel's own states
+        want = mean_t + std * eps_t
+        d = (fa[:, t, :].t() - want)[alive]
+        assert float(d.abs().max()) < 0.03 * max(1.0, float(want[alive].abs().max())), (t, float(d.abs().max()))
+        assert float(d.abs().mean()) < 5e-3, (t, float(d.abs().mean()))
 
 
 @pytest.mark.parametrize("name,hidden", [("CartPole", (128, 128)), ("CartPole", (128, 128, 128, 128)), ("QuadPole2D", (128, 128, 128)),

@@ -53,20 +53,40 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__
     float next_v_m = 0.0f;   // V[t+1] * m[t+1]
     float next_a_m = 0.0f;   // (gamma*lam*A[t+1]) * m[t+1]
     const float gl = rn_mul(gamma, lam);
-    for (int32_t t = T - 1; t >= 0; --t) {
-        const int64_t idx = (int64_t)t * n + i;
-        const float r = rew[idx], v = val[idx], mf = (float)mask[idx];
-        float a;
-        if (t == T - 1) {
-            a = rn_sub(r, v);
-        } else {
-            const float delta = rn_sub(rn_add(r, rn_mul(gamma, next_v_m)), v);
-            a = rn_add(delta, next_a_m);
+    // same walk as rtg_scan_kernel: kChunk time steps of independent loads in flight per lane, then the serial recurrence
+    // over them in the reference's order (one dependent HBM round trip per time step otherwise)
+    for (int32_t t_hi = T; t_hi > 0; t_hi -= kChunk) {
+        const int32_t cnt = t_hi < kChunk ? t_hi : kChunk;
+        float r[kChunk], v[kChunk];
+        uint8_t m[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            if (k < cnt) {
+                const int64_t idx = (int64_t)(t_hi - 1 - k) * n + i;
+                r[k] = rew[idx];
+                v[k] = val[idx];
+                m[k] = mask[idx];
+            }
         }
-        adv[idx] = a;
-        ret[idx] = rn_add(v, a);
-        next_v_m = rn_mul(v, mf);
-        next_a_m = rn_mul(rn_mul(gl, a), mf);
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            if (k < cnt) {
+                const int32_t t = t_hi - 1 - k;
+                const int64_t idx = (int64_t)t * n + i;
+                const float mf = (float)m[k];
+                float a;
+                if (t == T - 1) {
+                    a = rn_sub(r[k], v[k]);
+                } else {
+                    const float delta = rn_sub(rn_add(r[k], rn_mul(gamma, next_v_m)), v[k]);
+                    a = rn_add(delta, next_a_m);
+                }
+                adv[idx] = a;
+                ret[idx] = rn_add(v[k], a);
+                next_v_m = rn_mul(v[k], mf);
+                next_a_m = rn_mul(rn_mul(gl, a), mf);
+            }
+        }
     }
 }
 
