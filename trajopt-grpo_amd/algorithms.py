@@ -12,7 +12,7 @@ Mirrors algorithms/algorithm.py:3-35, algorithms/grpo.py:12-169 and algorithms/p
     fixed-covariance Gaussian is a constant (zero gradient).
 What changes is where it runs: RTG / moments / normalisation / log-prob / the loss head are HIP
 kernels over the device trajectory; the MLP forward/backward run through mlp.GemmMLP (forward chain
-kernel, fused backward-data kernel, batched weight-gradient GEMMs); gradients of all ranks are summed
+kernel, backward-data chain kernel, weight-gradient kernel); gradients of all ranks are summed
 with ONE flat all-reduce per optimizer step.
 """
 from __future__ import annotations

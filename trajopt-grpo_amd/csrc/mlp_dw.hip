@@ -11,9 +11,10 @@
 //     waves) while the rows stream past; the CUs are split between the jobs in proportion to their bytes per row, so
 //     all finish together and there are ~50 partial gradients ("slabs") per layer instead of one per CU and layer;
 //   * 32-row stages of both operands flow HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging) through a
-//     ring of 4 slots with 3 stages in flight (96 KiB per CU): counted `s_waitcnt vmcnt`, raw `s_barrier` (see
-//     mfma_ring.hpp).  Every stage issues the same number of DMA instructions per wave -- stages past the end re-read the
-//     last row -- so the count is a compile-time constant;
+//     ring sized per job kind (DwRing: 4 slots x 32 KiB for the H x H jobs, 7-8 x 18 KiB for the narrow ones, so that every
+//     CU keeps ~100 KB in flight): counted `s_waitcnt vmcnt`, raw `s_barrier` (see mfma_ring.hpp).  Every stage issues the
+//     same number of DMA instructions per wave -- stages past the end re-read the last row -- so the count is a
+//     compile-time constant;
 //   * the contraction runs over ROWS, which are the slow axis of both operands in memory: the fragments come out of
 //     LDS through the transposing read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16 lanes, delivered column-major).
 //     The LDS image of a panel is [row / 4][32-column group][row % 4][64 B]: a 32-lane half of a transposed read then
@@ -21,9 +22,9 @@
 //   * bias gradients ride along: one extra MFMA per k-step multiplies the dZ fragment with a matrix of ones (the
 //     matrix pipe is ~1/3 busy in this kernel; on the vector ALU the same sums cost the backward chain 10 %);
 //   * the first hidden layer's activations are not read at all (kind HR): they are a function of the 64-B input row,
-//     so the workgroup recomputes the stage's 32 x H tile (2 MFMAs per wave, same instruction sequence as the forward
-//     chain: identical bits) straight into the LDS image -- 576 instead of 1024 B per row for that layer, and the
-//     forward pass no longer has to write them;
+//     so the workgroup recomputes each stage's 32 x H tile (2 MFMAs per wave, same instruction sequence as the forward
+//     chain: identical bits) one stage ahead of its use, straight into the LDS image of a Q panel -- 576 instead of
+//     1024 B per row for that layer, and the forward pass no longer has to write them;
 //   * rows past the end: their (clamped, finite) data is multiplied by zeros -- the dZ fragments of the last stage are
 //     masked in registers;
 //   * a second small kernel adds the slabs in a fixed order straight into the gradient windows (the learner's flat

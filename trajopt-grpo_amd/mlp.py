@@ -11,8 +11,12 @@ minimises bytes per row:
   * backward data: tg_dx_relu_bias fuses `dA = dZ W` with the ReLU backward and bias gradient of the layer below
     (1.5 instead of 2.5 KB/row) for square bf16 layers of width 64 / 128 / 256; the head's rank-A product is
     formed inside the top layer's pass (tg_head_bwd_relu_bias); otherwise a GEMM + tg_relu_bwd_bias;
-  * weight gradients: dW = dZ^T A is a [256 x rows] x [rows x 256] GEMM -- 16 output tiles on 256 CUs without split-K
-    (1.6-1.9 ms per 2^20 rows): a batched GEMM over row blocks with fp32 partials plus one small reduction instead.
+  * backward data, chain shapes (bf16, H in {128, 256}, 3..6 hidden layers, <= 8 outputs): tg_mlp_backward_chain, the dZ of
+    all hidden layers in one launch (2.7 KB/row at 5 x 256);
+  * weight gradients, chain shapes: tg_mlp_weight_grad -- every weight and hidden bias gradient of the net in ONE persistent
+    launch (each dZ and activation read once, the first hidden activation recomputed from the input row instead of stored);
+    other shapes: dW = dZ^T A as a batched GEMM over row blocks with fp32 partials plus tg_dw_finish (a plain GEMM has 16
+    output tiles on 256 CUs: 1.6-1.9 ms per 2^20 rows).
 Gradients are accumulated in fp32 straight into `param.grad` (the learner's flat all-reduce bucket).
 
 Only ReLU hidden activations take this path; anything else stays on torch autograd.
