@@ -22,7 +22,7 @@
 //   * bias gradients ride along: one extra MFMA per k-step multiplies the dZ fragment with a matrix of ones (the
 //     matrix pipe is ~1/3 busy in this kernel; on the vector ALU the same sums cost the backward chain 10 %);
 //   * the first hidden layer's activations are not read at all (kind HR): they are a function of the 64-B input row,
-//     so the workgroup recomputes each stage's 32 x H tile (2 MFMAs per wave, same instruction sequence as the forward
+//     so the workgroup recomputes each stage's 32 x H tile (4 small MFMAs per wave, same instruction sequence as the forward
 //     chain: identical bits) one stage ahead of its use, straight into the LDS image of a Q panel -- 576 instead of
 //     1024 B per row for that layer, and the forward pass no longer has to write them;
 //   * rows past the end: their (clamped, finite) data is multiplied by zeros -- the dZ fragments of the last stage are
@@ -200,15 +200,19 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    // HR: this wave's 32 first-layer features (tile `wave`): weight fragments + bias in registers
+    // HR: this wave's 32 first-layer features (block `wave`): weight fragments + bias in registers, in the forward chain's own
+    // layout (mlp.FragmentStream(layout="chain"): v_mfma_f32_16x16x32_bf16, half f of lane (i, g) = features 8 (i >> 2) + 4 f + (i & 3))
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     bf16x8 w0[2] = {};
-    f32x16 b0v = {};
+    f32x4 b0v[2] = {};
     if constexpr (KIND == DW_HR) {
         if (wave < NT) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) w0[ks] = __builtin_bit_cast(bf16x8, args.w0frag[(wave * 2 + ks) * 64 + lane]);
+            for (int f = 0; f < 2; ++f) {
+                w0[f] = __builtin_bit_cast(bf16x8, args.w0frag[(wave * 2 + f) * 64 + lane]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b0v[r] = args.b0[32 * wave + 16 * h + r];
+                for (int r = 0; r < 4; ++r) b0v[f][r] = args.b0[32 * wave + 8 * (lane >> 4) + 4 * f + r];
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ordinary loads: none may be counted in the ring
     }
@@ -227,18 +231,17 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
     // the recompute's dependent chain -- LDS read, 2 MFMAs, pack, LDS write -- hides behind them; no second barrier)
     auto recompute_a0 = [&](const char* sb, char* qt) {
         if (wave < NT) {
-            const int row = lane & 31;
-            f32x16 t = b0v;
+            const int col16 = lane & 15, grp = lane >> 4;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + R::Q_OFF + row * 64 + 32 * ks + 16 * h));
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xb, t, 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                const int row = 16 * c + col16;
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + R::Q_OFF + row * 64 + 16 * grp));
+                // one k-step (K = 32), bias as the initial accumulator: the forward chain's first layer, instruction for instruction
+                const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0], xb, b0v[0], 0, 0, 0);
+                const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1], xb, b0v[1], 0, 0, 0);
+                const bf16x8 o = relu_pack_bf16(t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]);
+                lds_store16(qt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 16 * grp, __builtin_bit_cast(uint4, o));
             }
-            const bf16x8 lo = relu_pack_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
-            const bf16x8 hi = relu_pack_bf16(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
-            char* dst = qt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 32 * h;
-            lds_store16(dst, __builtin_bit_cast(uint4, lo));
-            lds_store16(dst + 16, __builtin_bit_cast(uint4, hi));
         }
     };
     // stages that must have landed at the top of an iteration: the current one; HR also the next (its x panel is read)

@@ -23,116 +23,114 @@
 
 namespace tg {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kChainMaxHidden = 8;
 struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; };   // activations, ReLU mask bits (or null)
 
-// Accumulator start values = the tile's 32 biases (LDS table), 16 per lane half.  `__restrict__` on an inlined
-// function's pointer parameters is what gives its LDS reads alias-scope metadata; hipcc makes an LDS read WITHOUT it
-// wait for every outstanding LDS-DMA (vmcnt(0)), which would drain the weight ring at each block.
-__device__ static inline f32x16 bias_tile(const float* __restrict__ b16) {
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(b16 + 4 * q);
-        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-    }
-    return acc;
-}
-
-// Activation stores.  After two output tiles a lane (n, h) holds 4 x 16 B of row n's 128-B line (tile t, half h, 16-B
-// piece sh at byte 64 t + 32 h + 16 sh).  Stored as they stand an instruction would write 32 rows x 32 B, and that
-// pattern alone caps at 4.1 TB/s on this chip; so the wave transposes the 32 x 128 B through its LDS staging area
-// (XOR-swizzled chunks: conflict-free both ways) and each of its 4 store instructions writes 8 WHOLE 128-B lines
-// (5.1 TB/s for the same bytes).  `__restrict__`: see bias_tile.  Rows past the end are clamped: the lanes that
-// computed them worked on the last row's input, so they rewrite the last row with identical bytes.
-__device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
-                                         int lane, bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi) {
-    // staging image: 32 rows x 8 chunks of 16 B, chunk c of row n at n*8 + (c ^ ((n>>1)&7)): conflict-free b128 writes
-    // (16 lanes = 16 rows, same chunk: row parity x swizzled chunk are 16 different bank groups) and reads (8 lanes per
-    // row, two rows of opposite parity per 16-lane pass)
-    const int n = lane & 31, sw = (n >> 1) & 7, c0 = 2 * (lane >> 5);
-    uint4* w = st + n * 8;
-    w[(c0 + 0) ^ sw] = __builtin_bit_cast(uint4, a_lo);
-    w[(c0 + 1) ^ sw] = __builtin_bit_cast(uint4, a_hi);
-    w[(c0 + 4) ^ sw] = __builtin_bit_cast(uint4, b_lo);
-    w[(c0 + 5) ^ sw] = __builtin_bit_cast(uint4, b_hi);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 8 * j + (lane >> 3), c = lane & 7;
-        const uint4 v = st[r * 8 + (c ^ ((r >> 1) & 7))];
-        int64_t row = row0 + r;
-        row = row < rows ? row : rows - 1;
-        // non-temporal: written once, read by a later kernel (A/B: 2.96 -> 2.91 ms per 2^22 rows)
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * c));
-    }
-}
-
-// ReLU masks for the backward pass, 1 bit per activation (the backward-data kernels only need `activation > 0`: 32 B per
-// row instead of re-reading the 512-B activation row).  `lo`/`hi` are a lane's 16 post-ReLU features of one tile
-// (feature r in dword r>>1, half r&1); the result has bit k (even features 2k) and bit 16+k (odd features 2k+1), k < 8.
-__device__ static inline uint32_t tile_mask_bits(bf16x8 lo, bf16x8 hi) {
-    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
-    // post-ReLU bf16 is +0 or positive: nonzero bits <=> positive; min(x, 1) per 16-bit half is that bit, shifted into place
-    // and merged by one v_lshl_or_b32: 16 instructions per tile.  ONE asm statement: hipcc pads every statement boundary with
-    // an s_nop (8 statements per tile cost as many issue slots as the arithmetic: the mask bits were 16 % of this kernel),
-    // and from the C form it makes two compares + selects per dword.  Plain VALU -> VALU dependences need no wait states.
-    uint32_t m, t0, t1;
-    asm("v_pk_min_u16 %0, %3, %11\n\t"
-        "v_pk_min_u16 %1, %4, %11\n\t"
-        "v_pk_min_u16 %2, %5, %11\n\t"
-        "v_lshl_or_b32 %0, %1, 1, %0\n\t"
-        "v_pk_min_u16 %1, %6, %11\n\t"
-        "v_lshl_or_b32 %0, %2, 2, %0\n\t"
-        "v_pk_min_u16 %2, %7, %11\n\t"
-        "v_lshl_or_b32 %0, %1, 3, %0\n\t"
-        "v_pk_min_u16 %1, %8, %11\n\t"
-        "v_lshl_or_b32 %0, %2, 4, %0\n\t"
-        "v_pk_min_u16 %2, %9, %11\n\t"
-        "v_lshl_or_b32 %0, %1, 5, %0\n\t"
-        "v_pk_min_u16 %1, %10, %11\n\t"
-        "v_lshl_or_b32 %0, %2, 6, %0\n\t"
-        "v_lshl_or_b32 %0, %1, 7, %0"
-        : "=&v"(m), "=&v"(t0), "=&v"(t1)
-        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(0x00010001u));
-    return m;
-}
-
-// Mask word i of lane (n, h) covers tiles 2i (bits 0-7 / 16-23) and 2i+1 (bits 8-15 / 24-31) of a layer's output `x`; a
-// row's mask is [h = 0: MT/2 words][h = 1: MT/2 words] = H bits.  The words of layer l are formed while layer l+1 (or
-// the head) runs its MFMAs -- `x` is that layer's input, the arithmetic hides in the matrix-core issue shadow -- and
-// leave as one store per lane, 1 KiB contiguous per wave at H = 256.
-template <int KS>
-__device__ static inline uint32_t pair_mask_word(const bf16x8 (&x)[KS], int i) {
-    return tile_mask_bits(x[4 * i], x[4 * i + 1]) | (tile_mask_bits(x[4 * i + 2], x[4 * i + 3]) << 8);
-}
-template <int MT>
-__device__ static inline void store_mask_words(uint32_t* __restrict__ g, int64_t row, int h, const uint32_t (&w)[MT / 2]) {
-    uint32_t* p = g + row * MT + h * (MT / 2);
-    if constexpr (MT == 8) *reinterpret_cast<uint4*>(p) = uint4{w[0], w[1], w[2], w[3]};
-    else *reinterpret_cast<uint2*>(p) = uint2{w[0], w[1]};
-}
-
-// One 32-feature output tile of a hidden layer: bias-init, K/16 MFMAs against the block's fragments, ReLU, bf16 pack.
-template <int KS>
-__device__ static inline void chain_tile(const uint4* __restrict__ cur, const float* __restrict__ b16, const bf16x8 (&xin)[KS],
-                                         bf16x8& lo, bf16x8& hi, int lane) {
-    f32x16 acc = bias_tile(b16);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
-    }
-    lo = relu_pack_bf16(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
-    hi = relu_pack_bf16(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
-}
-
-// 16 B from LDS without telling the compiler it is an LDS read (same reason); waits for it itself.
+// 16 B from LDS without telling the compiler it is an LDS read: hipcc makes an LDS read WITHOUT alias-scope metadata wait for
+// every outstanding LDS-DMA (vmcnt(0)), which would drain the weight ring at each block; waits for the read itself.
 __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint4*)p;
     uint4 v;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
     return v;
+}
+// (`__restrict__` on an inlined function's pointer parameters is the other way to give its LDS reads that metadata)
+__device__ static inline float4 lds_float4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+
+// Activation stores.  After two 32-feature blocks a lane (col, g) holds, for each of its two rows (16 c + col), 2 x 16 B of the
+// row's 128-B line (block b of the pair, bytes 64 b + 16 g).  Stored as they stand an instruction would write 16-B pieces;
+// the wave transposes the 32 rows x 128 B through its LDS staging area (chunks XOR-swizzled by the row: conflict-free
+// both ways) and each of its 4 store instructions writes 8 WHOLE 128-B lines (5.1 TB/s against 4.1 for 32-B pieces).
+// Rows past the end are clamped: the lanes that computed them worked on the last row's input, so they rewrite the last row
+// with identical bytes.
+__device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
+                                         int lane, const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+    const int col = lane & 15, grp = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = 16 * c + col, sw = n & 7;
+        st[n * 8 + ((grp + 0) ^ sw)] = __builtin_bit_cast(uint4, a[c]);
+        st[n * 8 + ((grp + 4) ^ sw)] = __builtin_bit_cast(uint4, b[c]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), ch = lane & 7;
+        const uint4 v = st[r * 8 + (ch ^ (r & 7))];
+        int64_t row = row0 + r;
+        row = row < rows ? row : rows - 1;
+        // non-temporal: written once, read by a later kernel (A/B: 2.96 -> 2.91 ms per 2^22 rows)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * ch));
+    }
+}
+
+// ReLU masks for the backward pass, 1 bit per activation (the backward-data kernels only need `activation > 0`: 32 B per
+// row instead of re-reading the 512-B activation row).  Memory layout per row: [half h = 0, 1][H / 64 words]; feature
+// 32 mt + 16 h + r is bit (mt & 1) * 8 + (r >> 1) + 16 * (r & 1) of word mt >> 1 of half h.  Lane (col, g) holds the features
+// 32 mt + 8 g + e (e = 0..7) of its two rows, i.e. h = g >> 1, r = 8 (g & 1) + e: dword d of a packed block holds e = 2 d (low
+// half) and 2 d + 1 (high half), so min(x, 1) per 16-bit half (post-ReLU bf16 is +0 or positive: nonzero bits <=> positive)
+// shifted left by (mt & 1) * 8 + 4 (g & 1) + d lands both bits.  `block_bits` leaves out the lane's 4 (g & 1).
+// ONE asm statement per block: hipcc pads every statement boundary with an s_nop, and from the C form it makes two compares
+// + selects per dword.  Plain VALU -> VALU dependences need no wait states.
+__device__ static inline uint32_t block_bits(bf16x8 x) {
+    const uint4 a = __builtin_bit_cast(uint4, x);
+    uint32_t m, t0;
+    asm("v_pk_min_u16 %0, %2, %6\n\t"
+        "v_pk_min_u16 %1, %3, %6\n\t"
+        "v_lshl_or_b32 %0, %1, 1, %0\n\t"
+        "v_pk_min_u16 %1, %4, %6\n\t"
+        "v_lshl_or_b32 %0, %1, 2, %0\n\t"
+        "v_pk_min_u16 %1, %5, %6\n\t"
+        "v_lshl_or_b32 %0, %1, 3, %0"
+        : "=&v"(m), "=&v"(t0)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(0x00010001u));
+    return m;
+}
+// word w of a lane's half-row: blocks 2 w (bits 0-3 / 16-19, + the lane's nibble) and 2 w + 1 (bits 8-11 / 24-27)
+__device__ static inline uint32_t pair_mask_word(const bf16x8* x, int w, int nibble) {
+    return (block_bits(x[2 * w]) | (block_bits(x[2 * w + 1]) << 8)) << nibble;
+}
+// The two lanes (g, g ^ 1) of a row own interleaved nibbles of the same words: one exchange (lane ^ 16, no LDS access), one OR,
+// and the even lane stores the half-row's MT / 2 words.
+template <int MT>
+__device__ static inline void store_mask_words(uint32_t* __restrict__ g, int64_t row, int grp, const uint32_t (&w)[MT / 2]) {
+    uint32_t full[MT / 2];
+#pragma unroll
+    for (int i = 0; i < MT / 2; ++i) full[i] = w[i] | (uint32_t)__builtin_amdgcn_ds_swizzle((int)w[i], 0x401F);   // xor 0x10
+    if ((grp & 1) == 0) {
+        uint32_t* p = g + row * MT + (grp >> 1) * (MT / 2);
+        if constexpr (MT == 8) *reinterpret_cast<uint4*>(p) = uint4{full[0], full[1], full[2], full[3]};
+        else *reinterpret_cast<uint2*>(p) = uint2{full[0], full[1]};
+    }
+}
+
+// One 32-feature output block of a hidden layer for the wave's 2 x 16 rows: bias-init, H / 32 k-steps of 2 x 2
+// v_mfma_f32_16x16x32_bf16 against the block's fragments, ReLU, bf16 pack.  (This shape, not 32x32x16: under the package's
+// power limit the chip holds a higher clock on it -- 1.53 vs 1.40 PFLOP/s in this very loop, tools/mfma_shape_probe.hip.)
+template <int K8>
+__device__ static inline void chain_block(const uint4* __restrict__ cur, const float* __restrict__ b8, const bf16x8 (&xin)[2][K8],
+                                          bf16x8 (&out)[2], int lane) {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const float4 b4 = lds_float4(b8 + 4 * f);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[f][c] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+#pragma unroll
+    for (int ks = 0; ks < K8; ++ks)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(ks * 2 + f) * 64 + lane]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[f][c], 0, 0, 0);
+        }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        out[c] = relu_pack_bf16(acc[0][c][0], acc[0][c][1], acc[0][c][2], acc[0][c][3], acc[1][c][0], acc[1][c][1], acc[1][c][2],
+                                acc[1][c][3]);
 }
 
 __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
@@ -141,16 +139,20 @@ __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
 
 // x [rows][32] bf16 (features >= in_dim zero); acts.p[l] [rows][H] bf16 for hidden layer l (kStore); out f32
 // [rows][out_cols], out_cols in {8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
+// A wave owns 32 rows as two 16-row MFMA column tiles (c = 0, 1): lane (col = lane & 15, g = lane >> 4) holds, per row
+// 16 c + col and 32-feature block, the 8 consecutive features 8 g .. 8 g + 7 -- as accumulators (4 of half f = 0, 4 of f = 1:
+// mlp.FragmentStream arranges the weight rows so), then packed: 16 B that are both the next layer's B operand for k-step =
+// block (natural k order) and a contiguous piece of the activation row.
 template <int H, int WPW, bool kStore, int D, bool kA0>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                                     const float* __restrict__ bias, int32_t n_hh, int64_t rows,
                                                                     ChainActs acts, float* __restrict__ out, int32_t out_cols) {
-    constexpr int MT = H / 32, KS = H / 16;
+    constexpr int MT = H / 32, KS = H / 16, K8 = H / 32;               // blocks per layer, 1-KiB pieces per block, k-steps per block
     constexpr int P = D - 1;
     // counted wait for block c: all but the youngest N vector-memory operations have retired.  Behind DMA(c) there are
-    // always the DMAs of the P-1 later blocks, plus the activation stores of the last P blocks: 4 per ODD output tile
-    // (store_pair), none per even one -- two odd tiles lie behind an even site, one behind an odd site.  (At the layer
-    // boundaries, the first-layer block with its 2 MT stores and the head with its 2-4 only ever add to that.)
+    // always the DMAs of the P-1 later blocks, plus the activation stores of the last P blocks: 4 per ODD output block
+    // (store_pair), none per even one -- two odd blocks lie behind an even site, one behind an odd site.  (At the layer
+    // boundaries, the first-layer block with its 2 MT stores and the head with its 1-2 only ever add to that.)
     static_assert(P % 2 == 1 && P >= 3, "the store counts below are for a window of an odd number of blocks");
     constexpr int kWaitEven = (P - 1) * (KS / WPW) + (kStore ? 4 * ((P + 1) / 2) : 0);
     constexpr int kWaitOdd = (P - 1) * (KS / WPW) + (kStore ? 4 * ((P - 1) / 2) : 0);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 8);    // per wave: 32 rows x 128 B (store_pair)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, col = lane & 31;
+    const int grp = lane >> 4, col = lane & 15;
     const int64_t n_rounds = (rows + 32 * WPW - 1) / (32 * WPW);
     const int n_blocks = n_hh * MT + 2;
 
@@ -198,89 +200,110 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 
     for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
         const int64_t row0 = round * (32 * WPW) + wave * 32;
-        int64_t row = row0 + col;
-        row = row < rows ? row : rows - 1;            // clamped rows recompute and rewrite the last row (identical bytes)
-        bf16x8 xin[KS], xout[KS];
+        int64_t rowc[2];                              // clamped rows recompute and rewrite the last row (identical bytes)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            rowc[c] = row0 + 16 * c + col;
+            rowc[c] = rowc[c] < rows ? rowc[c] : rows - 1;
+        }
+        bf16x8 xin[2][K8], xout[2][K8];
 
-        // ---- layer 0: [H x 32] . [32 x 32 rows]; one block holds all MT output tiles (2 k-steps each) ----
+        // ---- layer 0: [H x 32] . [32 x 32 rows]; one block holds all MT output blocks (one k-step, 2 halves each) ----
         {
             TG_CHAIN_ADVANCE(kWaitOdd)
             // the x tile was issued a full round ago (or in the prologue): it is older than everything the wait let pass
+            bf16x8 x0[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xin[ks] = __builtin_bit_cast(bf16x8, lds_read_b128_opaque(my_xs + col * 4 + 2 * ks + h));
+            for (int c = 0; c < 2; ++c) x0[c] = __builtin_bit_cast(bf16x8, lds_read_b128_opaque(my_xs + (16 * c + col) * 4 + grp));
             dma_x(round + gridDim.x);                 // next round's tile (clamped past the end)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x16 acc = bias_tile(bias_s + 32 * mt + 16 * h);
+                f32x4 acc[2][2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + ks) * 64 + lane]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+                for (int f = 0; f < 2; ++f) {
+                    const float4 b4 = lds_float4(bias_s + 32 * mt + 8 * grp + 4 * f);
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(mt * 2 + f) * 64 + lane]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x0[c], f32x4{b4.x, b4.y, b4.z, b4.w}, 0, 0, 0);
                 }
 #pragma unroll
-                for (int sh = 0; sh < 2; ++sh)
-                    xout[2 * mt + sh] = relu_pack_bf16(acc[8 * sh], acc[8 * sh + 1], acc[8 * sh + 2], acc[8 * sh + 3], acc[8 * sh + 4],
-                                                       acc[8 * sh + 5], acc[8 * sh + 6], acc[8 * sh + 7]);
-                if (kStore && kA0 && (mt & 1))
-                    store_pair(stage, acts.p[0] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1], xout[2 * mt],
-                               xout[2 * mt + 1]);
+                for (int c = 0; c < 2; ++c)
+                    xout[c][mt] = relu_pack_bf16(acc[0][c][0], acc[0][c][1], acc[0][c][2], acc[0][c][3], acc[1][c][0], acc[1][c][1],
+                                                 acc[1][c][2], acc[1][c][3]);
+                if (kStore && kA0 && (mt & 1)) {
+                    const bf16x8 pa[2] = {xout[0][mt - 1], xout[1][mt - 1]}, pb[2] = {xout[0][mt], xout[1][mt]};
+                    store_pair(stage, acts.p[0] + 32 * (mt - 1), row0, rows, H, lane, pa, pb);
+                }
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ks = 0; ks < K8; ++ks) xin[c][ks] = xout[c][ks];
         }
-        // ---- hidden H x H layers: one block per 32-feature output tile ----
+        // ---- hidden H x H layers: one block per 32 output features ----
         for (int l = 0; l < n_hh; ++l) {
-            const float* bl = bias_s + (l + 1) * H + 16 * h;
-            uint32_t mw[MT / 2];
+            const float* bl = bias_s + (l + 1) * H + 8 * grp;
+            uint32_t mw[2][MT / 2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                // (the mask bits of this layer's INPUT, activation l: one word per tile for the first MT/2 tiles, after the
-                // barrier so that the arithmetic sits beside the tile's MFMAs)
+                // (the mask bits of this layer's INPUT, activation l: one word per row tile and block for the first MT blocks'
+                // worth of words, after the barrier so that the arithmetic sits beside the block's MFMAs)
                 if (mt & 1) {
                     if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitOdd) }
-                    TG_RING_NEXT
-                    if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
-                    chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
-                    // (with the mask store one more store sits behind this tile than the wait sites count: stricter, never weaker)
-                    if (kStore && mt == MT / 2 - 1 && acts.m[l]) store_mask_words<MT>(acts.m[l], row, h, mw);
-                    if (kStore)
-                        store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, xout[2 * mt - 2], xout[2 * mt - 1],
-                                   xout[2 * mt], xout[2 * mt + 1]);
                 } else {
                     if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitEven) }
-                    TG_RING_NEXT
-                    if (kStore && mt < MT / 2) mw[mt] = pair_mask_word<KS>(xin, mt);
-                    chain_tile<KS>(cur, bl + 32 * mt, xin, xout[2 * mt], xout[2 * mt + 1], lane);
+                }
+                TG_RING_NEXT
+                if (kStore) {                                          // MT words per lane and layer, one per block
+                    const int q = mt;                                  // (c, word) = (q / (MT/2), q % (MT/2))
+                    mw[q / (MT / 2)][q % (MT / 2)] = pair_mask_word(xin[q / (MT / 2)], q % (MT / 2), 4 * (grp & 1));
+                }
+                bf16x8 o[2];
+                chain_block<K8>(cur, bl + 32 * mt, xin, o, lane);
+                xout[0][mt] = o[0];
+                xout[1][mt] = o[1];
+                if (mt & 1) {
+                    // (with the mask stores more stores sit behind this block than the wait sites count: stricter, never weaker)
+                    if (kStore && mt == MT - 1 && acts.m[l]) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) store_mask_words<MT>(acts.m[l], rowc[c], grp, mw[c]);
+                    }
+                    if (kStore) {
+                        const bf16x8 pa[2] = {xout[0][mt - 1], xout[1][mt - 1]}, pb[2] = {xout[0][mt], xout[1][mt]};
+                        store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, pa, pb);
+                    }
                 }
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xin[ks] = xout[ks];
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ks = 0; ks < K8; ++ks) xin[c][ks] = xout[c][ks];
         }
-        // ---- head: 32 padded output rows; features 0..15 are registers 0..15 of the h == 0 lanes ----
+        // ---- head: <= 16 outputs in half 0 of the block, natural order: register r of lane group g is output 4 g + r ----
         {
             TG_CHAIN_ADVANCE(kWaitEven)
             if (kStore && acts.m[n_hh]) {                       // the last hidden activation's mask bits
-                uint32_t mw[MT / 2];
 #pragma unroll
-                for (int i = 0; i < MT / 2; ++i) mw[i] = pair_mask_word<KS>(xin, i);
-                store_mask_words<MT>(acts.m[n_hh], row, h, mw);
+                for (int c = 0; c < 2; ++c) {
+                    uint32_t mw[MT / 2];
+#pragma unroll
+                    for (int i = 0; i < MT / 2; ++i) mw[i] = pair_mask_word(xin[c], i, 4 * (grp & 1));
+                    store_mask_words<MT>(acts.m[n_hh], rowc[c], grp, mw);
+                }
             }
-            f32x16 acc = bias_tile(bias_s + (n_hh + 1) * H + 16 * h);
+            const float4 b4 = lds_float4(bias_s + (n_hh + 1) * H + 4 * grp);
+            f32x4 acc[2] = {f32x4{b4.x, b4.y, b4.z, b4.w}, f32x4{b4.x, b4.y, b4.z, b4.w}};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, cur[ks * 64 + lane]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < K8; ++ks) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(ks * 2) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[c], 0, 0, 0);
             }
-            // the h == 1 lanes (features 16..31: padding) take their partner's values and write the same bytes again
-            float v[16];
+            if (4 * grp < out_cols) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = __shfl(acc[r], col, 64);
-            float* op = out + row * out_cols;
-            *reinterpret_cast<float4*>(op) = float4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<float4*>(op + 4) = float4{v[4], v[5], v[6], v[7]};
-            if (out_cols == 16) {
-                *reinterpret_cast<float4*>(op + 8) = float4{v[8], v[9], v[10], v[11]};
-                *reinterpret_cast<float4*>(op + 12) = float4{v[12], v[13], v[14], v[15]};
+                for (int c = 0; c < 2; ++c)
+                    *reinterpret_cast<float4*>(out + rowc[c] * out_cols + 4 * grp) = float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
             }
         }
     }

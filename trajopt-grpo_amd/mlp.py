@@ -419,24 +419,32 @@ def _fragment_index(k_pad: int, device):
     return 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
 
 
-def _chain_fragment_index(k_pad: int, device, first: bool):
-    """Same shape for tg_mlp_forward_chain: the first layer reads its input in natural order (16*ks + 8*h + j);
-    later layers take the previous accumulators, whose 16 registers per lane are CONSECUTIVE features there:
-    32*(ks>>1) + 16*h + 8*(ks&1) + j."""
-    ks = torch.arange(k_pad // 16, device=device).view(-1, 1, 1)
-    h = (torch.arange(64, device=device) >> 5).view(1, -1, 1)
-    j = torch.arange(8, device=device).view(1, 1, -1)
-    return 16 * ks + 8 * h + j if first else 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j
+def _chain_fragment_index(k_pad: int, device):
+    """[k_pad/32 k-steps][2 feature halves f][64 lanes][8] -> (row within the 32-row block, column) of W for the chain kernels'
+    `v_mfma_f32_16x16x32_bf16` A fragments.  Lane (i = lane & 15, g = lane >> 4) of half f holds, for k-step ks, the 8 weights
+    W[rowmap(f, i)][32 ks + 8 g + j]: the k order is natural (the B operand of the next layer is the packed accumulator of this
+    one, whose lane (col, g) holds the 8 CONSECUTIVE features 8 g .. 8 g + 7 of a block -- that is what the row map arranges:
+    accumulator register r of lane group g in half f is output feature 8 g + 4 f + r)."""
+    ks = torch.arange(k_pad // 32, device=device).view(-1, 1, 1, 1)
+    f = torch.arange(2, device=device).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=device).view(1, 1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, 1, -1)
+    i = lane & 15
+    chain_row = (8 * (i >> 2) + 4 * f + (i & 3)).expand(k_pad // 32, 2, 64, 8)      # outputs that feed another layer / are stored
+    natural_row = (16 * f + i).expand(k_pad // 32, 2, 64, 8)                          # the forward head: outputs 0..15 in half 0
+    col = (32 * ks + 8 * (lane >> 4) + j).expand(k_pad // 32, 2, 64, 8)
+    return chain_row, natural_row, col
 
 
 class FragmentStream:
-    """bf16 weight stream + f32 bias table in the layout tg_fused_rollout (layout="rollout") or
-    tg_mlp_forward_chain (layout="chain") consumes, refreshed from the fp32 master weights with one gather (the
-    permutation is built once).  Blocks: the first layer's output tiles (2 k-steps each), then one block per
-    32-row output tile of every later layer; a block = its k-steps x 64 lanes x 8 bf16 (1 KiB per k-step).
-    Lane (m, h) of a fragment holds 8 weights of output row `32*tile + row(m)`: row(m) = m for the rollout kernel;
-    for the chain kernel row(m) = 16*((m>>2)&1) + 4*(m>>3) + (m&3), which makes a lane's 16 accumulator registers
-    16 consecutive output features."""
+    """bf16 weight stream + f32 bias table in the layout tg_fused_rollout (layout="rollout", 32x32x16 MFMA) or the chain
+    kernels (layout="chain", 16x16x32 MFMA: tg_mlp_forward_chain, tg_mlp_backward_chain, tg_mlp_weight_grad's recompute)
+    consume, refreshed from the fp32 master weights with one gather (the permutation is built once).
+    rollout: blocks = the first layer's output tiles (2 k-steps each), then one block per 32-row output tile of every later
+      layer; a block = its k-steps x 64 lanes x 8 bf16 (1 KiB per k-step); lane (m, h) holds 8 weights of output row 32*tile + m.
+    chain: every block is H/16 pieces of 1 KiB.  A matrix with K <= 32 (the first layer; the backward stream's W_head^T) is ONE
+      block [output block mt][half f]; a matrix with K = H is one block per 32 output features, [k-step ks][half f]
+      (_chain_fragment_index documents the lane map); the forward head keeps its <= 16 outputs in half 0, natural order."""
 
     def __init__(self, net, H: int, layout: str = "rollout", transposed: bool = False):
         """transposed=True: the stream of the backward chain (tg_mlp_backward_chain): the head first, then the
@@ -448,7 +456,6 @@ class FragmentStream:
         dev = lin[0].weight.device
         self.H = H
         m = torch.arange(64, device=dev) & 31
-        row = (m if layout == "rollout" else 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)).view(1, -1, 1)
         # One gather builds the stream: source = the master weights laid end to end (row-major, unpadded) + the biases +
         # one zero that every padded position points at.
         flat_idx, off = [], 0
@@ -458,9 +465,14 @@ class FragmentStream:
         for li, l in enumerate(self.lin):
             rows_, cols_ = (l.in_features, l.out_features) if transposed else (l.out_features, l.in_features)
             m_pad, k_pad = _round_up(rows_, 32), _round_up(cols_, 32)
-            kidx = _fragment_index(k_pad, dev) if layout == "rollout" else _chain_fragment_index(k_pad, dev, li == 0)
+            if layout == "rollout":
+                kidx = _fragment_index(k_pad, dev)
+                rmap = m.view(1, -1, 1).expand_as(kidx)
+            else:
+                chain_row, natural_row, kidx = _chain_fragment_index(k_pad, dev)
+                rmap = natural_row if (not transposed and li == len(self.lin) - 1) else chain_row
             for mo in range(m_pad // 32):
-                r = (32 * mo + row).expand_as(kidx)                           # row / column of the (transposed) padded matrix
+                r = 32 * mo + rmap                                             # row / column of the (transposed) padded matrix
                 c = kidx
                 src = off + (c * l.in_features + r if transposed else r * l.in_features + c)   # weight is [out][in]
                 flat_idx.append(torch.where((r < rows_) & (c < cols_), src, torch.full_like(src, zero_at)).reshape(-1))
