@@ -4,21 +4,24 @@
 // (2.6 KB at 20-256x5-4) against 5.2 KB for a chain of per-layer GEMMs, each of which re-reads what the previous
 // one wrote.  With the HBM traffic halved the pass is bound by the matrix cores (557 kflop/row).
 //
-// Same machinery as fused_rollout.hip: transposed product Y^T = W . X^T with v_mfma_f32_32x32x16_bf16, 32 rows per
-// wave (the MFMA columns), a layer's accumulator tile IS the next layer's B operand (bias-init, ReLU, bf16 pack), the
-// weights stream L2 -> LDS by LDS-DMA through a ring shared by the 8 waves of the workgroup.  What differs:
-//   * the fragment rows are permuted so that the 16 accumulator registers of lane (n, h) in output tile mt are the 16
-//     CONSECUTIVE features 32 mt + 16 h + 0..15 of row n (32 B of its row), and the k-order of the next layer's A
-//     fragments is 8 contiguous weights per lane (mlp.FragmentStream(layout="chain") packs them); every second tile
-//     the wave transposes its 32 rows x 128 B through LDS and stores whole 128-B lines (store_pair);
+// Same machinery as fused_rollout.hip: transposed product Y^T = W . X^T on the matrix cores, 32 rows per wave (the MFMA
+// columns), a layer's packed accumulators ARE the next layer's B operand (bias-init, ReLU, bf16 pack), the weights stream
+// L2 -> LDS by LDS-DMA through a ring shared by the 8 waves of the workgroup.  What differs:
+//   * the products are v_mfma_f32_16x16x32_bf16 (2 feature halves x 2 row tiles per 32-feature block): under the package's
+//     power limit the chip holds a higher clock on this shape than on 32x32x16 (tools/mfma_shape_probe.hip: 1.53 vs 1.40
+//     PFLOP/s in this loop), and this kernel is priced in joules (profiles/r02_fwd_chain_store_ablation.md);
+//   * the fragment rows are permuted so that the 2 x 4 accumulator registers of lane (col, g) in output block mt are the 8
+//     CONSECUTIVE features 32 mt + 8 g + 0..7 of its row (16 B of the row) -- then the next layer's k order is natural
+//     (mlp.FragmentStream(layout="chain") builds the stream); every second block the wave transposes its 32 rows x 128 B
+//     through LDS and stores whole 128-B lines (store_pair);
 //   * the input tile (32 rows x 32 padded features, bf16) also arrives by LDS-DMA, one round ahead, so that no
 //     ordinary global load sits in the loop (hipcc would drain the ring with vmcnt(0) at its first use); for the
 //     same reason every LDS read in the loop carries alias-scope metadata or is opaque to the compiler (see
-//     bias_tile / lds_read_b128_opaque): a plain LDS read makes hipcc wait for ALL outstanding LDS-DMA;
+//     lds_float4 / lds_read_b128_opaque): a plain LDS read makes hipcc wait for ALL outstanding LDS-DMA;
 //   * vector-memory operations retire in issue order, stores included, so the counted wait of the ring must allow
 //     for the stores issued since the block it waits for.  The stores are unconditional (rows past the end are
 //     clamped to the last row and rewrite it with identical bytes) and their number per block is a compile-time
-//     pattern (4 after every odd tile), so every wait site has its own exact count.
+//     pattern (4 after every odd block), so every wait site has its own exact count.
 #include "mfma_ring.hpp"
 
 namespace tg {
