@@ -292,7 +292,7 @@ class GemmMLP:
                                           None, N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8,false>"))
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8>"))
         if self._dw_ws is None:
             self._dw_ws = weight_grad_workspace(H, device)
         lin = self.linears
