@@ -52,6 +52,7 @@ HBM_PEAK_GBS = 8000.0                                                 # MI355X_M
 PMC_JSON = {"dw": "r02_dw_probe_pmc.json", "bwd": "r02_bwd_chain_probe_pmc.json", "fwd": "r02_fwd_chain_probe_pmc.json"}
 CONFIGS = {
     #        env           algo    groups/GPU  episodes  agents  restart  total envs (strong scaling)
+    "c2": ("CartPole",      "grpo", 64,         64,       1,      False,   4096),
     "c3": ("QuadPole",      "ppo",  256,        256,      1,      False,   65536),
     "c4": ("QuadPole",      "grpo", 128,        256,      1,      True,    262144),
     "c5": ("QuadPoleSwarm", "grpo", 64,         64,       8,      True,    32768),
@@ -233,10 +234,10 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (whole groups); default: the config's shard")
-    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--horizon", type=int, default=None, help="default 256 (c2: CartPole's own 500)")
     ap.add_argument("--updates", type=int, default=None,
                     help="updates_per_iter (c3: the PPO factory's 32; c4 / c5: GRPO's constructor default 10, grpo.py:26-35)")
-    ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--policy-dtype", default=None, choices=["bf16", "fp32"], help="default bf16 (c2: fp32, as BASELINE says)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fixed-work", action="store_true", help="skip the all-alive (bounds opened) step after the timed region")
     ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
@@ -264,6 +265,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     env_name, algo_name, G_shard, E, agents, restart, total_envs = CONFIGS[args.config]
+    cartpole = env_name == "CartPole"
+    if args.horizon is None:
+        args.horizon = 500 if cartpole else 256
+    if args.policy_dtype is None:
+        args.policy_dtype = "fp32" if cartpole else "bf16"
+    # C2: actor 5-128-128-1, cov 0.5 and the hyper-parameters of pipelines/cartpole_pipeline_grpo.py:54-68
+    obs_dim, act_dim, hidden, cov = (5, 1, (128, 128), 0.5) if cartpole else (20, 4, HIDDEN, 0.3)
     if args.envs is not None:
         G_local = args.envs // E
     elif args.scaling == "strong":
@@ -280,7 +288,7 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == "c3":
         progress("cpu baseline (3 legs, ~40 s) ...")
         cpu = cpu_baseline(args.horizon, 32)
         progress(f"cpu baseline: {cpu['value']:.0f} env-steps/s on {cpu['cores']} cores")
@@ -294,7 +302,8 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    in_group = world > 1 or "WORLD_SIZE" in os.environ        # under torchrun even one rank forms a process group
+    if in_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -307,11 +316,13 @@ def main():
     cdt = torch.bfloat16 if args.policy_dtype == "bf16" else None
     torch.manual_seed(0)                                      # identical random-init weights on every rank
     if algo_name == "ppo":
-        policy = tg.GaussianActorCritic_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
+        policy = tg.GaussianActorCritic_NeuralNetwork(obs_dim, act_dim, hidden, cov=cov, device=dev)
     else:
-        policy = tg.GaussianActor_NeuralNetwork(20, 4, HIDDEN, cov=0.3, device=dev)
+        policy = tg.GaussianActor_NeuralNetwork(obs_dim, act_dim, hidden, cov=cov, device=dev)
 
     def make_env(open_bounds=False):
+        if cartpole:
+            return tg.CartPole(max_steps=T)
         env = tg.QuadPoleSwarm(n_agents=agents, max_steps=T) if agents > 1 else tg.QuadPole(max_steps=T)
         if open_bounds:
             env.spatial_bounds = tuple((-1e9, 1e9) for _ in env.spatial_bounds)
@@ -326,11 +337,11 @@ def main():
                       updates_per_iter=updates, c1=0.5, kl_coeff=0.5, gamma=0.999, lam=0.95, entropy=0.01,
                       batch_size=None, autocast_dtype=cdt)
     else:
-        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.99, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4),
+        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5 if cartpole else 0.99, policy=policy, optimizer=torch.optim.Adam(policy.parameters(), lr=3e-4),
                        updates_per_iter=updates, autocast_dtype=cdt)
 
     def barrier():
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -403,9 +414,9 @@ def main():
         fixed = (time.perf_counter() - f0, buf_open.device_traj.env_steps())
         del mgr_open, buf_open
 
-    dyn = dynamics_kernel_probe(tg, dev, envs_local * agents) if rank == 0 and agents == 1 else None
+    dyn = dynamics_kernel_probe(tg, dev, envs_local * agents) if rank == 0 and agents == 1 and not cartpole else None
     fused_all_alive = None
-    if rank == 0 and mgr.engine.fused and agents == 1:
+    if rank == 0 and mgr.engine.fused and agents == 1 and not cartpole:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
         eng = tg.DeviceRollout(make_env(True), policy, G_local, E, restart=restart, seed=7, compute_dtype=cdt, fused=True)
         eng.run()
@@ -422,7 +433,7 @@ def main():
         del eng
     tot = torch.tensor([float(env_steps), dt, t_roll, t_learn, fixed[0] if fixed else 0.0, float(fixed[1]) if fixed else 0.0],
                        dtype=torch.float64, device=dev)
-    if world > 1:
+    if in_group:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -433,7 +444,9 @@ def main():
 
     if rank == 0:
         n_nets = len(nets)
-        workload = {"c3": f"C3: QuadPole (quadrotor_env.py) PPO, {envs_local} envs/GPU x {T}-step horizon, natural termination, "
+        workload = {"c2": f"C2: CartPole GRPO, {envs_local} envs/GPU ({G_local} groups x {E}) x {T}-step horizon, actor 5-128-128-1, "
+                          f"{updates} updates/iter, {args.policy_dtype} policy",
+                    "c3": f"C3: QuadPole (quadrotor_env.py) PPO, {envs_local} envs/GPU x {T}-step horizon, natural termination, "
                           f"actor-critic 20-256x5-{{4,1}}, {updates} full-batch updates/iter, {args.policy_dtype} policy",
                     "c4": f"C4: QuadPole GRPO, {envs_local} envs/GPU ({G_local} restart groups x {E}) x {T}-step horizon, actor "
                           f"20-256x5-4, {updates} updates/iter, {args.policy_dtype} policy",
@@ -468,11 +481,14 @@ def main():
             n_par = sum(p.numel() for p in policy.actor.parameters())
             dur = sum(d for d, _ in launches) * 1e-3
             ach = 2.0 * n_par * sum(launch_units) / dur / 1e12
-            out["rollout_kernel"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+            f32 = args.policy_dtype == "fp32"
+            peak = 157.3 if f32 else 2500.0          # dense fp32 / bf16 matrix peaks (MI355X_MICROARCH.md)
+            out["rollout_kernel"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                      "traffic": 1706642656 if envs_local == 65536 and agents == 1 else None,
                                      "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
                                                        "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
-                                     "kernel": "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
+                                     "kernel": f"tg::fused_rollout_f32_kernel<{env_name}Env<float>,{hidden[0]},{len(hidden)}>" if f32 else
+                                               "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
                                      "flops_per_env_step": 2 * n_par, "launches": len(launches),
                                      "avg_launch_ms": 1e3 * dur / len(launches),
                                      "note": "valid env-steps only (natural termination: ended envs idle their lanes)",
@@ -521,7 +537,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if in_group:
         dist.destroy_process_group()
 
 

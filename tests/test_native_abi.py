@@ -182,46 +182,58 @@ def test_fragment_stream_layout_is_the_mfma_a_fragment_order():
 
 
 def test_chain_fragment_stream_layout_gives_every_lane_consecutive_features():
-    """Host logic of tg_mlp_forward_chain's weight stream (mlp.FragmentStream(layout="chain")), checked on CPU.
-    Fragment row m of a 32-row output tile carries feature 16*((m>>2)&1) + 4*(m>>3) + (m&3): accumulator register r of
-    lane half h is row (r&3) + 8*(r>>2) + 4h of the MFMA tile, which is then feature 16h + r.  The k order of a later
-    layer follows: 32*(ks>>1) + 16h + 8*(ks&1) + j; the first layer reads its input in natural order."""
+    """Host logic of the chain kernels' weight stream (mlp.FragmentStream(layout="chain")), checked on CPU.
+    The products are `v_mfma_f32_16x16x32_bf16`: a 32-feature output block is two 16-row tiles ("halves" f); accumulator
+    register r of lane group g = lane >> 4 is row 4 g + r of its tile.  Fragment row i of half f carries feature
+    8 (i >> 2) + 4 f + (i & 3), so register r of group g in half f is feature 8 g + 4 f + r: the lane's 2 x 4 accumulators are
+    the 8 consecutive features 8 g .. 8 g + 7 and the next layer reads its k in natural order, 32 ks + 8 g + j.  The forward
+    head keeps its outputs in natural order (16 f + i).  A block is stored [k-step][half][64 lanes][8 bf16]."""
     torch.manual_seed(1)
     net = tg.NeuralNetwork(20, 4, (128, 128), "ReLU")
     fs = tg.mlp.FragmentStream(net, 128, layout="chain")
     lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
-    KS = 128 // 16
     st = fs.stream.float().view(-1, 64, 8)
-    assert st.shape[0] == (1 + 4 + 1) * KS
+    assert st.shape[0] == 4 * 2 + 4 * 8 + 8          # first layer: 4 blocks x (1 k-step x 2); hidden: 4 x (4 x 2); head: 1 x (4 x 2)
 
-    # the permutation is what the kernel assumes: D-layout row of (h, r)  ->  fragment row m  ->  feature 16h + r
-    for h in range(2):
-        for r in range(16):
-            m = (r & 3) + 8 * (r >> 2) + 4 * h
-            assert 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) == 16 * h + r
+    for f in range(2):                               # the permutation is what the kernels assume
+        for g in range(4):
+            for r in range(4):
+                i = 4 * g + r
+                assert 8 * (i >> 2) + 4 * f + (i & 3) == 8 * g + 4 * f + r
 
-    def expect(W, mo, ks, lane, j, first):
-        m, h = lane & 31, lane >> 5
-        r = 32 * mo + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)
-        c = 16 * ks + 8 * h + j if first else 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j
+    def expect(W, mo, ks, f, lane, j, natural):
+        i, g = lane & 15, lane >> 4
+        r = 32 * mo + (16 * f + i if natural else 8 * (i >> 2) + 4 * f + (i & 3))
+        c = 32 * ks + 8 * g + j
         if r >= W.shape[0] or c >= W.shape[1]:
             return 0.0
         return float(W[r, c].to(torch.bfloat16))
 
     rng = np.random.default_rng(1)
     for _ in range(300):
-        mo, ks, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
-        assert float(st[mo * 2 + ks, lane, j]) == expect(lin[0].weight, mo, ks, lane, j, True)
+        mo, f, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(st[mo * 2 + f, lane, j]) == expect(lin[0].weight, mo, 0, f, lane, j, False)
     for _ in range(300):
-        mo, ks, lane, j = rng.integers(4), rng.integers(KS), rng.integers(64), rng.integers(8)
-        assert float(st[KS + mo * KS + ks, lane, j]) == expect(lin[1].weight, mo, ks, lane, j, False)
+        mo, ks, f, lane, j = rng.integers(4), rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(st[8 + mo * 8 + ks * 2 + f, lane, j]) == expect(lin[1].weight, mo, ks, f, lane, j, False)
     for _ in range(300):
-        ks, lane, j = rng.integers(KS), rng.integers(64), rng.integers(8)
-        assert float(st[5 * KS + ks, lane, j]) == expect(lin[2].weight, 0, ks, lane, j, False)
+        ks, f, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(st[40 + ks * 2 + f, lane, j]) == expect(lin[2].weight, 0, ks, f, lane, j, True)
     # every weight appears exactly once per layer: the stream is a permutation of the zero-padded matrices
     w1 = torch.zeros(128, 128)
     w1.copy_(lin[1].weight.detach().to(torch.bfloat16).float())
-    assert torch.equal(torch.sort(st[KS:5 * KS].reshape(-1))[0], torch.sort(w1.reshape(-1))[0])
+    assert torch.equal(torch.sort(st[8:40].reshape(-1))[0], torch.sort(w1.reshape(-1))[0])
+
+    # the backward stream: head first, every matrix transposed, chain rows throughout
+    bs = tg.mlp.FragmentStream(net, 128, layout="chain", transposed=True)
+    bt = bs.stream.float().view(-1, 64, 8)
+    assert bt.shape[0] == 4 * 2 + 4 * 8              # W_head^T: K = 32 (4 outputs, padded): 4 blocks x 2; W_1^T: 4 x (4 x 2)
+    for _ in range(300):
+        mo, f, lane, j = rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(bt[mo * 2 + f, lane, j]) == expect(lin[2].weight.t(), mo, 0, f, lane, j, False)
+    for _ in range(300):
+        mo, ks, f, lane, j = rng.integers(4), rng.integers(4), rng.integers(2), rng.integers(64), rng.integers(8)
+        assert float(bt[8 + mo * 8 + ks * 2 + f, lane, j]) == expect(lin[1].weight.t(), mo, ks, f, lane, j, False)
 
 
 def test_register_stream_f32_layout_follows_the_lds_exchange_order():

@@ -10,6 +10,7 @@ of ranks beyond floating-point summation order.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, Tuple
 
 import torch
@@ -32,9 +33,14 @@ def shard_groups(num_groups: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
+# TG_COLLECTIVES_AT_WORLD_1=1: a one-rank process group still issues every collective (rehearses the RCCL path -- communicator
+# set-up, dtypes, stream ordering -- on a single-GPU box; `bench.py` under torchrun with --nproc-per-node 1)
+_ALWAYS = os.environ.get("TG_COLLECTIVES_AT_WORLD_1", "0") == "1"
+
+
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     _, world = rank_world(group)
-    if world > 1:
+    if world > 1 or (_ALWAYS and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -49,7 +55,7 @@ def minibatch_schedule(m_local: int, batch_size: int, group=None, device=None):
     _, world = rank_world(group)
     local_bs = max(1, -(-int(batch_size) // world))
     counts = [int(m_local)]
-    if world > 1:
+    if world > 1 or (_ALWAYS and dist.is_available() and dist.is_initialized()):
         t = torch.zeros(world, dtype=torch.int64, device=device)
         t[dist.get_rank(group)] = int(m_local)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)          # an all-gather of one integer per rank
