@@ -258,6 +258,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    # The JSON line must be the only thing on stdout, but libraries write there too (RCCL prints a version banner at
+    # communicator set-up): keep a private handle on the real stdout and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -536,7 +542,7 @@ def main():
         out["dynamics_kernel"] = dyn
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if in_group:
         dist.destroy_process_group()
 
