@@ -553,8 +553,35 @@ def test_pipeline_trains_and_checkpoints(tg, dev, tmp_path, monkeypatch):
                                              load_path=str(ck))
     for a, b in zip(pol.parameters(), pol2.parameters()):
         assert torch.equal(a, b)
+    # GRPO deep-copies the policy at construction (grpo.py:48), before the checkpoint is loaded: the resumed learner must take
+    # its first old-log-probs from the LOADED weights, not from the random-init copy
+    for a, b in zip(algo2.old_policy.parameters(), pol2.parameters()):
+        assert torch.equal(a, b)
     assert len(pipe2.buffer.avg_reward) >= 1
+    # ... so one more iteration on the same rollout gives the same objective in both learners (ratio = pi / pi_old)
+    pipe.buffer.sample()
+    algo.learn(pipe.buffer)
+    algo2.learn(pipe.buffer)
+    assert algo2.last_stats["J"] == algo.last_stats["J"]
     pipe2.shutdown()
+
+
+def test_rollout_noise_follows_the_policy_covariance_of_the_moment(tg, dev):
+    """The reference reads `self.cov` on every forward (policies/actor_critic.py:107-138): a covariance changed after the
+    manager exists (annealed exploration noise, a restored checkpoint) must reach the next rollout."""
+    torch.manual_seed(0)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (64, 64), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=16), pol, num_workers=2, num_episodes_per_worker=64, seed=3)
+    t1 = mgr.rollout_device()
+    a1 = t1.act_rows().float().clone()
+    mgr2 = tg.RolloutManager(lambda: tg.CartPole(max_steps=16), pol, num_workers=2, num_episodes_per_worker=64, seed=3)
+    pol.cov = 1e-8 * torch.eye(1)
+    t2 = mgr2.rollout_device()
+    a2 = t2.act_rows().float()
+    with torch.no_grad():
+        mean0 = pol.actor(t2.obs_rows()[:128].float())              # step 0 of all 128 envs: same initial states in both runs
+    assert float((a2[:128] - mean0).abs().max()) < 1e-3              # sigma = 1e-4: the action is the mean
+    assert float((a1[:128] - mean0).abs().max()) > 0.1               # sigma = 0.71
 
 
 # --------------------------------------------------------------------------------------------
