@@ -525,7 +525,14 @@ def main():
             nrows = sum(r for _, _, r, _ in ls)
             ach = nbytes / dur / 1e9
             pmc, src = _pmc_bytes_per_row(fam)
+            # the same launches against the matrix-core roofline (nominal 2 x weights flop per row; the backward-data chain has
+            # no product for the first layer): the chain kernels load both resources at once under one power limit
+            lins = [[m_ for m_ in n_.network if isinstance(m_, torch.nn.Linear)] for n_ in nets]
+            w_all = sum(sum(l.weight.numel() for l in ls_) for ls_ in lins) / len(lins)
+            w_first = sum(ls_[0].weight.numel() for ls_ in lins) / len(lins)
+            tflops = 2.0 * (w_all - (w_first if fam == "bwd" else 0.0)) * nrows / dur / 1e12
             kernels[fam] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "matrix_TFLOPs": tflops, "matrix_frac_of_2500": tflops / 2500.0,
                             "traffic": pmc * nrows / len(ls) if pmc else None,
                             "traffic_source": f"profiles/{src}: 2 x FETCH_SIZE + WRITE_SIZE per row of the 2^22-row probe, times "
                                               "this run's average rows per launch" if pmc else None,
