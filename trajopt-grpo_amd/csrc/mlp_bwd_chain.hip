@@ -213,6 +213,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     mask_words(mw);
                 }
                 f32x4 acc[2][2] = {};
+                // scheduling fences around the block's products: left alone, hipcc threads the pack / mask arithmetic of the
+                // neighbouring blocks through the MFMA sequence (s_nop-padded); kept apart the kernel is 2.4 % faster (same-box A/B)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < K8; ++ks)
 #pragma unroll
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 #pragma unroll
                         for (int c = 0; c < 2; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[f][c], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) xout[c][mt] = masked_pack(acc[0][c], acc[1][c], mw[c][mt >> 1], mt);
                 if (mt & 1) {

@@ -122,6 +122,9 @@ __device__ static inline void chain_block(const uint4* __restrict__ cur, const f
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[f][c] = f32x4{b4.x, b4.y, b4.z, b4.w};
     }
+    // s_setprio doubles as a scheduling fence around the block's products (hipcc otherwise threads the neighbouring blocks' pack
+    // arithmetic through the MFMA sequence): -6 % on the pass without stores, neutral with them (same-box A/B)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < K8; ++ks)
 #pragma unroll
@@ -130,6 +133,7 @@ __device__ static inline void chain_block(const uint4* __restrict__ cur, const f
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[f][c], 0, 0, 0);
         }
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
         out[c] = relu_pack_bf16(acc[0][c][0], acc[0][c][1], acc[0][c][2], acc[0][c][3], acc[1][c][0], acc[1][c][1], acc[1][c][2],
