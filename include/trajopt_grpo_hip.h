@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -315,7 +315,9 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
  *   d_dout8   bf16 [rows][8]: d loss / d head output, columns >= out zero
  *   d_wfrag   bf16 stream of the TRANSPOSED weights, head first then the hidden-to-hidden layers top down
  *             (trajopt-grpo_amd/mlp.py `FragmentStream(layout="chain", transposed=True)`)
- *   d_dz      HOST array of n_hidden_layers device pointers, bf16 [rows][H]: outputs, TOP hidden layer first
+ *   d_dz      HOST array of n_hidden_layers device pointers, bf16 [rows][H]: outputs, TOP hidden layer first.  d_dz[0] may
+ *             be NULL (only with d_partial == NULL): the top layer's dZ is then not written -- it is a function of d_dout8
+ *             and the layer's mask bits, and tg_mlp_weight_grad (kind RH) rebuilds it on chip
  *   d_masks   HOST array of the same layers' ReLU mask bits (u32 [rows][H/32], as tg_mlp_forward_chain writes them)
  *   d_partial f32 [tg_mlp_backward_chain_blocks()][n_hidden_layers][H]: per-workgroup column sums of the dZ (bias
  *             gradients; the caller sums axis 0).  Deterministic.  NULL: no column sums (tg_mlp_weight_grad forms the
@@ -340,8 +342,14 @@ int  tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hid
  *                                                        input row (d_w0frag = first block of the forward chain's weight
  *                                                        stream, d_b0 = first-layer bias f32 [H]); bit-identical to
  *                                                        what tg_mlp_forward_chain would have stored
+ *        RH: P bf16 [rows][8],  Q bf16 [rows][H]         top hidden-to-hidden layer WITHOUT its stored dZ: dZ_top =
+ *                                                        (dOut . W_head) * (a_top > 0) is recomputed on chip from P = d loss /
+ *                                                        d head output (as DH's P), d_aux = the top hidden layer's ReLU mask
+ *                                                        bits (u32 [rows][H/32], tg_mlp_forward_chain) and d_whfrag = the first
+ *                                                        block of the backward chain's weight stream (W_head^T);
+ *                                                        bit-identical to what tg_mlp_backward_chain would have stored
  * H in {128, 256}.  d_workspace: tg_mlp_weight_grad_workspace(H) bytes. */
-enum { TG_DW_HH = 0, TG_DW_HX = 1, TG_DW_DH = 2, TG_DW_HR = 3 };
+enum { TG_DW_HH = 0, TG_DW_HX = 1, TG_DW_DH = 2, TG_DW_HR = 3, TG_DW_RH = 4 };
 typedef struct tg_dw_job {
     const void* d_p;
     const void* d_q;
@@ -350,10 +358,11 @@ typedef struct tg_dw_job {
     int64_t     wgrad_ld;
     int32_t     kind;
     int32_t     m_out, n_out;
+    const void* d_aux;        /* RH: the top hidden layer's ReLU mask bits; otherwise unused */
 } tg_dw_job;
 int64_t tg_mlp_weight_grad_workspace(int32_t hidden);
 int  tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag,
-                        const float* d_b0, void* d_workspace, int64_t workspace_bytes, void* stream);
+                        const float* d_b0, const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1366,6 +1366,51 @@ def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, laye
     assert torch.equal(w_a, w_b) and torch.equal(b_a, b_b)
 
 
+@pytest.mark.parametrize("H,layers,A", [(256, 5, 4), (128, 3, 1), (256, 3, 8)])
+@pytest.mark.parametrize("rows", [255, 40000])
+def test_weight_gradient_kernel_recomputes_the_top_layer_dz(tg, dev, H, layers, A, rows):
+    """Kind RH of tg_mlp_weight_grad rebuilds dZ_top = (dOut . W_head) * (a_top > 0) on chip from the 16-B head gradient row and
+    the layer's mask bits instead of reading a stored dZ; tg_mlp_backward_chain then leaves that store out (d_dz[0] = NULL).
+    Bit-identical to the HH job on what the backward chain stores, and the lower layers' dZ do not depend on the store."""
+    from trajopt_grpo_amd import mlp as M, _native as N
+    torch.manual_seed(rows + H + A)
+    net = tg.NeuralNetwork(20, A, (H,) * layers, "ReLU").to(dev)
+    mlp = M.GemmMLP(net, torch.bfloat16)
+    lib = N.load()
+    xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
+    mlp.forward(xp, keep=True)
+    acts, bits = mlp._acts, mlp._bits
+    nh = layers
+    dzh = torch.zeros(rows, 8, dtype=torch.bfloat16, device=dev)
+    dzh[:, :A] = torch.randn(rows, A, device=dev).bfloat16()
+    mlp._fresh("bchain")
+    m_ptrs = (N.C.c_void_p * nh)(*[bits[nh - j].data_ptr() for j in range(nh)])
+
+    def chain(store_top):
+        dzs = [torch.full((rows, H), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(nh)]
+        ptrs = (N.C.c_void_p * nh)(*[(t.data_ptr() if (j > 0 or store_top) else None) for j, t in enumerate(dzs)])
+        N.check(lib.tg_mlp_backward_chain(dzh.data_ptr(), mlp._bchain.stream.data_ptr(), H, nh, rows, ptrs, m_ptrs, None,
+                                          N.stream_ptr(dev)), "tg_mlp_backward_chain")
+        torch.cuda.synchronize()
+        return dzs
+
+    full, lean = chain(True), chain(False)
+    assert float(lean[0].float().min()) == 7.0 == float(lean[0].float().max())          # untouched
+    for a, b in zip(full[1:], lean[1:]):
+        assert torch.equal(a, b)
+    a_below = acts[nh - 1]                                        # input of the top hidden-to-hidden layer
+    ws = M.weight_grad_workspace(H, dev)
+    w_a, b_a = torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)
+    w_b, b_b = torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)
+    M.weight_grad(H, [(N.TG_DW_HH, full[0], a_below, w_a, b_a)], rows, ws)
+    M.weight_grad(H, [(N.TG_DW_RH, dzh, a_below, w_b, b_b, bits[nh])], rows, ws, whfrag=mlp._bchain.stream)
+    torch.cuda.synchronize()
+    ref = full[0].double().t() @ a_below.double()
+    assert float((w_a.double() - ref).abs().max()) < 2e-5 * (float(ref.abs().max()) + 1.0) * max(1.0, (rows / 1000) ** 0.5)
+    assert torch.equal(w_a, w_b) and torch.equal(b_a, b_b)
+    assert float(w_b.abs().max()) > 0 and float(b_b.abs().max()) > 0
+
+
 # --------------------------------------------------------------------------------------------
 # learn() at the shapes the hot learner kernels run, minibatch PPO, the configs' shard sizes
 # --------------------------------------------------------------------------------------------

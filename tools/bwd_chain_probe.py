@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rows", type=int, nargs="+", default=[1 << 20, 1 << 22])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bias", action="store_true")
+    ap.add_argument("--store-top", action="store_true", help="also write the top layer's dZ (the learner leaves it out: kind RH of tg_mlp_weight_grad rebuilds it)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = N.load()
@@ -35,7 +36,8 @@ def main():
         dzh[:, :4] = (torch.randn(rows, 4, device=dev) * 1e-3).bfloat16()
         dzs = [torch.empty(rows, H, dtype=torch.bfloat16, device=dev) for _ in range(nh)]
         part = torch.empty(lib.tg_mlp_backward_chain_blocks(), nh, H, dtype=torch.float32, device=dev)
-        dz_ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+        top = a.store_top or a.bias
+        dz_ptrs = (N.C.c_void_p * nh)(*[(t.data_ptr() if (j > 0 or top) else None) for j, t in enumerate(dzs)])
         m_ptrs = (N.C.c_void_p * nh)(*[bits[nh - j].data_ptr() for j in range(nh)])
         st = N.stream_ptr(dev)
         run = lambda: N.check(lib.tg_mlp_backward_chain(dzh.data_ptr(), mlp._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
@@ -50,7 +52,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / a.iters * 1e3
-        bpr = 16 + nh * (H // 8 + 2 * H)
+        bpr = 16 + nh * (H // 8) + (nh if top else nh - 1) * 2 * H
         res.append({"rows": rows, "bias_sums": bool(a.bias), "chain_us": us, "bytes_per_row": bpr, "GBps": bpr * rows / us / 1e3,
                     "frac_of_8TBps": bpr * rows / us / 1e3 / 8000, "TFLOPs": 2.0 * rows * (32 * H + (nh - 1) * H * H) / us / 1e6})
     print(json.dumps(res))

@@ -19,6 +19,7 @@ ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--layers", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--no-recompute", action="store_true", help="read the stored first activation (kind HH) instead of recomputing it (HR)")
+ap.add_argument("--no-rh", action="store_true", help="read a stored top-layer dZ (kind HH) instead of rebuilding it from the head gradient (RH)")
 ap.add_argument("--no-gemm", action="store_true", help="skip the split-K GEMM comparison (profiling runs)")
 a_ = ap.parse_args()
 rows, H, nh, recompute = a_.rows, a_.hidden, a_.layers, 0 if a_.no_recompute else 1
@@ -40,16 +41,20 @@ lin = mlp.linears
 ws = M.weight_grad_workspace(H, dev)
 jobs = [(N.TG_DW_DH, dh, acts[nh], lin[nh].weight.grad, None)]
 for i in range(nh - 1, 0, -1):
-    if i == 1 and recompute:
+    if i == nh - 1 and not a_.no_rh and nh >= 3:
+        mlp.forward(xp, keep=True)                # (chain mode: mask bits; the activations are the same)
+        jobs.append((N.TG_DW_RH, dh, acts[i], lin[i].weight.grad, lin[i].bias.grad, mlp._bits[nh]))
+    elif i == 1 and recompute:
         jobs.append((N.TG_DW_HR, dzs[i], xp, lin[i].weight.grad, lin[i].bias.grad))
     else:
         jobs.append((N.TG_DW_HH, dzs[i], acts[i], lin[i].weight.grad, lin[i].bias.grad))
 jobs.append((N.TG_DW_HX, dzs[0], xp, lin[0].weight.grad, lin[0].bias.grad))
-bytes_per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16}[j[0]] for j in jobs)
+bytes_per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16,
+                     N.TG_DW_RH: 2 * H + 16 + H // 8}[j[0]] for j in jobs)
 
 
 def ours():
-    M.weight_grad(H, jobs, rows, ws, mlp._chain.stream, mlp._chain.bias[0])
+    M.weight_grad(H, jobs, rows, ws, mlp._chain.stream, mlp._chain.bias[0], mlp._bchain.stream)
 
 
 def gemms():

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 3                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 4                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -50,10 +50,10 @@ class LossArgs(C.Structure):
 
 class DwJob(C.Structure):
     _fields_ = [("d_p", C.c_void_p), ("d_q", C.c_void_p), ("d_wgrad", C.c_void_p), ("d_bgrad", C.c_void_p),
-                ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32)]
+                ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32), ("d_aux", C.c_void_p)]
 
 
-TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR = 0, 1, 2, 3
+TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR, TG_DW_RH = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); every symbol include/trajopt_grpo_hip.h declares
 _P, _I32, _I64, _U64, _F, _VP = C.POINTER, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
@@ -94,7 +94,7 @@ SIGNATURES = {
     "tg_mlp_backward_chain_blocks": (C.c_int, []),
     "tg_mlp_backward_chain": (C.c_int, [_VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),
     "tg_mlp_weight_grad_workspace": (C.c_int64, [_I32]),
-    "tg_mlp_weight_grad": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _I64, _VP]),
+    "tg_mlp_weight_grad": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,
                                        _VP]),
 }

@@ -23,6 +23,7 @@ namespace tg {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 // ReLU + bf16 pack of 8 accumulators: round first (v_cvt_pk_bf16_f32, 2 per instruction), then clamp the PACKED halves
@@ -39,6 +40,27 @@ __device__ static inline uint32_t relu_pack_bf16x2(float a, float b) {
 __device__ static inline bf16x8 relu_pack_bf16(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
     const uint4 u = {relu_pack_bf16x2(a0, a1), relu_pack_bf16x2(a2, a3), relu_pack_bf16x2(a4, a5), relu_pack_bf16x2(a6, a7)};
     return __builtin_bit_cast(bf16x8, u);
+}
+
+// Masked epilogue of one 32-feature block of a backward-data product (tg_mlp_backward_chain; tg_mlp_weight_grad's kind RH rebuilds
+// the top layer's dZ with the same instructions) for one of the lane's two rows: round the 2 x 4 accumulators pairwise (dword d =
+// features 2 d, 2 d + 1 of the lane's 8) and multiply each 16-bit half by its keep bit (v_pk_mul_lo_u16).  `wsh` = the block
+// pair's mask word already shifted right by the lane's nibble 4 (g & 1): feature pair d of block mt is bit (mt & 1) * 8 + d
+// (even feature) and 16 + that (odd feature).
+__device__ static inline bf16x8 masked_pack(const f32x4& lo, const f32x4& hi, uint32_t wsh, int mt) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t wk = wsh >> ((mt & 1) * 8);
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v[2 * d], v[2 * d + 1]}, bf16x2));
+        const u16x2 keep = __builtin_bit_cast(u16x2, (wk >> d) & 0x00010001u);
+        o[d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, pk) * keep);
+    }
+    return __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
 }
 
 template <int KS, int WPW>

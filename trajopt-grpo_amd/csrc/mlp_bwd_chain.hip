@@ -17,14 +17,13 @@
 // "chain", transposed=True), head first).  The mask bits of a layer (1 KiB per wave) arrive by LDS-DMA two layers ahead,
 // dOut one round ahead; neither is counted in the ring's waits (more operations behind a block only make its wait
 // stricter).  Every second output block issues exactly four stores per wave, always (rows past the end are clamped to the
-// last row and rewrite it with identical bytes), so the counted wait is the same at every site.
+// last row and rewrite it with identical bytes), so the counted wait is the same at every site.  The top layer's dZ need not
+// be written (dz[0] == NULL): it is a function of dOut and the mask bits, and tg_mlp_weight_grad (kind RH) rebuilds it on chip.
 // Bias gradients: tg_mlp_weight_grad forms them inside its contraction; for callers that still ask for per-workgroup column
 // sums (d_partial) a separate reduction kernel runs over the dZ just written (dz_colsum_kernel below).
 #include "mfma_ring.hpp"
 
 namespace tg {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBwdMaxLayers = 6;
 struct BwdChainPtrs {
@@ -63,26 +62,6 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
     return v;
 }
 
-// Masked epilogue of one 32-feature block for one of the lane's two rows: round the 2 x 4 accumulators pairwise (dword d =
-// features 2 d, 2 d + 1 of the lane's 8) and multiply each 16-bit half by its keep bit (v_pk_mul_lo_u16).  `wsh` = the block
-// pair's mask word already shifted right by the lane's nibble 4 (g & 1): feature pair d of block mt is bit (mt & 1) * 8 + d
-// (even feature) and 16 + that (odd feature).
-__device__ static inline bf16x8 masked_pack(const f32x4& lo, const f32x4& hi, uint32_t wsh, int mt) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const uint32_t wk = wsh >> ((mt & 1) * 8);
-    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    uint32_t o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v[2 * d], v[2 * d + 1]}, bf16x2));
-        const u16x2 keep = __builtin_bit_cast(u16x2, (wk >> d) & 0x00010001u);
-        o[d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, pk) * keep);
-    }
-    return __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
-}
-
 template <int H, int WPW>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4* __restrict__ dzh, const uint4* __restrict__ wfrag,
                                                                     int32_t n_layers, int64_t rows, BwdChainPtrs ptrs) {
@@ -101,6 +80,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, col = lane & 15, nib = 4 * (grp & 1);
+    const bool store_top = ptrs.dz[0] != nullptr;                      // null: tg_mlp_weight_grad (kind RH) rebuilds the top layer's dZ
     const int64_t n_rounds = (rows + 32 * WPW - 1) / (32 * WPW);
     const int n_blocks = (n_layers - 1) * MT + 1;
     constexpr int WPL = MT / 2;                                         // mask words per half-row and layer
@@ -192,7 +172,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) xout[c][mt] = masked_pack(acc[0][c], acc[1][c], mw[c][mt >> 1], mt);
-                if (mt & 1) {
+                if ((mt & 1) && store_top) {
                     const bf16x8 pa[2] = {xout[0][mt - 1], xout[1][mt - 1]}, pb[2] = {xout[0][mt], xout[1][mt]};
                     store_pair(stage, ptrs.dz[0] + 32 * (mt - 1), row0, rows, H, lane, pa, pb);
                 }
@@ -207,7 +187,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         for (int j = 1; j < n_layers; ++j) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                TG_RING_ADVANCE(kWaitN)
+                // (without the head block's stores nothing but the one later DMA lies behind the second block of the first layer)
+                if (mt == 1 && j == 1 && !store_top) { TG_RING_WAIT((P - 1) * (KS / WPW)) } else { TG_RING_WAIT(kWaitN) }
+                TG_RING_NEXT
                 if (mt == 0) {
                     prefetch_mask(round, j);
                     mask_words(mw);
@@ -290,7 +272,7 @@ static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_
     }
     BwdChainPtrs ptrs{};
     for (int j = 0; j < n_hidden_layers; ++j) {
-        TG_REQUIRE(d_dz[j] && d_masks[j], "tg_mlp_backward_chain: buffer %d is null", j);
+        TG_REQUIRE((d_dz[j] || (j == 0 && !d_partial)) && d_masks[j], "tg_mlp_backward_chain: buffer %d is null", j);
         ptrs.dz[j] = (uint16_t*)d_dz[j];
         ptrs.mask[j] = (const uint32_t*)d_masks[j];
     }

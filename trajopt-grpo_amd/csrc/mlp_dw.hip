@@ -31,6 +31,8 @@
 //     all-reduce bucket): deterministic, no float atomics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mfma_ring.hpp"
 
 namespace tg {
@@ -43,8 +45,9 @@ constexpr int kDwMaxJobs = 8;
 constexpr int kDwStageRows = 32;
 
 struct DwJob {
-    const uint16_t* p;        // bf16 [rows][H] (HH, HX, HR) or [rows][8] (DH)
-    const uint16_t* q;        // bf16 [rows][H] (HH, DH) or [rows][32] (HX, HR)
+    const uint16_t* p;        // bf16 [rows][H] (HH, HX, HR) or [rows][8] (DH, RH)
+    const uint16_t* q;        // bf16 [rows][H] (HH, DH, RH) or [rows][32] (HX, HR)
+    const uint32_t* aux;      // RH: ReLU mask bits of the top hidden layer, u32 [rows][H/32]
     int32_t kind;
     int32_t first_block;      // workgroups [first_block, first_block + n_blocks) work on this job
     int32_t n_blocks;
@@ -56,6 +59,7 @@ struct DwArgs {
     int32_t n_jobs;
     const uint4* w0frag;      // HR: first-layer block of the forward chain's weight stream ([tile][k-step][64 lanes] x 16 B)
     const float* b0;          // HR: first-layer bias, f32 [H]
+    const uint4* whfrag;      // RH: first block of the backward chain's weight stream (W_head^T: [tile][half][64 lanes] x 16 B)
 };
 
 // One MFMA operand fragment (8 consecutive ROWS of one column per lane) out of a row-major LDS panel: two transposing
@@ -66,8 +70,32 @@ __device__ static inline bf16x8 tr_frag(const char* __restrict__ base, int off_l
     const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(base + off_hi));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+// The same fragment as two raw instructions on a 32-bit LDS address + compile-time offset, invisible to hipcc's waitcnt
+// insertion (which puts lgkmcnt(0) in front of the first MFMA even when only the first 4 of 12 reads feed it): the square jobs
+// count their own lgkmcnt (tr_wait) so that the products start as soon as their two fragments have landed.
+template <int OFF_LO, int OFF_HI>
+__device__ static inline bf16x8 tr_frag_raw(uint32_t addr_lo, uint32_t addr_hi) {
+    i16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr_lo), "n"(OFF_LO));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr_hi), "n"(OFF_HI));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// all but the youngest N LDS operations of this wave have returned; ties the two fragments that are about to be used to the wait
+template <int N>
+__device__ static inline void tr_wait(bf16x8& x, bf16x8& y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+template <int I, int N, class F>
+__device__ static inline void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ static inline uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ static inline uint4 lds_load16(const char* __restrict__ p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ static inline void lds_store16(char* __restrict__ p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ static inline uint32_t lds_load4(const char* __restrict__ p) { return *reinterpret_cast<const uint32_t*>(p); }
 
 // zero the fragment elements whose row (first row of the lane's 8: `first`) is >= rows
 __device__ static inline bf16x8 mask_rows(bf16x8 f, int64_t first, int64_t rows) {
@@ -80,7 +108,7 @@ __device__ static inline bf16x8 mask_rows(bf16x8 f, int64_t first, int64_t rows)
     return __builtin_bit_cast(bf16x8, uint4{d[0], d[1], d[2], d[3]});
 }
 
-enum : int32_t { DW_HH = 0, DW_HX = 1, DW_DH = 2, DW_HR = 3 };
+enum : int32_t { DW_HH = 0, DW_HX = 1, DW_DH = 2, DW_HR = 3, DW_RH = 4 };
 
 template <int H>
 struct DwGeom {
@@ -95,14 +123,17 @@ struct DwGeom {
 
 // LDS ring of one job kind.  A CU's share of the HBM stream is (bytes it keeps in flight) / (latency under load, 2-3 us):
 // the narrow kinds (18 KB per stage) get deeper rings so that every kind keeps ~100 KB in flight.
-//   slot = [P panel][second operand]; HR keeps its recomputed Q tiles (2: the stage in use, the next one) behind the ring.
+//   slot = [P panel][second operand]; HR keeps its recomputed Q tiles (2: the stage in use, the next one) behind the ring;
+//   RH: slot = [Q panel][dOut panel][mask bits], the recomputed P tiles behind the ring.
 template <int H, int KIND>
 struct DwRing {
     using G = DwGeom<H>;
+    static constexpr bool kRecomp = KIND == DW_HR || KIND == DW_RH;          // one operand is rebuilt on chip, one stage ahead
     static constexpr int P_OFF = 0;
-    static constexpr int Q_OFF = (KIND == DW_DH) ? 1024 : G::PANEL;          // DH: the [32][8] panel takes 512 B
+    static constexpr int Q_OFF = (KIND == DW_DH) ? 1024 : (KIND == DW_RH ? 0 : G::PANEL);   // DH: the [32][8] panel takes 512 B
+    static constexpr int AUX_OFF = G::PANEL;                                 // RH: [32][8] dOut panel, + 1024: the mask bits
     static constexpr int SLOT = (KIND == DW_HH) ? 2 * G::PANEL : (KIND == DW_DH ? G::PANEL + 1024 : G::PANEL + 2048);
-    static constexpr int QTILES = (KIND == DW_HR) ? 2 * G::PANEL : 0;
+    static constexpr int QTILES = kRecomp ? 2 * G::PANEL : 0;
     static constexpr int D_FIT = (G::ZERO - QTILES) / SLOT;
     static constexpr int D = D_FIT > 8 ? 8 : D_FIT;                          // slots; D - 1 stages in flight
     static constexpr int QT_OFF = D * SLOT;
@@ -125,17 +156,42 @@ __device__ static inline void dma_wide(const uint16_t* __restrict__ g, int64_t r
         __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, 0);
     }
 }
+// kSwz (HR, whose recompute reads the panel as MFMA B fragments, 16 rows x one 16-B chunk per 16 lanes: 4 rows share a bank group
+// in the plain image): chunk c of row r lands in slot c ^ ((r >> 2) & 3) of its 64 bytes -- the source address does the permutation.
+template <bool kSwz>
 __device__ static inline void dma_x(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* xpanel, int wave, int lane) {
     const int pc = wave & 1;                                        // 2 pieces of 16 rows x 64 B; every wave moves one
     int64_t r = row0 + 16 * pc + (lane >> 2);
     r = r < rows ? r : rows - 1;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r * 4 + (lane & 3), (lds_void*)(xpanel + pc * 1024), 16, 0, 0);
+    const int chunk = kSwz ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3);
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r * 4 + chunk, (lds_void*)(xpanel + pc * 1024), 16, 0, 0);
 }
 __device__ static inline void dma_d8(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* panel, int lane) {
     if (lane < 32) {                                                // 32 rows x 16 B
         int64_t r = row0 + lane;
         r = r < rows ? r : rows - 1;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r, (lds_void*)panel, 16, 0, 0);
+    }
+}
+
+// RH: the stage's [32][8] dOut rows (even waves) or its mask bits (odd waves): one instruction per wave, like dma_x.
+// Mask bits land row-major: H = 256: lane L fetches the 16 B of (row L >> 1, half L & 1); H = 128: a row's two halves are 16 B.
+template <int H>
+__device__ static inline void dma_rh_aux(const uint16_t* __restrict__ dout, const uint32_t* __restrict__ bits, int64_t row0, int64_t rows,
+                                         char* aux, int wave, int lane) {
+    constexpr int MT = H / 32;
+    if ((wave & 1) == 0) {
+        dma_d8(dout, row0, rows, aux, lane);
+    } else if constexpr (MT == 8) {
+        int64_t r = row0 + (lane >> 1);
+        r = r < rows ? r : rows - 1;
+        __builtin_amdgcn_global_load_lds(bits + r * MT + (lane & 1) * (MT / 2), (lds_void*)(aux + 1024), 16, 0, 0);
+    } else {
+        if (lane < 32) {
+            int64_t r = row0 + lane;
+            r = r < rows ? r : rows - 1;
+            __builtin_amdgcn_global_load_lds(bits + r * MT, (lds_void*)(aux + 1024), 16, 0, 0);
+        }
     }
 }
 
@@ -148,7 +204,10 @@ __device__ static inline void dw_issue(const DwJob& job, int64_t sg, int64_t row
         dma_wide<H>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
     } else if constexpr (KIND == DW_HX || KIND == DW_HR) {
         dma_wide<H>(job.p, row0, rows, slot + R::P_OFF, wave, lane);
-        dma_x(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
+        dma_x<KIND == DW_HR>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
+    } else if constexpr (KIND == DW_RH) {
+        dma_wide<H>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
+        dma_rh_aux<H>(job.p, job.aux, row0, rows, slot + R::AUX_OFF, wave, lane);
     } else {
         dma_d8(job.p, row0, rows, slot + R::P_OFF, lane);
         dma_wide<H>(job.q, row0, rows, slot + R::Q_OFF, wave, lane);
@@ -160,8 +219,9 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
     using G = DwGeom<H>;
     using R = DwRing<H, KIND>;
     constexpr int D = R::D, P = D - 1, NG = R::NG;
-    constexpr int MA = (KIND == DW_HH || KIND == DW_HR) ? G::MA : 1;
-    constexpr int NB = (KIND == DW_HH || KIND == DW_HR) ? G::NB : 1;
+    constexpr bool kSquare = KIND == DW_HH || KIND == DW_HR || KIND == DW_RH;       // H x H output, 4 x 2 waves
+    constexpr int MA = kSquare ? G::MA : 1;
+    constexpr int NB = kSquare ? G::NB : 1;
     constexpr int NT = H / 32;                                        // 32-wide tiles across a wide operand
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
@@ -170,17 +230,30 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
 
     // wave -> output tiles.  HH / HR: 4 (m) x 2 (n) waves; HX: wave w = m-tile w; DH: wave w = n-tile w
     const int wm = wave >> 1, wn = wave & 1;
-    const bool active = (KIND == DW_HH || KIND == DW_HR) ? true : wave < NT;
+    const bool active = kSquare ? true : wave < NT;
     // lane part of a transposed fragment read: rows 8h + q (+4), columns 16 g1 + 4 p .. +3 of the tile's 32
     const int lane_wide = 2 * h * G::ROWQ + q4 * 64 + g1 * 32 + p4 * 8;
     const int lane_x = 2 * h * 256 + q4 * 64 + g1 * 32 + p4 * 8;
+    // a recomputed tile (HR: Q, RH: P) keeps the 16-B chunk c of a row's 64-byte segment in slot c ^ (quad & 3) (quad = row / 4):
+    // its writers hold 16 rows x one chunk per 16 lanes, which would put 4 rows on one bank group in the plain image.  The reader's
+    // low / high transposing reads look at quads 2 h and 2 h + 1 (+ 4 ks): two lane addresses instead of one.
+    const int lane_sw_lo = 2 * h * G::ROWQ + q4 * 64 + (((2 * g1 + (p4 >> 1)) ^ ((2 * h) & 3)) * 16) + (p4 & 1) * 8;
+    const int lane_sw_hi = 2 * h * G::ROWQ + q4 * 64 + (((2 * g1 + (p4 >> 1)) ^ ((2 * h + 1) & 3)) * 16) + (p4 & 1) * 8;
     int offA, offB;                                                   // + slot (or Q tile) base + k-step / tile immediates
+    int offR_lo = 0, offR_hi = 0;                                     // the recomputed operand's pair
     if constexpr (KIND == DW_HH) {
         offA = R::P_OFF + lane_wide + (MA * wm) * 256;
         offB = R::Q_OFF + lane_wide + (NB * wn) * 256;
     } else if constexpr (KIND == DW_HR) {
         offA = R::P_OFF + lane_wide + (MA * wm) * 256;
         offB = lane_wide + (NB * wn) * 256;                           // relative to the stage's recomputed Q tile
+        offR_lo = lane_sw_lo + (NB * wn) * 256;
+        offR_hi = lane_sw_hi + (NB * wn) * 256;
+    } else if constexpr (KIND == DW_RH) {
+        offA = lane_wide + (MA * wm) * 256;                           // relative to the stage's recomputed P tile
+        offR_lo = lane_sw_lo + (MA * wm) * 256;
+        offR_hi = lane_sw_hi + (MA * wm) * 256;
+        offB = R::Q_OFF + lane_wide + (NB * wn) * 256;
     } else if constexpr (KIND == DW_HX) {
         offA = R::P_OFF + lane_wide + (wave % NT) * 256;
         offB = R::Q_OFF + lane_x;
@@ -202,7 +275,6 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
 
     // HR: this wave's 32 first-layer features (block `wave`): weight fragments + bias in registers, in the forward chain's own
     // layout (mlp.FragmentStream(layout="chain"): v_mfma_f32_16x16x32_bf16, half f of lane (i, g) = features 8 (i >> 2) + 4 f + (i & 3))
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     bf16x8 w0[2] = {};
     f32x4 b0v[2] = {};
     if constexpr (KIND == DW_HR) {
@@ -215,6 +287,14 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ordinary loads: none may be counted in the ring
+    }
+    // RH: this wave's 32 top-layer features (block `wave`) of W_head^T, in the backward chain's own layout
+    if constexpr (KIND == DW_RH) {
+        if (wave < NT) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) w0[f] = __builtin_bit_cast(bf16x8, args.whfrag[(wave * 2 + f) * 64 + lane]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     int64_t sg_issue = my;
@@ -235,29 +315,53 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int row = 16 * c + col16;
-                const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + R::Q_OFF + row * 64 + 16 * grp));
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, lds_load16(sb + R::Q_OFF + row * 64 + 16 * (grp ^ ((row >> 2) & 3))));
                 // one k-step (K = 32), bias as the initial accumulator: the forward chain's first layer, instruction for instruction
                 const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0], xb, b0v[0], 0, 0, 0);
                 const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1], xb, b0v[1], 0, 0, 0);
                 const bf16x8 o = relu_pack_bf16(t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]);
-                lds_store16(qt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 16 * grp, __builtin_bit_cast(uint4, o));
+                lds_store16(qt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 16 * (grp ^ ((row >> 2) & 3)), __builtin_bit_cast(uint4, o));
             }
         }
     };
-    // stages that must have landed at the top of an iteration: the current one; HR also the next (its x panel is read)
-    constexpr int kWait = (KIND == DW_HR ? P - 2 : P - 1) * NG;
-    int parity = 0;                                                   // HR: Q tile of the current stage
-    if constexpr (KIND == DW_HR) {
+    // RH: dZ_top tile = (W_head^T . dOut^T) * keep bits for a stage's 32 rows (dOut panel + mask bits of slot `sb`), written as the
+    // image of a P panel: the backward chain's head block, instruction for instruction (identical bits), one stage ahead like a0
+    auto recompute_dz = [&](const char* sb, char* pt) {
+        if (wave < NT) {
+            constexpr int MT = H / 32;
+            const int col16 = lane & 15, grp = lane >> 4;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int row = 16 * c + col16;
+                const uint4 gq = lds_load16(sb + R::AUX_OFF + row * 16);
+                const bf16x8 xb = grp ? bf16x8{} : __builtin_bit_cast(bf16x8, gq);      // k = 8 g + j: outputs 0..7 sit in the g = 0 lanes
+                const f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0], xb, f32x4{}, 0, 0, 0);
+                const f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1], xb, f32x4{}, 0, 0, 0);
+                // the lane's mask word: (row, half g >> 1, word wave >> 1), shifted right by its nibble 4 (g & 1)
+                const uint32_t mwv = lds_load4(sb + R::AUX_OFF + 1024 + row * (MT * 4) + (grp >> 1) * (MT * 2) + (wave >> 1) * 4);
+                const bf16x8 o = masked_pack(t0, t1, mwv >> (4 * (grp & 1)), wave);
+                lds_store16(pt + (row >> 2) * G::ROWQ + wave * 256 + (row & 3) * 64 + 16 * (grp ^ ((row >> 2) & 3)), __builtin_bit_cast(uint4, o));
+            }
+        }
+    };
+    // stages that must have landed at the top of an iteration: the current one; HR / RH also the next (its inputs are read)
+    constexpr int kWait = (R::kRecomp ? P - 2 : P - 1) * NG;
+    int parity = 0;                                                   // HR / RH: recomputed tile of the current stage
+    if constexpr (R::kRecomp) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");      // the first stage
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        recompute_a0(lds_c, lds_c + R::QT_OFF);
+        if constexpr (KIND == DW_HR) recompute_a0(lds_c, lds_c + R::QT_OFF);
+        else recompute_dz(lds_c, lds_c + R::QT_OFF);
     }
 
     int slot = 0;
-#pragma unroll 1
-    for (int64_t sg = my; sg < n_st; sg += nb) {
-        if constexpr (KIND == DW_HR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's a0 writes are done
+    // One stage.  kPartial (the one stage that holds the last rows, if they do not fill it) masks the dZ fragments; it is a
+    // separate instantiation so that the loop over full stages is ONE basic block per k-step: hipcc only then issues the next
+    // k-step's fragment reads among the current MFMAs, and its counted lgkmcnt lets the first products start after 4 of 12 reads.
+    auto stage = [&](const int64_t sg, auto partial_c) {
+        constexpr bool kPartial = decltype(partial_c)::value;
+        if constexpr (R::kRecomp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's tile writes are done
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWait) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -268,15 +372,75 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
         const char* sb = lds_c + slot * R::SLOT;
         slot = slot + 1 == D ? 0 : slot + 1;
         const int64_t row0 = sg * kDwStageRows;
-        const bool partial = row0 + kDwStageRows > rows;              // wave-uniform
-        const char* qb = sb;                                          // base of the B operand's panel
+        const char* pb = sb;                                          // bases of the A / B operands' panels
+        const char* qb = sb;
         if constexpr (KIND == DW_HR) {
             qb = lds_c + R::QT_OFF + parity * G::PANEL;
             parity ^= 1;
             if (sg + nb < n_st) recompute_a0(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);   // the next stage's tile
+        } else if constexpr (KIND == DW_RH) {
+            pb = lds_c + R::QT_OFF + parity * G::PANEL;
+            parity ^= 1;
+            if (sg + nb < n_st) recompute_dz(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);
         }
 
-        if (active) {
+        if constexpr (kSquare) {
+            // H x H jobs: both k-steps' fragments through raw transposing reads in the order of their use, a0 b0 b1 .. a1 .. (12
+            // reads per k-step at H = 256), with the wave's own counted lgkmcnt: the products of (a0, b0) start when 4 reads have
+            // returned, and the second k-step's reads go out before the last group of products of the first.  LDS operations
+            // return in issue order, so other accesses of this wave in the queue (the recompute's, wherever hipcc puts them) can
+            // only make a counted wait stricter, never weaker: "at most N outstanding" still covers everything older than the
+            // youngest N, and the raw reads and waits keep their order among themselves (volatile).
+            const uint32_t pa = lds_addr(pb) + (uint32_t)(KIND == DW_RH ? offR_lo : offA);
+            const uint32_t pa_hi = KIND == DW_RH ? lds_addr(pb) + (uint32_t)offR_hi : pa;
+            const uint32_t qa = lds_addr(qb) + (uint32_t)(KIND == DW_HR ? offR_lo : offB);
+            const uint32_t qa_hi = KIND == DW_HR ? lds_addr(qb) + (uint32_t)offR_hi : qa;
+            constexpr int TOTAL = 2 * (MA + NB);
+            bf16x8 fa[2][MA], fb[2][NB];
+            auto reads = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+                constexpr int K0 = 4 * ks * G::ROWQ, K1 = (4 * ks + 1) * G::ROWQ;
+                fa[ks][0] = tr_frag_raw<K0, K1>(pa, pa_hi);
+                static_for<0, NB>([&](auto n) {
+                    constexpr int N_ = decltype(n)::value;
+                    fb[ks][N_] = tr_frag_raw<K0 + N_ * 256, K1 + N_ * 256>(qa, qa_hi);
+                });
+                static_for<1, MA>([&](auto m) {
+                    constexpr int M_ = decltype(m)::value;
+                    fa[ks][M_] = tr_frag_raw<K0 + M_ * 256, K1 + M_ * 256>(pa, pa_hi);
+                });
+            };
+            reads(std::integral_constant<int, 0>{});
+            static_for<0, 2>([&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+                // products of a[0]: b[n] is complete when 2 + 2 (n + 1) reads have returned
+                static_for<0, NB>([&](auto n) {
+                    constexpr int N_ = decltype(n)::value;
+                    tr_wait<TOTAL - 2 - 2 * (N_ + 1)>(fa[ks][0], fb[ks][N_]);
+                    if constexpr (kPartial && N_ == 0) fa[ks][0] = mask_rows(fa[ks][0], row0 + 16 * ks + 8 * h, rows);
+                    if constexpr (MA == 1 && N_ == NB - 1 && ks == 0) reads(std::integral_constant<int, 1>{});
+                    acc[0][N_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0], fb[ks][N_], acc[0][N_], 0, 0, 0);
+                });
+                static_for<1, MA>([&](auto m) {
+                    constexpr int M_ = decltype(m)::value;
+                    tr_wait<TOTAL - 2 - 2 * NB - 2 * M_>(fa[ks][M_], fb[ks][0]);
+                    if constexpr (kPartial) fa[ks][M_] = mask_rows(fa[ks][M_], row0 + 16 * ks + 8 * h, rows);
+                    // every read of this k-step has returned: the next k-step's go out under the remaining products
+                    if constexpr (M_ == MA - 1 && ks == 0) reads(std::integral_constant<int, 1>{});
+                    static_for<0, NB>([&](auto n) {
+                        constexpr int N_ = decltype(n)::value;
+                        acc[M_][N_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][M_], fb[ks][N_], acc[M_][N_], 0, 0, 0);
+                    });
+                });
+                // bias gradient of one m-tile per wave: H = 256: tile 2 wm + wn; H = 128: the wn == 0 waves
+                if constexpr (MA == 2) {
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? fa[ks][1] : fa[ks][0], ones, accb, 0, 0, 0);
+                } else {
+                    if (wn == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0], ones, accb, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if (active) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 a[MA], b[NB];
@@ -284,17 +448,12 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
                     // lanes without a column of their own (columns 8..31 of the padded tile) read the zero word
                     const int o = d8_valid ? (int)(sb - lds_c) + offA + 256 * ks : G::ZERO;
                     a[0] = tr_frag(lds_c, o, d8_valid ? o + 64 : o);
+                    b[0] = tr_frag(qb, offB + 4 * ks * G::ROWQ, offB + (4 * ks + 1) * G::ROWQ);
                 } else {
-#pragma unroll
-                    for (int m = 0; m < MA; ++m) a[m] = tr_frag(sb, offA + 4 * ks * G::ROWQ + m * 256, offA + (4 * ks + 1) * G::ROWQ + m * 256);
-                }
-                if constexpr (KIND == DW_HX) {
+                    a[0] = tr_frag(pb, offA + 4 * ks * G::ROWQ, offA + (4 * ks + 1) * G::ROWQ);
                     b[0] = tr_frag(qb, offB + 4 * ks * 256, offB + (4 * ks + 1) * 256);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) b[n] = tr_frag(qb, offB + 4 * ks * G::ROWQ + n * 256, offB + (4 * ks + 1) * G::ROWQ + n * 256);
                 }
-                if (partial) {
+                if constexpr (kPartial) {
 #pragma unroll
                     for (int m = 0; m < MA; ++m) a[m] = mask_rows(a[m], row0 + 16 * ks + 8 * h, rows);
                 }
@@ -302,26 +461,24 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
                 for (int m = 0; m < MA; ++m)
 #pragma unroll
                     for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
-                // bias gradient of one m-tile per wave: HH / HR at H = 256: tile 2 wm + wn; at H = 128: the wn == 0 waves
-                if constexpr (KIND == DW_HH || KIND == DW_HR) {
-                    if constexpr (MA == 2) {
-                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? a[1] : a[0], ones, accb, 0, 0, 0);
-                    } else {
-                        if (wn == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, accb, 0, 0, 0);
-                    }
-                } else if constexpr (KIND == DW_HX) {
+                if constexpr (KIND == DW_HX) {
                     accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], ones, accb, 0, 0, 0);
                 }
             }
         }
-    }
+    };
+    const int64_t n_full = rows / kDwStageRows;                       // stages below this index hold 32 rows
+    int64_t sg = my;
+#pragma unroll 1
+    for (; sg < n_full; sg += nb) stage(sg, std::false_type{});
+    if (sg < n_st) stage(sg, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no LDS-DMA may outlive the workgroup's LDS allocation
 
     // ---- this workgroup's slab: [M][N] gradient (+ [M] bias sums) ----
     float* slab = ws + job.slab_off + (int64_t)my * job.slab_len;
     const int col = lane & 31;
     if (active) {
-        if constexpr (KIND == DW_HH || KIND == DW_HR) {
+        if constexpr (kSquare) {
 #pragma unroll
             for (int m = 0; m < MA; ++m)
 #pragma unroll
@@ -365,6 +522,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(DwArgs args, int64_t rows, f
         case DW_HH: dw_run<H, DW_HH>(args, job, rows, ws, lds_c); break;
         case DW_HX: dw_run<H, DW_HX>(args, job, rows, ws, lds_c); break;
         case DW_DH: dw_run<H, DW_DH>(args, job, rows, ws, lds_c); break;
+        case DW_RH: dw_run<H, DW_RH>(args, job, rows, ws, lds_c); break;
         default: dw_run<H, DW_HR>(args, job, rows, ws, lds_c); break;
     }
 }
@@ -405,25 +563,26 @@ static int dw_cus() { return device_cus(); }
 
 // Relative cost of a row of each job kind = its bytes, times a per-kind factor for the kinds that are not purely
 // byte-bound (HR recomputes a tile per stage).  The workgroups are split between the jobs in proportion to it.
-// TG_DW_COST="hh,hx,dh,hr" (percent of the byte count) overrides the factors: a tuning knob, read once.
+// TG_DW_COST="hh,hx,dh,hr,rh" (percent of the byte count) overrides the factors: a tuning knob, read once.
 static int64_t dw_row_cost(int H, int kind) {
-    static int pct[4] = {0, 0, 0, 0};
+    static int pct[5] = {0, 0, 0, 0, 0};
     if (pct[0] == 0) {
-        int v[4] = {100, 100, 100, 280};   // HR: measured optimum 270-300 (tools/dw_probe.py, 2^22 rows)
-        if (const char* e = getenv("TG_DW_COST")) (void)sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-        for (int k = 0; k < 4; ++k) pct[k] = v[k] > 0 ? v[k] : 100;
+        int v[5] = {100, 100, 100, 280, 280};   // HR: measured optimum 270-300 (tools/dw_probe.py, 2^22 rows); RH: the same structure
+        if (const char* e = getenv("TG_DW_COST")) (void)sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+        for (int k = 0; k < 5; ++k) pct[k] = v[k] > 0 ? v[k] : 100;
     }
     int64_t bytes;
     switch (kind) {
         case DW_HH: bytes = 4 * H; break;
         case DW_HX: case DW_HR: bytes = 2 * H + 64; break;
+        case DW_RH: bytes = 2 * H + 16 + H / 8; break;
         default: bytes = 2 * H + 16; break;
     }
     return bytes * pct[kind];
 }
 static int dw_slab_len(int H, int kind) {
     switch (kind) {
-        case DW_HH: case DW_HR: return H * H + H;
+        case DW_HH: case DW_HR: case DW_RH: return H * H + H;
         case DW_HX: return H * 32 + H;
         default: return 8 * H;
     }
@@ -452,7 +611,7 @@ int64_t tg_mlp_weight_grad_workspace(int32_t hidden) {
 }
 
 int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag, const float* d_b0,
-                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+                       const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, void* stream) {
     TG_REQUIRE(jobs && d_workspace, "tg_mlp_weight_grad: null pointer");
     TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_weight_grad: hidden width %d unsupported (128, 256)", hidden);
     TG_REQUIRE(n_jobs >= 1 && n_jobs <= kDwMaxJobs, "tg_mlp_weight_grad: %d jobs outside 1..%d", n_jobs, kDwMaxJobs);
@@ -464,13 +623,14 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
     int64_t wsum = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const tg_dw_job& jb = jobs[j];
-        TG_REQUIRE(jb.kind >= TG_DW_HH && jb.kind <= TG_DW_HR, "tg_mlp_weight_grad: job %d has kind %d", j, jb.kind);
+        TG_REQUIRE(jb.kind >= TG_DW_HH && jb.kind <= TG_DW_RH, "tg_mlp_weight_grad: job %d has kind %d", j, jb.kind);
         TG_REQUIRE(jb.d_p && jb.d_q && jb.d_wgrad, "tg_mlp_weight_grad: job %d has a null pointer", j);
         const int M = jb.kind == TG_DW_DH ? 8 : H, N = (jb.kind == TG_DW_HX) ? 32 : H;
         TG_REQUIRE(jb.m_out >= 1 && jb.m_out <= M && jb.n_out >= 1 && jb.n_out <= N && jb.wgrad_ld >= jb.n_out,
                    "tg_mlp_weight_grad: job %d: window %d x %d (ld %lld) outside %d x %d", j, jb.m_out, jb.n_out, (long long)jb.wgrad_ld, M, N);
         TG_REQUIRE(jb.kind != TG_DW_DH || !jb.d_bgrad, "tg_mlp_weight_grad: job %d: the head's bias gradient comes from tg_head_prep", j);
         TG_REQUIRE(jb.kind != TG_DW_HR || (d_w0frag && d_b0), "tg_mlp_weight_grad: job %d recomputes the first layer: weights / bias missing", j);
+        TG_REQUIRE(jb.kind != TG_DW_RH || (d_whfrag && jb.d_aux), "tg_mlp_weight_grad: job %d recomputes the top dZ: head weights / mask bits missing", j);
         wsum += dw_row_cost(H, jb.kind);
     }
     // workgroups per job in proportion to its bytes per row (largest remainders), at least one, at most one per 4 stages
@@ -500,6 +660,7 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
     args.n_jobs = n_jobs;
     args.w0frag = (const uint4*)d_w0frag;
     args.b0 = d_b0;
+    args.whfrag = (const uint4*)d_whfrag;
     DwFinishArgs fa{};
     int grid = 0, elems = 0;
     int64_t off = 0;
@@ -508,6 +669,7 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
         DwJob& dj = args.job[j];
         dj.p = (const uint16_t*)jb.d_p;
         dj.q = (const uint16_t*)jb.d_q;
+        dj.aux = (const uint32_t*)jb.d_aux;
         dj.kind = jb.kind;
         dj.first_block = grid;
         dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;

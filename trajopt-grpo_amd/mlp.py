@@ -27,24 +27,34 @@ import torch
 
 from . import _native as N
 
+import os
+
 _ROW_BLOCK = 8192
+_STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
 _SPLIT_BATCHES = 128
 
 
-def weight_grad(hidden: int, jobs, rows: int, workspace: torch.Tensor, w0frag: torch.Tensor = None, b0: torch.Tensor = None):
+def weight_grad(hidden: int, jobs, rows: int, workspace: torch.Tensor, w0frag: torch.Tensor = None, b0: torch.Tensor = None,
+                whfrag: torch.Tensor = None):
     """tg_mlp_weight_grad: every job's `wgrad += P^T Q` (and `bgrad += column sums of P`) in one persistent launch + one
-    fixed-order reduction.  jobs = [(kind, P, Q, wgrad, bgrad or None)]; P / Q bf16 row-major [rows][*], wgrad a 2-D
-    fp32 view with unit column stride (e.g. a window of the learner's flat gradient bucket)."""
+    fixed-order reduction.  jobs = [(kind, P, Q, wgrad, bgrad or None[, aux])]; P / Q bf16 row-major [rows][*], wgrad a 2-D
+    fp32 view with unit column stride (e.g. a window of the learner's flat gradient bucket).  Kind HR rebuilds its Q (the first
+    hidden activation) from the net input with `w0frag` / `b0`; kind RH rebuilds its P (the top layer's dZ) from d loss / d head
+    output, the layer's ReLU mask bits (`aux`) and `whfrag` (the backward chain's weight stream)."""
     arr = (N.DwJob * len(jobs))()
-    for slot, (kind, p, q, wgrad, bgrad) in zip(arr, jobs):
-        N.require_cuda(p, q, wgrad, bgrad)
+    for slot, job in zip(arr, jobs):
+        kind, p, q, wgrad, bgrad = job[:5]
+        aux = job[5] if len(job) > 5 else None
+        N.require_cuda(p, q, wgrad, bgrad, aux)
+        assert (kind == N.TG_DW_RH) == (aux is not None)
+        slot.d_aux = N.ptr(aux)
         assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and p.is_contiguous() and q.is_contiguous()
         assert p.shape[0] >= rows and q.shape[0] >= rows
         assert wgrad.dtype == torch.float32 and wgrad.dim() == 2 and wgrad.stride(1) == 1
         assert bgrad is None or (bgrad.dtype == torch.float32 and bgrad.is_contiguous() and bgrad.numel() == wgrad.shape[0])
         slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wgrad.data_ptr(), N.ptr(bgrad)
         slot.wgrad_ld, slot.kind, slot.m_out, slot.n_out = wgrad.stride(0), kind, wgrad.shape[0], wgrad.shape[1]
-    N.check(N.load().tg_mlp_weight_grad(hidden, arr, len(jobs), rows, N.ptr(w0frag), N.ptr(b0), workspace.data_ptr(),
+    N.check(N.load().tg_mlp_weight_grad(hidden, arr, len(jobs), rows, N.ptr(w0frag), N.ptr(b0), N.ptr(whfrag), workspace.data_ptr(),
                                         workspace.numel() * workspace.element_size(), N.stream_ptr(workspace.device)),
             "tg_mlp_weight_grad")
 
@@ -281,8 +291,11 @@ class GemmMLP:
         L = len(self.linears)
         nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
         H = self._bchain.H
-        dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) for j in range(nh)]
-        dz_ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+        # the top layer's dZ is neither written nor read: tg_mlp_weight_grad rebuilds it from dz_head and the mask bits (kind RH)
+        # (TG_STORE_TOP_DZ=1 keeps the stored form for A/B runs)
+        store_top = _STORE_TOP_DZ
+        dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) if (j > 0 or store_top) else None for j in range(nh)]
+        dz_ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
         m_ptrs = (N.C.c_void_p * nh)(*[bits[L - 1 - j].data_ptr() for j in range(nh)])     # bits[i + 1] masks hidden layer i
         ev = None
         if self.dx_events is not None:
@@ -292,14 +305,18 @@ class GemmMLP:
                                           None, N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8 + 2 * H), f"tg::mlp_bwd_chain_kernel<{H},8>"))
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8) + (nh if store_top else nh - 1) * 2 * H,
+                                   f"tg::mlp_bwd_chain_kernel<{H},8>"))
         if self._dw_ws is None:
             self._dw_ws = weight_grad_workspace(H, device)
         lin = self.linears
         jobs = [(N.TG_DW_DH, dz_head, acts[L - 1], lin[L - 1].weight.grad, None)]             # head (bias: tg_head_prep)
         for j in range(nh - 1):
             i = L - 2 - j                                                                      # hidden-to-hidden layer i
-            if acts[i] is None:                                                                # i == 1: input not stored
+            if j == 0 and not store_top:                                                       # top layer: dZ not stored
+                assert acts[i] is not None
+                jobs.append((N.TG_DW_RH, dz_head, acts[i], lin[i].weight.grad, lin[i].bias.grad, bits[L - 1]))
+            elif acts[i] is None:                                                              # i == 1: input not stored
                 jobs.append((N.TG_DW_HR, dzs[j], acts[0], lin[i].weight.grad, lin[i].bias.grad))
             else:
                 jobs.append((N.TG_DW_HH, dzs[j], acts[i], lin[i].weight.grad, lin[i].bias.grad))
@@ -308,10 +325,11 @@ class GemmMLP:
         if self.dw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0])
+        weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0], self._bchain.stream)
         if ev is not None:
             ev[1].record()
-            per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16}[jb[0]] for jb in jobs)
+            per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16,
+                           N.TG_DW_RH: 2 * H + 16 + H // 8}[jb[0]] for jb in jobs)
             self.dw_events.append((ev[0], ev[1], rows, per_row, f"tg::dw_kernel<{H}>"))
         self._acts = self._bits = None
 
