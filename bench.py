@@ -511,10 +511,11 @@ def main():
                                      "avg_launch_us": 1e6 * dur / len(launches), "event_pair_overhead_us": 1e3 * ev_overhead_ms}
         # ---- the three hand-written learner kernel families: every launch of the timed steps, HIP events on the launch stream ----
         kernels = {}
-        notes = {"dw": "tg_mlp_weight_grad: every weight + hidden bias gradient of a net in one launch; algorithmic bytes = each dZ "
-                       "and stored activation read once (the first activation is recomputed from the 64-B input row)",
+        notes = {"dw": "tg_mlp_weight_grad: every weight + hidden bias gradient of a net in one launch; algorithmic bytes = each stored dZ "
+                       "and activation read once (the first activation is recomputed from the 64-B input row, the top layer's dZ "
+                       "from the 16-B head gradient + 32 B of mask bits)",
                  "bwd": "tg_mlp_backward_chain: the dZ of all hidden layers in one launch; 16 B + per layer 32 B of mask bits read "
-                        "and 512 B of dZ written",
+                        "and, for every layer but the top one, 512 B of dZ written",
                  "fwd": "tg_mlp_forward_chain (training passes): 64 B read; per stored layer 512 B of activations + 32 B of mask "
                         "bits written (the first activation is not stored)"}
         for fam, ls in fam_launches.items():

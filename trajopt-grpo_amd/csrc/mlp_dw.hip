@@ -377,11 +377,15 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
         if constexpr (KIND == DW_HR) {
             qb = lds_c + R::QT_OFF + parity * G::PANEL;
             parity ^= 1;
-            if (sg + nb < n_st) recompute_a0(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);   // the next stage's tile
         } else if constexpr (KIND == DW_RH) {
             pb = lds_c + R::QT_OFF + parity * G::PANEL;
             parity ^= 1;
-            if (sg + nb < n_st) recompute_dz(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);
+        }
+        if constexpr (R::kRecomp) {
+            if (sg + nb < n_st) {
+                if constexpr (KIND == DW_HR) recompute_a0(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);
+                else recompute_dz(lds_c + slot * R::SLOT, lds_c + R::QT_OFF + parity * G::PANEL);
+            }
         }
 
         if constexpr (kSquare) {
