@@ -1341,7 +1341,7 @@ def test_weight_gradient_kernel_matches_fp64(tg, dev, H, rows):
 
 
 @pytest.mark.parametrize("H,layers", [(256, 5), (128, 3)])
-@pytest.mark.parametrize("rows", [255, 40000])
+@pytest.mark.parametrize("rows", [1, 31, 255, 40000])
 def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, layers, rows):
     """Kind HR of tg_mlp_weight_grad rebuilds relu(W0 x + b0) on chip from the 64-B input row instead of reading the
     stored activation: bit-identical to the HH job on what tg_mlp_forward_chain stored."""
@@ -1367,7 +1367,7 @@ def test_weight_gradient_kernel_recomputes_the_first_activation(tg, dev, H, laye
 
 
 @pytest.mark.parametrize("H,layers,A", [(256, 5, 4), (128, 3, 1), (256, 3, 8)])
-@pytest.mark.parametrize("rows", [255, 40000])
+@pytest.mark.parametrize("rows", [1, 31, 255, 40000])
 def test_weight_gradient_kernel_recomputes_the_top_layer_dz(tg, dev, H, layers, A, rows):
     """Kind RH of tg_mlp_weight_grad rebuilds dZ_top = (dOut . W_head) * (a_top > 0) on chip from the 16-B head gradient row and
     the layer's mask bits instead of reading a stored dZ; tg_mlp_backward_chain then leaves that store out (d_dz[0] = NULL).
