@@ -287,6 +287,9 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ordinary loads: none may be counted in the ring
+        // ... and hipcc must SEE them complete here: its own wait insertion does not look into the asm above, would still count
+        // these registers as pending at the loop header and drain the DMA ring (vmcnt(0)) at their first use in EVERY stage
+        asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(b0v[0]), "+v"(b0v[1]));
     }
     // RH: this wave's 32 top-layer features (block `wave`) of W_head^T, in the backward chain's own layout
     if constexpr (KIND == DW_RH) {
@@ -295,6 +298,7 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
             for (int f = 0; f < 2; ++f) w0[f] = __builtin_bit_cast(bf16x8, args.whfrag[(wave * 2 + f) * 64 + lane]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(w0[0]), "+v"(w0[1]));                  // (see HR above)
     }
 
     int64_t sg_issue = my;
