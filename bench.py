@@ -513,7 +513,8 @@ def main():
         kernels = {}
         notes = {"dw": "tg_mlp_weight_grad: every weight + hidden bias gradient of a net in one launch; algorithmic bytes = each stored dZ "
                        "and activation read once (the first activation is recomputed from the 64-B input row, the top layer's dZ "
-                       "from the 16-B head gradient + 32 B of mask bits)",
+                       "from the 16-B head gradient + 32 B of mask bits: 4288 B per row; reading a stored top dZ instead, TG_STORE_TOP_DZ=1, "
+                       "is 4752 B per row at a higher byte rate but 1.5 % more time)",
                  "bwd": "tg_mlp_backward_chain: the dZ of all hidden layers in one launch; 16 B + per layer 32 B of mask bits read "
                         "and, for every layer but the top one, 512 B of dZ written",
                  "fwd": "tg_mlp_forward_chain (training passes): 64 B read; per stored layer 512 B of activations + 32 B of mask "
