@@ -153,7 +153,8 @@ __device__ static inline void dma_wide(const uint16_t* __restrict__ g, int64_t r
         int64_t r = row0 + 4 * rquad + ((lane >> 2) & 3);
         r = r < rows ? r : rows - 1;
         const uint4* src = reinterpret_cast<const uint4*>(g) + r * (H / 8) + (4 * ch + (lane >> 4)) * 4 + (lane & 3);
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, 0);
+        // aux = 2: non-temporal -- every byte of the wide panels is read once (same-box A/B over the cache-policy bits: -1.3 %)
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, 2);
     }
 }
 // kSwz (HR, whose recompute reads the panel as MFMA B fragments, 16 rows x one 16-B chunk per 16 lanes: 4 rows share a bank group
