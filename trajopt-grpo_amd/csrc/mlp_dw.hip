@@ -25,8 +25,15 @@
 //     so the workgroup recomputes each stage's 32 x H tile (4 small MFMAs per wave, same instruction sequence as the forward
 //     chain: identical bits) one stage ahead of its use, straight into the LDS image of a Q panel -- 576 instead of
 //     1024 B per row for that layer, and the forward pass no longer has to write them;
-//   * rows past the end: their (clamped, finite) data is multiplied by zeros -- the dZ fragments of the last stage are
-//     masked in registers;
+//   * the top hidden layer's dZ is not read either (kind RH): dZ_top = (dOut . W_head) * (a_top > 0) is a function of the 16-B
+//     head-gradient row and 32 B of mask bits, rebuilt per stage like a0 (the backward chain's own head block: identical bits), so
+//     tg_mlp_backward_chain need not write it.  Recomputed tiles keep chunk c of a row's 64-byte segment in slot c ^ (row / 4 & 3):
+//     their writers hold 16 rows x one 16-B chunk per 16 lanes, which would be a 4-way bank conflict in the plain image;
+//   * the H x H jobs read their fragments with raw `ds_read_b64_tr_b16` in the order of use and count lgkmcnt themselves (hipcc
+//     waits for all 12 reads of a k-step before the first MFMA): LDS operations return in order, so foreign accesses in the
+//     queue can only make a counted wait stricter;
+//   * rows past the end: their (clamped, finite) data is multiplied by zeros -- the dZ fragments of the one stage that holds
+//     the last rows are masked in registers (a separate instantiation of the stage: the loop over full stages has no branch);
 //   * a second small kernel adds the slabs in a fixed order straight into the gradient windows (the learner's flat
 //     all-reduce bucket): deterministic, no float atomics.
 #include <stdlib.h>
