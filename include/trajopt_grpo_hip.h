@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -325,6 +325,15 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
 int  tg_mlp_backward_chain_blocks(void);
 int  tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
                            void* const* d_dz, const void* const* d_masks, float* d_partial, void* stream);
+/* The same pass with the FIRST layer's weight gradient formed inside it: dW0 = dZ_bottom^T . x contracts over the rows the kernel
+ * already holds, so the bottom layer's dZ is not written (d_dz[n_hidden_layers - 1] may be NULL) and tg_mlp_weight_grad needs no
+ * HX job.  d_x = the net input, bf16 [rows][32], zero padded -- with column 31 set to ONE if the caller wants the first layer's
+ * bias gradient as column 31 of the result.  d_w0_slabs: f32 [*n_slabs][H][32] partial gradients (2 per workgroup; buffer of at
+ * least 2 * tg_mlp_backward_chain_blocks() * H * 32 floats = slab_floats); the caller adds the *n_slabs slabs in order.
+ * Replaces: the bottom Linear's weight.grad / bias.grad of `loss.backward()` (algorithms/ppo.py:181-183). */
+int  tg_mlp_backward_chain_w0(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
+                              void* const* d_dz, const void* const* d_masks, const void* d_x, float* d_w0_slabs, int64_t slab_floats,
+                              int32_t* n_slabs, void* stream);
 
 /* ---- MLP weight gradients, every layer in one persistent launch (what `loss.backward()` leaves in Linear.weight.grad /
  *      .bias.grad: algorithms/ppo.py:181-183, algorithms/grpo.py:143-145) ----

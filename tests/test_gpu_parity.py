@@ -1411,6 +1411,49 @@ def test_weight_gradient_kernel_recomputes_the_top_layer_dz(tg, dev, H, layers, 
     assert float(w_b.abs().max()) > 0 and float(b_b.abs().max()) > 0
 
 
+@pytest.mark.parametrize("H,layers,S,A", [(256, 5, 20, 4), (128, 3, 5, 1), (256, 3, 10, 2)])
+@pytest.mark.parametrize("rows", [1, 255, 777, 40000])
+def test_backward_chain_forms_the_first_layer_gradient(tg, dev, H, layers, S, A, rows):
+    """tg_mlp_backward_chain_w0 contracts the bottom layer's dZ with the net input inside the chain (the dZ is not written, the
+    weight-gradient kernel has no HX job; the bias gradient is the ones column of the input): same gradients as the stored form
+    within fp32 summation order, and dW0 / db0 against an fp64 product of the stored dZ."""
+    from trajopt_grpo_amd import mlp as M
+    torch.manual_seed(rows + H + S)
+    net = tg.NeuralNetwork(S, A, (H,) * layers, "ReLU").to(dev)
+    X = torch.randn(rows, S, device=dev)
+    g = torch.randn(rows, A, device=dev)
+
+    def run(fuse):
+        mlp = M.GemmMLP(net, torch.bfloat16)
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        old = M._FUSE_W0
+        M._FUSE_W0 = fuse
+        try:
+            xp = mlp.prepare_input(X)
+            assert float(xp[:, 31].float().min()) == 1.0 and float(xp[:, S:31].float().abs().max()) == 0.0
+            mlp.forward(xp, keep=True)
+            mlp.backward(g)
+            torch.cuda.synchronize()
+        finally:
+            M._FUSE_W0 = old
+        dz_bottom = None if fuse else mlp._ws.get(f"z{layers - 1}", rows, H, torch.bfloat16, dev).clone()
+        return [p.grad.clone() for p in net.parameters()], dz_bottom, xp
+
+    stored, dz_bottom, xp = run(False)
+    fused, _, _ = run(True)
+    names = [n for n, _ in net.named_parameters()]
+    for n, a, b in zip(names, stored, fused):
+        # (not bit-identical even above the first layer: without the HX job the weight-gradient kernel splits its CUs -- and with
+        # them the fixed-order partial sums of every layer -- differently)
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-5 * scale * max(1.0, (rows / 1000) ** 0.5), n
+    ref = dz_bottom.double().t() @ xp.double()                  # [H][32]: columns < S = dW0, column 31 = db0
+    w0, b0 = fused[0].double(), fused[1].double()
+    tol = 2e-5 * (float(ref.abs().max()) + 1.0) * max(1.0, (rows / 1000) ** 0.5)
+    assert float((w0 - ref[:, :S]).abs().max()) < tol and float((b0 - ref[:, 31]).abs().max()) < tol
+
+
 # --------------------------------------------------------------------------------------------
 # learn() at the shapes the hot learner kernels run, minibatch PPO, the configs' shard sizes
 # --------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 4                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 5                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -93,6 +93,8 @@ SIGNATURES = {
     "tg_dx_relu_bias": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "tg_mlp_backward_chain_blocks": (C.c_int, []),
     "tg_mlp_backward_chain": (C.c_int, [_VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),
+    "tg_mlp_backward_chain_w0": (C.c_int, [_VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP, _I64,
+                                           C.POINTER(C.c_int32), _VP]),
     "tg_mlp_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_weight_grad": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,

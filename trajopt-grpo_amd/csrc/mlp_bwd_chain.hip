@@ -29,7 +29,27 @@ constexpr int kBwdMaxLayers = 6;
 struct BwdChainPtrs {
     uint16_t* dz[kBwdMaxLayers];            // outputs, top hidden layer first: bf16 [rows][H]
     const uint32_t* mask[kBwdMaxLayers];    // ReLU mask bits of the same layers (tg_mlp_forward_chain): u32 [rows][H/32]
+    const uint4* x;                         // kFuse0: the net input, bf16 [rows][32] (column 31 = 1: the bias gradient rides along)
+    float* w0_slabs;                        // kFuse0: f32 [grid][2][H][32] partial first-layer weight gradients
 };
+
+// ---- first layer's weight gradient inside the chain (kFuse0) ----
+// dW0 = dZ1^T . x contracts over rows, which sit on LANES in this kernel, and a wave's own share of it (H x 32 fp32) would be 128
+// registers.  So the eight waves of a workgroup split the OUTPUT: after every block of the last layer each wave leaves its
+// 32 rows x 32 features (2 KiB, masked and rounded exactly as it would have been stored) in a shared LDS tile; one block later
+// -- behind that block's ring barrier -- wave i multiplies the 16 features (i >> 1 & 1) x 16 inputs (i & 1) of that block over
+// the rows of four of the eight waves (i >> 2), fragments through the transposing LDS read as in mlp_dw.hip: 4 MFMAs per wave and
+// block (+ 12 % in the last layer), 4 accumulator registers per block.  dZ1 is never written (-512 B per row), the weight-gradient
+// kernel loses its HX job (-576 B per row), and db0 is column 31 of dW0 because the caller put ones there.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+__device__ static inline bf16x8 tr_frag16(const char* __restrict__ lo_p, const char* __restrict__ hi_p) {
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)lo_p);
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)hi_p);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ static inline void lds_store16(char* __restrict__ p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
 
 // dZ stores (as the forward chain's activation stores): after two 32-feature blocks a lane (col, g) holds, for each of its two
 // rows, 2 x 16 B of the row's 128-B line; the wave transposes the 32 x 128 B through its LDS staging area (chunks XOR-swizzled
@@ -62,7 +82,7 @@ __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
     return v;
 }
 
-template <int H, int WPW>
+template <int H, int WPW, bool kFuse0>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4* __restrict__ dzh, const uint4* __restrict__ wfrag,
                                                                     int32_t n_layers, int64_t rows, BwdChainPtrs ptrs) {
     constexpr int MT = H / 32, KS = H / 16, K8 = H / 32;
@@ -77,6 +97,10 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     uint4* dzs = lds + D * KS * 64;                                     // WPW waves * 64 uint4 (lanes 0..31 used)
     uint4* mks = dzs + WPW * 64;                                        // WPW waves * 3 buffers * 64 uint4
     uint4* stage = mks + WPW * 3 * 64 + (threadIdx.x >> 6) * (32 * 8);   // per wave: 32 rows x 128 B (store_pair)
+    // kFuse0: the same 32 KiB seen as shared tiles T[2][WPW][2 KiB] (the last layer does not store), and behind them the
+    // workgroup's input rows X[2][WPW][2 KiB] (double-buffered over rounds)
+    char* tiles = reinterpret_cast<char*>(mks + WPW * 3 * 64);
+    char* xtiles = tiles + 2 * WPW * 2048;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, col = lane & 15, nib = 4 * (grp & 1);
@@ -88,6 +112,17 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     uint4* my_dzs = dzs + wave * 64;
     uint4* my_mks = mks + wave * 3 * 64;
 
+    // kFuse0: this wave's 32 input rows of `round` (64 B each) into X[round parity][wave], in the tile image [row / 4][row % 4][64 B]
+    // with the 16-B chunk c of a row in slot c ^ (row / 4 & 3) (bank-conflict-free for the transposing reads AND plain: mlp_dw.hip)
+    [[maybe_unused]] auto dma_x0 = [&](int64_t round, int par) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            int64_t r = round * (32 * WPW) + wave * 32 + 16 * pc + (lane >> 2);
+            r = r < rows ? r : rows - 1;
+            const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+            __builtin_amdgcn_global_load_lds(ptrs.x + r * 4 + chunk, (lds_void*)(xtiles + (par * WPW + wave) * 2048 + pc * 1024), 16, 0, 0);
+        }
+    };
     auto dma_dzh = [&](int64_t round) {
         if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
@@ -113,6 +148,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     int mseq = 0;                                   // running layer number of this workgroup; its masks sit in buffer mseq % 3
     dma_dzh(blockIdx.x);
+    if constexpr (kFuse0) dma_x0(blockIdx.x, 0);
     dma_mask(blockIdx.x, 0, 0);
     dma_mask(blockIdx.x, 1, 1);
     for (int b0 = 0; b0 < P; ++b0) {
@@ -144,6 +180,31 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         }
     };
 
+    // kFuse0: this wave's share of dW0 (see BwdChainPtrs): block b's 16 features (wave >> 1 & 1) x 16 inputs (wave & 1), contracted
+    // over the rows of waves 4 (wave >> 2) .. + 3
+    [[maybe_unused]] f32x4 acc0[MT];
+    if constexpr (kFuse0) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc0[b] = f32x4{};
+    }
+    [[maybe_unused]] const int q4 = (lane >> 2) & 3, p4 = lane & 3;
+    [[maybe_unused]] auto frag_off = [&](int t, int hi) {              // lane part of a 16-column fragment read of a 2-KiB tile
+        const int quad = 2 * grp + hi;
+        return quad * 256 + q4 * 64 + (((2 * t + (p4 >> 1)) ^ (quad & 3)) * 16) + (p4 & 1) * 8;
+    };
+    [[maybe_unused]] const int a_lo = frag_off((wave >> 1) & 1, 0), a_hi = frag_off((wave >> 1) & 1, 1);
+    [[maybe_unused]] const int b_lo = frag_off(wave & 1, 0), b_hi = frag_off(wave & 1, 1);
+    [[maybe_unused]] auto owner_work = [&](int b) {
+#pragma unroll
+        for (int ks = 0; ks < WPW / 2; ++ks) {
+            const int v = (WPW / 2) * (wave >> 2) + ks;
+            const char* tb = tiles + ((b & 1) * WPW + v) * 2048;
+            const char* xb = xtiles + v * 2048;
+            const bf16x8 fa = tr_frag16(tb + a_lo, tb + a_hi), fb = tr_frag16(xb + b_lo, xb + b_hi);
+            acc0[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc0[b], 0, 0, 0);
+        }
+    };
+
     for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
         const int64_t row0 = round * (32 * WPW) + wave * 32;
         bf16x8 xin[2][K8], xout[2][K8];
@@ -151,7 +212,12 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 
         // ---- head: dZ_top^T = W_head^T . dOut^T; one block holds all MT output blocks (K padded to 32: one k-step) ----
         {
-            TG_RING_ADVANCE(kWaitN)
+            // (kFuse0: the last layer of the previous round stored nothing: only the one later DMA lies behind this block)
+            if constexpr (kFuse0) { TG_RING_WAIT((P - 1) * (KS / WPW)) } else { TG_RING_WAIT(kWaitN) }
+            TG_RING_NEXT
+            if constexpr (kFuse0) {
+                if (round != (int64_t)blockIdx.x) dma_x0(round, 0);   // everyone is past the previous round's last tile reads (the barrier above)
+            }
             bf16x8 x0[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -187,9 +253,22 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         for (int j = 1; j < n_layers; ++j) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                // (without the head block's stores nothing but the one later DMA lies behind the second block of the first layer)
-                if (mt == 1 && j == 1 && !store_top) { TG_RING_WAIT((P - 1) * (KS / WPW)) } else { TG_RING_WAIT(kWaitN) }
+                // (without the head block's stores nothing but the one later DMA lies behind the second block of the first layer;
+                // kFuse0: nor behind its first block -- the previous round ended without stores -- nor from the third block of the
+                // last layer on, which writes LDS tiles instead of dZ)
+                const bool fused_layer = kFuse0 && j == n_layers - 1;
+                if constexpr (kFuse0) {
+                    if (fused_layer) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's tile writes are done
+                }
+                if ((mt == 1 && j == 1 && !store_top) || (kFuse0 && mt == 0 && j == 1 && !store_top) || (fused_layer && mt >= 2)) {
+                    TG_RING_WAIT((P - 1) * (KS / WPW))
+                } else {
+                    TG_RING_WAIT(kWaitN)
+                }
                 TG_RING_NEXT
+                if constexpr (kFuse0) {
+                    if (fused_layer && mt >= 1) owner_work(mt - 1);   // the tiles of block mt - 1 are complete behind this barrier
+                }
                 if (mt == 0) {
                     prefetch_mask(round, j);
                     mask_words(mw);
@@ -209,7 +288,18 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) xout[c][mt] = masked_pack(acc[0][c], acc[1][c], mw[c][mt >> 1], mt);
-                if (mt & 1) {
+                if (kFuse0 && fused_layer) {
+                    // the block's 32 rows x 32 features into T[mt & 1][wave]; rows past the end (clamped duplicates of the last row)
+                    // as zeros: they must not be counted twice in the contraction
+                    char* tw = tiles + ((mt & 1) * WPW + wave) * 2048;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int row = 16 * c + col;
+                        uint4 o = __builtin_bit_cast(uint4, xout[c][mt]);
+                        if (row0 + row >= rows) o = uint4{0u, 0u, 0u, 0u};
+                        lds_store16(tw + (row >> 2) * 256 + (row & 3) * 64 + ((grp ^ ((row >> 2) & 3)) * 16), o);
+                    }
+                } else if (mt & 1) {
                     const bf16x8 pa[2] = {xout[0][mt - 1], xout[1][mt - 1]}, pb[2] = {xout[0][mt], xout[1][mt]};
                     store_pair(stage, ptrs.dz[j] + 32 * (mt - 1), row0, rows, H, lane, pa, pb);
                 }
@@ -220,6 +310,21 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                 for (int ks = 0; ks < K8; ++ks) xin[c][ks] = xout[c][ks];
             ++mseq;
         }
+        if constexpr (kFuse0) {                      // the last block's tiles: one plain barrier, then their products
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            owner_work(MT - 1);
+        }
+    }
+    if constexpr (kFuse0) {
+        // this wave's 16 x 16 tiles of the workgroup's partial dW0: slab [workgroup][K half][H][32]
+        float* slab = ptrs.w0_slabs + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * H * 32;
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(32 * b + 16 * ((wave >> 1) & 1) + 4 * grp + r) * 32 + 16 * (wave & 1) + col] = acc0[b][r];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -262,7 +367,7 @@ using namespace tg;
 
 template <int H>
 static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_hidden_layers, int64_t rows, void* const* d_dz,
-                            const void* const* d_masks, float* d_partial, hipStream_t st) {
+                            const void* const* d_masks, float* d_partial, const void* d_x, float* d_w0_slabs, hipStream_t st) {
     constexpr int WPW = 8, KS = H / 16;
     const int grid_max = bwd_chain_blocks();
     if (rows == 0) {
@@ -272,18 +377,30 @@ static int launch_bwd_chain(const void* d_dout8, const void* d_wfrag, int32_t n_
     }
     BwdChainPtrs ptrs{};
     for (int j = 0; j < n_hidden_layers; ++j) {
-        TG_REQUIRE((d_dz[j] || (j == 0 && !d_partial)) && d_masks[j], "tg_mlp_backward_chain: buffer %d is null", j);
+        TG_REQUIRE((d_dz[j] || (j == 0 && !d_partial) || (j == n_hidden_layers - 1 && d_x)) && d_masks[j],
+                   "tg_mlp_backward_chain: buffer %d is null", j);
         ptrs.dz[j] = (uint16_t*)d_dz[j];
         ptrs.mask[j] = (const uint32_t*)d_masks[j];
     }
-    const size_t shmem = (size_t)3 * KS * 1024 + (size_t)WPW * 32 * 128 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024;
-    auto kern = mlp_bwd_chain_kernel<H, WPW>;
-    static LdsOptIn opt_in;
-    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_backward_chain")) return rc;
+    ptrs.x = (const uint4*)d_x;
+    ptrs.w0_slabs = d_w0_slabs;
+    const size_t shmem = (size_t)3 * KS * 1024 + (size_t)WPW * 32 * 128 + (size_t)WPW * 1024 + (size_t)WPW * 3 * 1024 +
+                         (d_x ? (size_t)WPW * 2048 : 0);
     const int64_t n_rounds = ceil_div(rows, (int64_t)32 * WPW);
     const unsigned grid = (unsigned)(n_rounds < grid_max ? n_rounds : grid_max);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint4*)d_dout8, (const uint4*)d_wfrag, n_hidden_layers, rows,
-                       ptrs);
+    if (d_x) {
+        auto kern = mlp_bwd_chain_kernel<H, WPW, true>;
+        static LdsOptIn opt_in;
+        if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_backward_chain_w0")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint4*)d_dout8, (const uint4*)d_wfrag, n_hidden_layers,
+                           rows, ptrs);
+    } else {
+        auto kern = mlp_bwd_chain_kernel<H, WPW, false>;
+        static LdsOptIn opt_in;
+        if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_backward_chain")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint4*)d_dout8, (const uint4*)d_wfrag, n_hidden_layers,
+                           rows, ptrs);
+    }
     TG_LAUNCH_CHECK("tg_mlp_backward_chain");
     if (d_partial) {                     // the legacy bias-gradient contract: column sums of what was just written
         for (int j = 0; j < n_hidden_layers; ++j)
@@ -306,8 +423,27 @@ int tg_mlp_backward_chain(const void* d_dout8, const void* d_wfrag, int32_t hidd
                n_hidden_layers, kBwdMaxLayers);
     TG_REQUIRE(rows >= 0, "tg_mlp_backward_chain: negative row count");
     hipStream_t st = (hipStream_t)stream;
-    return hidden == 256 ? launch_bwd_chain<256>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st)
-                         : launch_bwd_chain<128>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, st);
+    return hidden == 256 ? launch_bwd_chain<256>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, nullptr, nullptr, st)
+                         : launch_bwd_chain<128>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, d_partial, nullptr, nullptr, st);
+}
+
+int tg_mlp_backward_chain_w0(const void* d_dout8, const void* d_wfrag, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
+                             void* const* d_dz, const void* const* d_masks, const void* d_x, float* d_w0_slabs, int64_t slab_floats,
+                             int32_t* n_slabs, void* stream) {
+    TG_REQUIRE(d_dout8 && d_wfrag && d_dz && d_masks && d_x && d_w0_slabs && n_slabs, "tg_mlp_backward_chain_w0: null pointer");
+    TG_REQUIRE(hidden == 256 || hidden == 128, "tg_mlp_backward_chain_w0: hidden width %d unsupported (128, 256)", hidden);
+    TG_REQUIRE(n_hidden_layers >= 3 && n_hidden_layers <= kBwdMaxLayers, "tg_mlp_backward_chain_w0: %d hidden layers outside 3..%d",
+               n_hidden_layers, kBwdMaxLayers);
+    TG_REQUIRE(rows >= 0, "tg_mlp_backward_chain_w0: negative row count");
+    const int64_t n_rounds = ceil_div(rows, (int64_t)32 * 8);
+    const int grid = (int)(n_rounds < bwd_chain_blocks() ? n_rounds : bwd_chain_blocks());
+    *n_slabs = 2 * grid;
+    TG_REQUIRE(slab_floats >= (int64_t)2 * bwd_chain_blocks() * hidden * 32, "tg_mlp_backward_chain_w0: slab buffer of %lld floats < %lld",
+               (long long)slab_floats, (long long)2 * bwd_chain_blocks() * hidden * 32);
+    if (rows == 0) return TG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return hidden == 256 ? launch_bwd_chain<256>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, nullptr, d_x, d_w0_slabs, st)
+                         : launch_bwd_chain<128>(d_dout8, d_wfrag, n_hidden_layers, rows, d_dz, d_masks, nullptr, d_x, d_w0_slabs, st);
 }
 
 }  // extern "C"

@@ -31,6 +31,11 @@ import os
 
 _ROW_BLOCK = 8192
 _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
+_FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
+
+
+def lin_ok(l) -> bool:
+    return l.weight.grad is not None and l.weight.grad.dtype == torch.float32 and l.bias.grad is not None
 _SPLIT_BATCHES = 128
 
 
@@ -129,6 +134,7 @@ class GemmMLP:
         self._dx_partial = None
         self._head_partial = None
         self._dw_ws = None
+        self._w0_slabs = None
         # like dx_events, for every tg_mlp_weight_grad launch / every training (keep=True) tg_mlp_forward_chain launch
         self.dw_events = None
         self.fwd_events = None
@@ -180,6 +186,10 @@ class GemmMLP:
         (into `out` when given: a [M][in_pad] buffer of the compute dtype)."""
         xp = torch.zeros(X.shape[0], self.in_pad, dtype=self.cd, device=X.device) if out is None else out.zero_()
         xp[:, :self.in_dim].copy_(X)
+        if self.in_pad == 32 and self.in_dim < 32:
+            # a padding column of ones: the first layer's weights are zero there (the forward pass does not see it), and
+            # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0
+            xp[:, 31] = 1.0
         return xp
 
     @torch.no_grad()
@@ -297,16 +307,36 @@ class GemmMLP:
         dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) if (j > 0 or store_top) else None for j in range(nh)]
         dz_ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
         m_ptrs = (N.C.c_void_p * nh)(*[bits[L - 1 - j].data_ptr() for j in range(nh)])     # bits[i + 1] masks hidden layer i
+        # the first layer's weight (and, through the ones column of the input, bias) gradient is formed inside the backward chain
+        # from the bottom dZ it holds in registers: that dZ is neither written nor read (TG_FUSE_W0=0: the stored form, kind HX)
+        xin = acts[0]
+        fuse0 = _FUSE_W0 and xin is not None and xin.shape[1] == 32 and self.in_dim < 32 and lin_ok(self.linears[0])
+        if fuse0:
+            dzs[nh - 1] = None
+            dz_ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
+            if self._w0_slabs is None:
+                self._w0_slabs = torch.empty(2 * lib.tg_mlp_backward_chain_blocks() * H * 32, dtype=torch.float32, device=device)
         ev = None
         if self.dx_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        N.check(lib.tg_mlp_backward_chain(dz_head.data_ptr(), self._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
-                                          None, N.stream_ptr(device)), "tg_mlp_backward_chain")
+        if fuse0:
+            n_slabs = N.C.c_int32(0)
+            N.check(lib.tg_mlp_backward_chain_w0(dz_head.data_ptr(), self._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
+                                                 xin.data_ptr(), self._w0_slabs.data_ptr(), self._w0_slabs.numel(),
+                                                 N.C.byref(n_slabs), N.stream_ptr(device)), "tg_mlp_backward_chain_w0")
+        else:
+            N.check(lib.tg_mlp_backward_chain(dz_head.data_ptr(), self._bchain.stream.data_ptr(), H, nh, rows, dz_ptrs, m_ptrs,
+                                              None, N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8) + (nh if store_top else nh - 1) * 2 * H,
-                                   f"tg::mlp_bwd_chain_kernel<{H},8>"))
+            n_stored = nh - (0 if store_top else 1) - (1 if fuse0 else 0)
+            self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8) + n_stored * 2 * H + (64 if fuse0 else 0),
+                                   f"tg::mlp_bwd_chain_kernel<{H},8,{'true' if fuse0 else 'false'}>"))
+        if fuse0 and rows > 0:
+            part = self._w0_slabs[:n_slabs.value * H * 32].view(n_slabs.value, H, 32).sum(0)      # fixed order: deterministic
+            self.linears[0].weight.grad.add_(part[:, :self.in_dim])
+            self.linears[0].bias.grad.add_(part[:, 31])
         if self._dw_ws is None:
             self._dw_ws = weight_grad_workspace(H, device)
         lin = self.linears
@@ -320,7 +350,8 @@ class GemmMLP:
                 jobs.append((N.TG_DW_HR, dzs[j], acts[0], lin[i].weight.grad, lin[i].bias.grad))
             else:
                 jobs.append((N.TG_DW_HH, dzs[j], acts[i], lin[i].weight.grad, lin[i].bias.grad))
-        jobs.append((N.TG_DW_HX, dzs[nh - 1], acts[0], lin[0].weight.grad, lin[0].bias.grad))
+        if not fuse0:
+            jobs.append((N.TG_DW_HX, dzs[nh - 1], acts[0], lin[0].weight.grad, lin[0].bias.grad))
         ev = None
         if self.dw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
