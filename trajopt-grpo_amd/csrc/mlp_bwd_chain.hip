@@ -199,8 +199,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
         for (int ks = 0; ks < WPW / 2; ++ks) {
             const int v = (WPW / 2) * (wave >> 2) + ks;
             const char* tb = tiles + ((b & 1) * WPW + v) * 2048;
+            const bf16x8 fa = tr_frag16(tb + a_lo, tb + a_hi);
             const char* xb = xtiles + v * 2048;
-            const bf16x8 fa = tr_frag16(tb + a_lo, tb + a_hi), fb = tr_frag16(xb + b_lo, xb + b_hi);
+            const bf16x8 fb = tr_frag16(xb + b_lo, xb + b_hi);      // (kept in registers across the round's blocks it spills: slower)
             acc0[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc0[b], 0, 0, 0);
         }
     };
@@ -266,9 +267,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                     TG_RING_WAIT(kWaitN)
                 }
                 TG_RING_NEXT
-                if constexpr (kFuse0) {
-                    if (fused_layer && mt >= 1) owner_work(mt - 1);   // the tiles of block mt - 1 are complete behind this barrier
-                }
+
                 if (mt == 0) {
                     prefetch_mask(round, j);
                     mask_words(mw);
@@ -286,6 +285,11 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                         for (int c = 0; c < 2; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[f][c], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kFuse0) {
+                    // the tiles of block mt - 1 are complete behind this block's barrier; their products go behind this block's own
+                    // (in front of them the fragment reads' latency is exposed: same-box A/B 2522 -> 2513 us per 2^22 rows)
+                    if (fused_layer && mt >= 1) owner_work(mt - 1);
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) xout[c][mt] = masked_pack(acc[0][c], acc[1][c], mw[c][mt >> 1], mt);
                 if (kFuse0 && fused_layer) {
