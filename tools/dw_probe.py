@@ -20,6 +20,7 @@ ap.add_argument("--layers", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--no-recompute", action="store_true", help="read the stored first activation (kind HH) instead of recomputing it (HR)")
 ap.add_argument("--no-rh", action="store_true", help="read a stored top-layer dZ (kind HH) instead of rebuilding it from the head gradient (RH)")
+ap.add_argument("--hx", action="store_true", help="include the first layer's job (kind HX); the learner forms that gradient inside the backward chain")
 ap.add_argument("--no-gemm", action="store_true", help="skip the split-K GEMM comparison (profiling runs)")
 a_ = ap.parse_args()
 rows, H, nh, recompute = a_.rows, a_.hidden, a_.layers, 0 if a_.no_recompute else 1
@@ -48,7 +49,8 @@ for i in range(nh - 1, 0, -1):
         jobs.append((N.TG_DW_HR, dzs[i], xp, lin[i].weight.grad, lin[i].bias.grad))
     else:
         jobs.append((N.TG_DW_HH, dzs[i], acts[i], lin[i].weight.grad, lin[i].bias.grad))
-jobs.append((N.TG_DW_HX, dzs[0], xp, lin[0].weight.grad, lin[0].bias.grad))
+if a_.hx:
+    jobs.append((N.TG_DW_HX, dzs[0], xp, lin[0].weight.grad, lin[0].bias.grad))
 bytes_per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16,
                      N.TG_DW_RH: 2 * H + 16 + H // 8}[j[0]] for j in jobs)
 
@@ -59,7 +61,7 @@ def ours():
 
 def gemms():
     mlp._dw_into(lin[nh].weight.grad, dh, acts[nh])
-    for i in range(nh - 1, -1, -1):
+    for i in range(nh - 1, -1 if a_.hx else 0, -1):
         mlp._dw_into(lin[i].weight.grad, dzs[i], acts[i])
 
 
