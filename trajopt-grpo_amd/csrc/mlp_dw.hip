@@ -583,7 +583,7 @@ static int dw_cus() { return device_cus(); }
 static int64_t dw_row_cost(int H, int kind) {
     static int pct[5] = {0, 0, 0, 0, 0};
     if (pct[0] == 0) {
-        int v[5] = {100, 100, 100, 280, 280};   // HR: measured optimum 270-300 (tools/dw_probe.py, 2^22 rows); RH: the same structure
+        int v[5] = {100, 100, 100, 260, 300};   // HR / RH: measured optimum (tools/dw_probe.py, 2^22 rows, the learner's job set)
         if (const char* e = getenv("TG_DW_COST")) (void)sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
         for (int k = 0; k < 5; ++k) pct[k] = v[k] > 0 ? v[k] : 100;
     }
