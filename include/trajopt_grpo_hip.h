@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -304,6 +304,28 @@ int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act
 int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden,
                           int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_masks,
                           float* d_out, int32_t out_cols, void* stream);
+
+/* The training forward pass with the LOSS HEAD and the head's weight gradient inside it.  The clipped-surrogate / squared-error
+ * gradient of a row (what tg_surrogate_loss + tg_head_prep produce: algorithms/ppo.py:159-179, grpo.py:122-140) is a function of the
+ * head output the kernel holds and of per-row inputs, so d loss / d output is written directly (bf16 [rows][8], the backward
+ * chain's input) and contracted on chip with the top hidden activation: that activation is NOT written (d_acts[n - 1] may be
+ * NULL, as d_acts[0]) and tg_mlp_weight_grad needs no DH job.
+ *   kind 0 (actor): d_act (strides in floats), d_logp_old, d_adv, d_norm (or NULL), var[act_dim], epsilon, surr_coef, kl_coef
+ *   kind 1 (critic): d_ret, d_norm (or NULL), critic_coef              act_dim <= 4
+ *   d_head_slabs  f32 [tg_mlp_forward_chain_blocks()][4][16][H] partial head weight gradients (rows 0..act_dim-1 of each [16][H]);
+ *                 d_bias_partial f32 [blocks][4]; d_work f64 [blocks][4] partial sums (surrogate, squared error, KL, count):
+ *                 the caller adds the first `grid` = min(blocks, ceil(rows / 256)) of each in order. */
+typedef struct tg_chain_loss {
+    int32_t      kind, act_dim;
+    const float* d_act; int64_t act_row_stride, act_col_stride;
+    const float* d_logp_old; const float* d_adv; const float* d_ret; const float* d_norm;
+    float        var[4];
+    float        epsilon, surr_coef, critic_coef, kl_coef;
+    void*        d_dout8; float* d_head_slabs; double* d_work; float* d_bias_partial;
+} tg_chain_loss;
+int  tg_mlp_forward_chain_blocks(void);
+int  tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
+                               int64_t rows, void* const* d_acts, void* const* d_masks, const tg_chain_loss* loss, void* stream);
 
 /* ---- MLP backward-data pass, all hidden layers in one persistent launch ----
  * For Linear(in, H) ReLU [Linear(H, H) ReLU]^(n_hidden_layers-1) Linear(H, out <= 8), H in {128, 256}, 3..6 hidden

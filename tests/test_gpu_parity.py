@@ -1454,6 +1454,73 @@ def test_backward_chain_forms_the_first_layer_gradient(tg, dev, H, layers, S, A,
     assert float((w0 - ref[:, :S]).abs().max()) < tol and float((b0 - ref[:, 31]).abs().max()) < tol
 
 
+@pytest.mark.parametrize("H,layers,S,A,kind", [(256, 5, 20, 4, 0), (256, 5, 20, 1, 1), (128, 3, 5, 1, 0), (128, 3, 5, 1, 1), (256, 3, 10, 2, 0)])
+@pytest.mark.parametrize("rows", [1, 255, 777, 40000])
+def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind, rows):
+    """tg_mlp_forward_chain_loss: the clipped-surrogate (kind 0) / squared-error (kind 1) gradient formed in the forward kernel, the
+    head's weight gradient contracted on chip with the top activation (never written): against forward + tg_surrogate_loss +
+    backward of the same rows -- d loss / d output equal up to 1 bf16 ulp, loss sums to 1e-6, gradients within fp32 summation order."""
+    from trajopt_grpo_amd import mlp as M, hip_ops as K
+    torch.manual_seed(rows + H + S + kind)
+    net = tg.NeuralNetwork(S, A, (H,) * layers, "ReLU").to(dev)
+    X = torch.randn(rows, S, device=dev)
+    act = torch.randn(rows, A, device=dev)
+    lpo = (-0.5 * torch.rand(rows, device=dev) - 1.0).contiguous()
+    adv = torch.randn(rows, device=dev)
+    ret = torch.randn(rows, device=dev)
+    norm = torch.tensor([0.1, 1.3, -0.2, 0.7], device=dev)
+    var = torch.full((A,), 0.3)
+    eps, sc, cc, kc = 0.2, -1.0 / rows, 0.5 / rows, 0.5 / rows
+
+    def grads():
+        return [p.grad.clone() for p in net.parameters()]
+
+    mlp = M.GemmMLP(net, torch.bfloat16)
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    xp = mlp.prepare_input(X)
+    out = mlp.forward(xp, keep=True)
+    if kind == 0:
+        _, s_ref, g_mean, _ = K.surrogate_loss(out, None, act, lpo, adv, None, None, norm, var, eps, sc, 0.0, kc, want_total=False)
+        mlp.backward(g_mean)
+    else:
+        value = out.reshape(-1).contiguous()
+        dummy = torch.zeros(rows, 1, device=dev)
+        _, s_ref, _, g_val = K.surrogate_loss(dummy, value, dummy, lpo, adv, ret, None, norm, torch.ones(1), eps, 0.0, cc, 0.0,
+                                              want_total=False)
+        mlp.backward(g_val.view(rows, 1))
+    dz_ref = mlp._ws.get("z_head", rows, mlp.out_pad, torch.bfloat16, dev).clone()
+    torch.cuda.synchronize()
+    ref = grads()
+
+    mlp2 = M.GemmMLP(net, torch.bfloat16)
+    old = M._FUSE_HEAD
+    M._FUSE_HEAD = True
+    try:
+        assert mlp2.can_fuse_head()
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        if kind == 0:
+            s = mlp2.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=norm, var=var, epsilon=eps, surr_coef=sc, kl_coef=kc)
+        else:
+            s = mlp2.forward_loss(xp, 1, ret=ret, norm=norm, critic_coef=cc)
+        dz = mlp2._dz_head.clone()
+        mlp2.backward_fused()
+        torch.cuda.synchronize()
+    finally:
+        M._FUSE_HEAD = old
+    got = grads()
+    ddz = (dz.float() - dz_ref.float()).abs()
+    assert float((ddz > 2.0 ** -7 * dz_ref.float().abs() + 1e-30).float().mean()) < 1e-3 and float(ddz.max()) <= 2.0 ** -6 * float(dz_ref.float().abs().max())
+    idx = [0, 2, 3] if kind == 0 else [1, 3]
+    for j in idx:
+        # (the two kernels contract a * b + c differently here and there: 1-ulp differences per row)
+        assert abs(float(s[j]) - float(s_ref[j])) <= 1e-6 * (abs(float(s_ref[j])) + 1.0), (j, float(s[j]), float(s_ref[j]))
+    for (n, _), a, b in zip(net.named_parameters(), ref, got):
+        scale = float(a.abs().max()) + 1e-9
+        assert float((a - b).abs().max()) <= 2e-5 * scale * max(1.0, (rows / 1000) ** 0.5), n
+
+
 # --------------------------------------------------------------------------------------------
 # learn() at the shapes the hot learner kernels run, minibatch PPO, the configs' shard sizes
 # --------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 5                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 6                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -54,6 +54,15 @@ class DwJob(C.Structure):
 
 
 TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR, TG_DW_RH = 0, 1, 2, 3, 4
+
+
+class ChainLoss(C.Structure):
+    """tg_chain_loss (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("act_dim", C.c_int32), ("d_act", C.c_void_p), ("act_row_stride", C.c_int64),
+                ("act_col_stride", C.c_int64), ("d_logp_old", C.c_void_p), ("d_adv", C.c_void_p), ("d_ret", C.c_void_p),
+                ("d_norm", C.c_void_p), ("var", C.c_float * 4), ("epsilon", C.c_float), ("surr_coef", C.c_float),
+                ("critic_coef", C.c_float), ("kl_coef", C.c_float), ("d_dout8", C.c_void_p), ("d_head_slabs", C.c_void_p),
+                ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p)]
 
 # name -> (restype, argtypes); every symbol include/trajopt_grpo_hip.h declares
 _P, _I32, _I64, _U64, _F, _VP = C.POINTER, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
@@ -99,6 +108,9 @@ SIGNATURES = {
     "tg_mlp_weight_grad": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
     "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,
                                        _VP]),
+    "tg_mlp_forward_chain_blocks": (C.c_int, []),
+    "tg_mlp_forward_chain_loss": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(ChainLoss), _VP]),
 }
 
 _lib = None

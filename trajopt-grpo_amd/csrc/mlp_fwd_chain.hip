@@ -31,6 +31,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kChainMaxHidden = 8;
 struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; };   // activations, ReLU mask bits (or null)
 
+// kHead: the loss head and the head's weight gradient inside the forward pass (tg_mlp_forward_chain_loss).  The clipped-surrogate
+// / squared-error gradient of a row is a function of the head output the lane holds and of per-row inputs (loss_kernels.hip: the
+// same arithmetic), so d loss / d output is known one block after the top activation: the eight waves pass that activation
+// block by block through shared LDS tiles and split the product dOut^T . a_top over the OUTPUT (as mlp_bwd_chain.hip does for the
+// first layer): the top activation is never written (-512 B per row) and tg_mlp_weight_grad has no DH job (-528 B per row).
+struct ChainLoss {
+    int32_t kind, A;                        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error); A <= 4 outputs
+    const float* act; int64_t act_rs, act_cs;
+    const float* logp_old; const float* adv; const float* ret; const float* norm;
+    float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
+    uint16_t* dout8;                        // out: d loss / d head output, bf16 [rows][8], zero padded (tg_mlp_backward_chain's input)
+    float* head_slabs;                      // out: f32 [grid][4][16][H] partial head weight gradients
+    double* work;                           // out: f64 [grid][4] partial loss sums (surrogate, squared error, KL, count)
+    float* bias_partial;                    // out: f32 [grid][4] partial head bias gradients
+};
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+__device__ static inline bf16x8 tr_frag16(const char* __restrict__ lo_p, const char* __restrict__ hi_p) {
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)lo_p);
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)hi_p);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ static inline void lds_store16(char* __restrict__ p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ static inline float lds_loadf(const float* __restrict__ p) { return *p; }
+__device__ static inline double2 lds_loadd2(const double* __restrict__ p) { return *reinterpret_cast<const double2*>(p); }
+__device__ static inline void lds_stored2(double* __restrict__ p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+
 // 16 B from LDS without telling the compiler it is an LDS read: hipcc makes an LDS read WITHOUT alias-scope metadata wait for
 // every outstanding LDS-DMA (vmcnt(0)), which would drain the weight ring at each block; waits for the read itself.
 __device__ static inline uint4 lds_read_b128_opaque(const uint4* p) {
@@ -150,10 +177,12 @@ __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
 // 16 c + col and 32-feature block, the 8 consecutive features 8 g .. 8 g + 7 -- as accumulators (4 of half f = 0, 4 of f = 1:
 // mlp.FragmentStream arranges the weight rows so), then packed: 16 B that are both the next layer's B operand for k-step =
 // block (natural k order) and a contiguous piece of the activation row.
-template <int H, int WPW, bool kStore, int D, bool kA0>
+template <int H, int WPW, bool kStore, int D, bool kA0, bool kHead = false>
 __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16_t* __restrict__ x, const uint4* __restrict__ wfrag,
                                                                     const float* __restrict__ bias, int32_t n_hh, int64_t rows,
-                                                                    ChainActs acts, float* __restrict__ out, int32_t out_cols) {
+                                                                    ChainActs acts, float* __restrict__ out, int32_t out_cols,
+                                                                    ChainLoss L) {
+    static_assert(!kHead || (kStore && !kA0), "the fused head belongs to the learner's training pass");
     constexpr int MT = H / 32, KS = H / 16, K8 = H / 32;               // blocks per layer, 1-KiB pieces per block, k-steps per block
     constexpr int P = D - 1;
     // counted wait for block c: all but the youngest N vector-memory operations have retired.  Behind DMA(c) there are
@@ -172,6 +201,13 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     float* bias_s = reinterpret_cast<float*>(lds + D * KS * 64);        // (n_hh + 2) * H floats
     uint4* xs = reinterpret_cast<uint4*>(bias_s + (n_hh + 2) * H);      // WPW waves * 2 pieces * 64 uint4
     uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 8);    // per wave: 32 rows x 128 B (store_pair)
+    // kHead: behind the staging area (which the head phase reuses as the shared tiles T[2][WPW][2 KiB]): per wave 1 KiB of d loss /
+    // d output rows ([32][16] bf16), 1 KiB of per-row loss inputs ([8 fields][32 rows] f32), 16 lanes x (4 f64 + 4 f32) of sums
+    char* tiles = reinterpret_cast<char*>(xs + WPW * 128);
+    char* dtiles = tiles + WPW * 32 * 128;
+    float* lin = reinterpret_cast<float*>(dtiles + WPW * 1024) + wave_of(threadIdx.x) * 256;
+    double* sums_d = reinterpret_cast<double*>(dtiles + 2 * WPW * 1024) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4;
+    float* sums_f = reinterpret_cast<float*>(dtiles + 2 * WPW * 1024 + WPW * 16 * 32) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, col = lane & 15;
@@ -179,6 +215,13 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     const int n_blocks = n_hh * MT + 2;
 
     for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
+    if constexpr (kHead) {
+        if (grp == 0) {
+            lds_stored2(sums_d, double2{0.0, 0.0});
+            lds_stored2(sums_d + 2, double2{0.0, 0.0});
+            *reinterpret_cast<float4*>(sums_f) = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();                                  // bias table in place; no DMA outstanding yet
 
     uint4* my_xs = xs + wave * 128;
@@ -194,8 +237,30 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         }
     };
 
+    // kHead: the round's per-row loss inputs, one float per lane and field (lanes 0..31 = the wave's rows), to lin[field][row]
+    [[maybe_unused]] auto dma_loss_inputs = [&](int64_t round) {
+        if (lane < 32) {
+            int64_t r = round * (32 * WPW) + wave * 32 + lane;
+            r = r < rows ? r : rows - 1;
+            if (L.kind == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < L.A) __builtin_amdgcn_global_load_lds(L.act + r * L.act_rs + k * L.act_cs, (lds_void*)(lin + 32 * k), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(L.logp_old + r, (lds_void*)(lin + 32 * 4), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(L.adv + r, (lds_void*)(lin + 32 * 5), 4, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds(L.ret + r, (lds_void*)(lin + 32 * 0), 4, 0, 0);
+            }
+        }
+    };
+    [[maybe_unused]] f32x4 acch[MT];                  // kHead: this wave's 16 x 16 tiles of the head's weight gradient, one per block
+    if constexpr (kHead) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acch[b] = f32x4{};
+    }
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     dma_x(blockIdx.x);
+    if constexpr (kHead) dma_loss_inputs(blockIdx.x);
     for (int b0 = 0; b0 < P; ++b0) {                  // blocks 0..P-1 in flight before the first round
         ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
         pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
@@ -217,7 +282,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 
         // ---- layer 0: [H x 32] . [32 x 32 rows]; one block holds all MT output blocks (one k-step, 2 halves each) ----
         {
-            TG_CHAIN_ADVANCE(kWaitOdd)
+            // (kHead: the top layer of the previous round stored nothing: count the DMAs alone)
+            if constexpr (kHead) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitOdd) }
+            TG_RING_NEXT
             // the x tile was issued a full round ago (or in the prologue): it is older than everything the wait let pass
             bf16x8 x0[2];
 #pragma unroll
@@ -256,10 +323,15 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
             for (int mt = 0; mt < MT; ++mt) {
                 // (the mask bits of this layer's INPUT, activation l: one word per row tile and block for the first MT blocks'
                 // worth of words, after the barrier so that the arithmetic sits beside the block's MFMAs)
-                if (mt & 1) {
-                    if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitOdd) }
+                // (kHead: the top layer stores nothing: from its fourth block on only DMAs lie behind a block, behind its third
+                // one stored pair of the layer below)
+                const bool top_layer = kHead && l == n_hh - 1;
+                if ((kStore && !kA0 && l == 0 && mt < 3) || (top_layer && mt >= 3)) {
+                    TG_RING_WAIT(kWaitMin)
+                } else if ((mt & 1) || (top_layer && mt == 2)) {
+                    TG_RING_WAIT(kWaitOdd)
                 } else {
-                    if (kStore && !kA0 && l == 0 && mt < 3) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitEven) }
+                    TG_RING_WAIT(kWaitEven)
                 }
                 TG_RING_NEXT
                 if (kStore) {                                          // MT words per lane and layer, one per block
@@ -276,7 +348,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 #pragma unroll
                         for (int c = 0; c < 2; ++c) store_mask_words<MT>(acts.m[l], rowc[c], grp, mw[c]);
                     }
-                    if (kStore) {
+                    if (kStore && !top_layer) {
                         const bf16x8 pa[2] = {xout[0][mt - 1], xout[1][mt - 1]}, pb[2] = {xout[0][mt], xout[1][mt]};
                         store_pair(stage, acts.p[l + 1] + 32 * (mt - 1), row0, rows, H, lane, pa, pb);
                     }
@@ -289,7 +361,8 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         }
         // ---- head: <= 16 outputs in half 0 of the block, natural order: register r of lane group g is output 4 g + r ----
         {
-            TG_CHAIN_ADVANCE(kWaitEven)
+            if constexpr (kHead) { TG_RING_WAIT(kWaitMin) } else { TG_RING_WAIT(kWaitEven) }
+            TG_RING_NEXT
             if (kStore && acts.m[n_hh]) {                       // the last hidden activation's mask bits
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -307,30 +380,145 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xin[c][ks], acc[c], 0, 0, 0);
             }
-            if (4 * grp < out_cols) {
+            if (out != nullptr && 4 * grp < out_cols) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     *reinterpret_cast<float4*>(out + rowc[c] * out_cols + 4 * grp) = float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+            }
+            if constexpr (kHead) {
+                // ---- the loss head (loss_kernels.hip::surrogate_loss_kernel, same arithmetic): the g == 0 lanes hold outputs 0..3 of
+                // their two rows; d loss / d output goes to dout8 (for the backward chain) and, padded to 16 columns, to this
+                // wave's LDS tile (the A operand of the head's weight gradient) ----
+                char* dt = dtiles + wave * 1024;
+                if (grp == 0) {
+                    float n_am = 0.f, n_ai = 1.f, n_rm = 0.f, n_ri = 1.f;
+                    if (L.norm != nullptr) { n_am = L.norm[0]; n_ai = L.norm[1]; n_rm = L.norm[2]; n_ri = L.norm[3]; }
+                    double2 s01 = lds_loadd2(sums_d), s23 = lds_loadd2(sums_d + 2);
+                    float4 gs = *reinterpret_cast<const float4*>(sums_f);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int rl = 16 * c + col;
+                        const bool valid = row0 + rl < rows;              // clamped duplicates of the last row contribute nothing
+                        float g[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (valid) {
+                            if (L.kind == 0) {
+                                float quad = 0.f, dmu[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {              // (inv_var is 0 beyond the net's outputs; the tile slots hold zeros)
+                                    const float d = (k < L.A ? lds_loadf(lin + 32 * k + rl) : 0.f) - acc[c][k];
+                                    dmu[k] = d;
+                                    quad += d * d * L.inv_var[k];
+                                }
+                                const float lp = -0.5f * quad + L.logp_const;
+                                const float lpo = lds_loadf(lin + 32 * 4 + rl);
+                                const float adv = (lds_loadf(lin + 32 * 5 + rl) - n_am) * n_ai;
+                                const float rho = expf(lp - lpo);
+                                const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
+                                const float surr1 = rho * adv, surr2 = fminf(fmaxf(rho, lo), hi) * adv;
+                                const bool inside = (rho >= lo) && (rho <= hi);
+                                const float w = inside ? 1.0f : (surr1 < surr2 ? 1.0f : 0.0f);
+                                s01.x += (double)fminf(surr1, surr2);
+                                float dlp = L.surr_coef * adv * rho * w;
+                                if (L.kl_coef != 0.0f) {
+                                    const float eo = expf(lpo);
+                                    s23.x += (double)(eo * (lpo - lp));
+                                    dlp -= L.kl_coef * eo;
+                                }
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) g[k] = dlp * dmu[k] * L.inv_var[k];
+                            } else {
+                                const float d = acc[c][0] - (lds_loadf(lin + rl) - n_rm) * n_ri;
+                                s01.y += (double)(d * d);
+                                g[0] = L.critic_coef * 2.0f * d;
+                            }
+                            s23.y += 1.0;
+                        }
+                        gs.x += g[0]; gs.y += g[1]; gs.z += g[2]; gs.w += g[3];
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const uint4 o = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g[0], g[1]}, bf16x2)),
+                                         __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g[2], g[3]}, bf16x2)), 0u, 0u};
+                        if (valid) *reinterpret_cast<uint4*>(L.dout8 + rowc[c] * 8) = o;     // (a clamped duplicate must not zero the last row)
+                        lds_store16(dt + rl * 32, o);
+                        lds_store16(dt + rl * 32 + 16, uint4{0u, 0u, 0u, 0u});
+                    }
+                    lds_stored2(sums_d, s01);
+                    lds_stored2(sums_d + 2, s23);
+                    *reinterpret_cast<float4*>(sums_f) = gs;
+                }
+                // ---- the head's weight gradient: the top activation passes through the shared tiles block by block; wave i takes
+                // the 16 features (i & 1) of the block over the rows of waves 2 (i >> 1), 2 (i >> 1) + 1 ----
+                const int q4 = (lane >> 2) & 3, p4 = lane & 3;
+                const int d_lo = (2 * grp) * 128 + q4 * 32 + p4 * 8, d_hi = (2 * grp + 1) * 128 + q4 * 32 + p4 * 8;
+                const int nt = wave & 1;
+                const int t_lo = (2 * grp) * 256 + q4 * 64 + (((2 * nt + (p4 >> 1)) ^ ((2 * grp) & 3)) * 16) + (p4 & 1) * 8;
+                const int t_hi = (2 * grp + 1) * 256 + q4 * 64 + (((2 * nt + (p4 >> 1)) ^ ((2 * grp + 1) & 3)) * 16) + (p4 & 1) * 8;
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    char* tw = tiles + ((b & 1) * WPW + wave) * 2048;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int rl = 16 * c + col;
+                        lds_store16(tw + (rl >> 2) * 256 + (rl & 3) * 64 + ((grp ^ ((rl >> 2) & 3)) * 16), __builtin_bit_cast(uint4, xin[c][b]));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int v = 2 * (wave >> 1) + ks;
+                        const char* db = dtiles + v * 1024;
+                        const char* tb = tiles + ((b & 1) * WPW + v) * 2048;
+                        const bf16x8 fa = tr_frag16(db + d_lo, db + d_hi), fb = tr_frag16(tb + t_lo, tb + t_hi);
+                        acch[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acch[b], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next round's loss inputs overwrite what was read above)
+                dma_loss_inputs(round + gridDim.x);
+            }
+        }
+    }
+    if constexpr (kHead) {
+        // partial head weight gradient: slab [workgroup][K quarter][16 outputs][H]; outputs 4 g + r (only < 8 are ever non-zero)
+        float* slab = L.head_slabs + ((int64_t)blockIdx.x * 4 + (wave >> 1)) * 16 * H;
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(4 * grp + r) * H + 32 * b + 16 * (wave & 1) + col] = acch[b][r];
+        // loss sums and head bias sums: the 16 g == 0 lanes of every wave, added in a fixed order
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int j = threadIdx.x & 3;
+            if (threadIdx.x < 4) {
+                double t = 0.0;
+                const double* sd = reinterpret_cast<const double*>(dtiles + 2 * WPW * 1024);
+                for (int q = 0; q < WPW * 16; ++q) t += sd[q * 4 + j];
+                L.work[(int64_t)blockIdx.x * 4 + j] = t;
+            } else {
+                float t = 0.f;
+                const float* sf = reinterpret_cast<const float*>(dtiles + 2 * WPW * 1024 + WPW * 16 * 32);
+                for (int q = 0; q < WPW * 16; ++q) t += sf[q * 4 + j];
+                L.bias_partial[(int64_t)blockIdx.x * 4 + j] = t;
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <int H, bool kStore, int D, bool kA0>
+template <int H, bool kStore, int D, bool kA0, bool kHead = false>
 static int chain_launch(const void* x, const void* wfrag, const float* bias, int n_hh, int64_t rows, const ChainActs& acts, float* out,
-                        int out_cols, hipStream_t st) {
+                        int out_cols, hipStream_t st, const ChainLoss& loss = ChainLoss{}) {
     constexpr int WPW = 8, KS = H / 16;
     const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048 +
-                         (size_t)WPW * 32 * 128;
-    auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D, kA0>;
+                         (size_t)WPW * 32 * 128 + (kHead ? (size_t)2 * WPW * 1024 + (size_t)WPW * 16 * 48 : 0);
+    auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D, kA0, kHead>;
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_forward_chain")) return rc;
     const int cus = device_cus();
     const int64_t n_rounds = ceil_div(rows, (int64_t)32 * WPW);
     const unsigned grid = (unsigned)(n_rounds < cus ? n_rounds : cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPW), shmem, st, (const uint16_t*)x, (const uint4*)wfrag, bias, n_hh, rows, acts, out,
-                       out_cols);
+                       out_cols, loss);
     TG_LAUNCH_CHECK("tg_mlp_forward_chain");
     return TG_OK;
 }
@@ -369,6 +557,45 @@ int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bi
     return !d_acts ? chain_launch<128, false, 4, true>(TG_CHAIN_ARGS)
                    : (a0 ? chain_launch<128, true, 4, true>(TG_CHAIN_ARGS) : chain_launch<128, true, 4, false>(TG_CHAIN_ARGS));
 #undef TG_CHAIN_ARGS
+}
+
+int tg_mlp_forward_chain_blocks(void) { return device_cus(); }
+
+int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
+                              int64_t rows, void* const* d_acts, void* const* d_masks, const tg_chain_loss* loss, void* stream) {
+    TG_REQUIRE(d_x && d_wfrag && d_bias && d_acts && d_masks && loss, "tg_mlp_forward_chain_loss: null pointer");
+    TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_forward_chain_loss: hidden width %d unsupported (128, 256)", hidden);
+    TG_REQUIRE(n_hidden_layers >= 3 && n_hidden_layers <= kChainMaxHidden, "tg_mlp_forward_chain_loss: %d hidden layers outside 3..%d",
+               n_hidden_layers, kChainMaxHidden);
+    TG_REQUIRE(loss->kind == 0 || loss->kind == 1, "tg_mlp_forward_chain_loss: kind %d", loss->kind);
+    TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_forward_chain_loss: %d outputs unsupported (1..4)", loss->act_dim);
+    TG_REQUIRE(loss->d_dout8 && loss->d_head_slabs && loss->d_work && loss->d_bias_partial, "tg_mlp_forward_chain_loss: null output");
+    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && loss->d_logp_old && loss->d_adv),
+               "tg_mlp_forward_chain_loss: missing per-row input");
+    TG_REQUIRE(rows > 0, "tg_mlp_forward_chain_loss: no rows");
+    ChainActs acts{};
+    for (int l = 0; l < n_hidden_layers; ++l) {
+        TG_REQUIRE(d_masks[l] && (d_acts[l] || l == 0 || l == n_hidden_layers - 1), "tg_mlp_forward_chain_loss: buffer %d is null", l);
+        acts.p[l] = (uint16_t*)d_acts[l];
+        acts.m[l] = (uint32_t*)d_masks[l];
+    }
+    TG_REQUIRE(!d_acts[0], "tg_mlp_forward_chain_loss: the first activation is recomputed by tg_mlp_weight_grad, not stored");
+    ChainLoss L{};
+    L.kind = loss->kind; L.A = loss->act_dim;
+    L.act = loss->d_act; L.act_rs = loss->act_row_stride; L.act_cs = loss->act_col_stride;
+    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv; L.ret = loss->d_ret; L.norm = loss->d_norm;
+    float logdet = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        L.inv_var[k] = k < loss->act_dim ? 1.0f / loss->var[k] : 0.f;
+        if (k < loss->act_dim) logdet += logf(loss->var[k]);
+    }
+    L.logp_const = -0.5f * (float)loss->act_dim * 1.8378770664093453f - 0.5f * logdet;
+    L.epsilon = loss->epsilon; L.surr_coef = loss->surr_coef; L.critic_coef = loss->critic_coef; L.kl_coef = loss->kl_coef;
+    L.dout8 = (uint16_t*)loss->d_dout8; L.head_slabs = loss->d_head_slabs; L.work = loss->d_work; L.bias_partial = loss->d_bias_partial;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_hh = n_hidden_layers - 1;
+    return hidden == 256 ? chain_launch<256, true, 4, false, true>(d_x, d_wfrag, d_bias, n_hh, rows, acts, nullptr, 8, st, L)
+                         : chain_launch<128, true, 4, false, true>(d_x, d_wfrag, d_bias, n_hh, rows, acts, nullptr, 8, st, L);
 }
 
 }  // extern "C"

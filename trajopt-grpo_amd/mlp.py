@@ -32,6 +32,7 @@ import os
 _ROW_BLOCK = 8192
 _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
 _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
+_FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "0") == "1"
 
 
 def lin_ok(l) -> bool:
@@ -135,6 +136,8 @@ class GemmMLP:
         self._head_partial = None
         self._dw_ws = None
         self._w0_slabs = None
+        self._head_ws = None
+        self._dz_head = None
         # like dx_events, for every tg_mlp_weight_grad launch / every training (keep=True) tg_mlp_forward_chain launch
         self.dw_events = None
         self.fwd_events = None
@@ -240,6 +243,83 @@ class GemmMLP:
         self._bits = None
         return out if padded else out[:, :self.out_dim].contiguous()
 
+    def can_fuse_head(self) -> bool:
+        """The loss head + the head's weight gradient inside the forward chain (tg_mlp_forward_chain_loss): chain shapes with the
+        backward chain active, at most 4 outputs, fp32 gradient windows."""
+        return (_FUSE_HEAD and self._chain is not None and self._bchain is not None and self.cd == torch.bfloat16
+                and len(self.linears) - 1 >= 3 and self.out_dim <= 4 and all(lin_ok(l) for l in self.linears)
+                and self.linears[-1].weight.grad.stride(1) == 1)
+
+    @torch.no_grad()
+    def forward_loss(self, xp: torch.Tensor, kind: int, *, act=None, logp_old=None, adv=None, ret=None, norm=None, var=None,
+                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0) -> torch.Tensor:
+        """Training forward pass with the loss head inside it (kind 0: actor, clipped surrogate; kind 1: critic, squared error).
+        Stores what backward_fused() needs, adds the head's weight / bias gradient into their windows and returns the f64 sums
+        [surrogate, squared error, KL, count] of these rows."""
+        lib = N.load()
+        self._fresh("chain")
+        L = len(self.linears)
+        rows, H, dev = xp.shape[0], self._chain.H, xp.device
+        hid = [None if i in (0, L - 2) else self._ws.get(f"a{i}", rows, H, self.cd, dev) for i in range(L - 1)]
+        bits = [self._ws.get(f"m{i}", rows, H // 32, torch.int32, dev) for i in range(L - 1)]
+        dz_head = self._ws.get("z_head", rows, self.out_pad, self.cd, dev)
+        nblk = lib.tg_mlp_forward_chain_blocks()
+        if self._head_ws is None:
+            self._head_ws = (torch.empty(nblk * 4 * 16 * H, dtype=torch.float32, device=dev),
+                             torch.empty(nblk * 4, dtype=torch.float64, device=dev),
+                             torch.empty(nblk * 4, dtype=torch.float32, device=dev))
+        slabs, work, bpart = self._head_ws
+        a = N.ChainLoss()
+        a.kind, a.act_dim = kind, self.out_dim
+        if kind == 0:
+            N.require_cuda(act, logp_old, adv)
+            assert act.dtype == torch.float32 and logp_old.dtype == torch.float32 and adv.dtype == torch.float32
+            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim)
+            a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
+            a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
+            va = [float(v) for v in (var.tolist() if isinstance(var, torch.Tensor) else var)]
+            for i in range(self.out_dim):
+                a.var[i] = va[i]
+        else:
+            N.require_cuda(ret)
+            assert ret.dtype == torch.float32 and ret.is_contiguous() and self.out_dim == 1
+            a.d_ret = ret.data_ptr()
+            a.var[0] = 1.0
+        a.d_norm = N.ptr(norm)
+        a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
+        a.d_dout8, a.d_head_slabs, a.d_work, a.d_bias_partial = dz_head.data_ptr(), slabs.data_ptr(), work.data_ptr(), bpart.data_ptr()
+        ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid])
+        mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits])
+        ev = None
+        if self.fwd_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(lib.tg_mlp_forward_chain_loss(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H, L - 1,
+                                              rows, ptrs, mptrs, N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_forward_chain_loss")
+        if ev is not None:
+            ev[1].record()
+            stored = sum(1 for t in hid if t is not None)
+            per_row = 2 * self.in_pad + stored * 2 * H + (L - 1) * (H // 8) + 16 + (4 * self.out_dim + 8 if kind == 0 else 4)
+            self.fwd_events.append((ev[0], ev[1], rows, per_row, f"tg::mlp_fwd_chain_kernel<{H},8,true,4,false,true>"))
+        grid = min(nblk, -(-rows // 256))
+        lin = self.linears[-1]
+        hw = slabs[:grid * 4 * 16 * H].view(grid * 4, 16, H).sum(0)               # fixed order: deterministic
+        lin.weight.grad.add_(hw[:self.out_dim])
+        lin.bias.grad.add_(bpart[:grid * 4].view(grid, 4).sum(0)[:self.out_dim])
+        sums = work[:grid * 4].view(grid, 4).sum(0)
+        self._acts = [xp] + hid
+        self._bits = [None] + bits
+        self._dz_head = dz_head
+        return sums
+
+    @torch.no_grad()
+    def backward_fused(self):
+        """The rest of the backward pass after forward_loss(): the backward chain and the weight gradients (no head job)."""
+        acts, bits = self._acts, self._bits
+        assert acts is not None and self._dz_head is not None, "backward_fused() needs forward_loss()"
+        self._backward_chain(self._dz_head, acts, bits, acts[0].shape[0], acts[0].device)
+        self._dz_head = None
+
     def _dw(self, dz: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         """dz^T a in fp32 via a batched GEMM over row blocks (split-K with fp32 partials)."""
         rows = dz.shape[0]
@@ -340,7 +420,8 @@ class GemmMLP:
         if self._dw_ws is None:
             self._dw_ws = weight_grad_workspace(H, device)
         lin = self.linears
-        jobs = [(N.TG_DW_DH, dz_head, acts[L - 1], lin[L - 1].weight.grad, None)]             # head (bias: tg_head_prep)
+        # head (bias: tg_head_prep) -- unless forward_loss() already formed its gradient and did not store the top activation
+        jobs = [(N.TG_DW_DH, dz_head, acts[L - 1], lin[L - 1].weight.grad, None)] if acts[L - 1] is not None else []
         for j in range(nh - 1):
             i = L - 2 - j                                                                      # hidden-to-hidden layer i
             if j == 0 and not store_top:                                                       # top layer: dZ not stored
