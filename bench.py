@@ -513,14 +513,15 @@ def main():
         kernels = {}
         notes = {"dw": "tg_mlp_weight_grad: every weight + hidden bias gradient of a net in one launch; algorithmic bytes = each stored dZ "
                        "and activation read once (the first activation is recomputed from the 64-B input row, the top layer's dZ "
-                       "from the 16-B head gradient + 32 B of mask bits; the first layer's gradient is formed inside the backward chain: "
-                       "3712 B per row.  With a stored top dZ and the first layer's job, TG_STORE_TOP_DZ=1 TG_FUSE_W0=0, it read 4752 B "
+                       "from the 16-B head gradient + 32 B of mask bits; the first layer's gradient is formed inside the backward chain and the "
+                       "head's inside the forward chain: 3184 B per row.  With a stored top dZ and the first layer's job, TG_STORE_TOP_DZ=1 TG_FUSE_W0=0, it read 4752 B "
                        "per row at a higher byte rate and the step took 5 % longer)",
                  "bwd": "tg_mlp_backward_chain: the dZ of all hidden layers in one launch; 16 B + per layer 32 B of mask bits read "
                         "and, for every layer but the top and the bottom one, 512 B of dZ written; the bottom layer's dZ is contracted with the "
                         "64-B input row on chip (the first layer's weight and bias gradient)",
-                 "fwd": "tg_mlp_forward_chain (training passes): 64 B read; per stored layer 512 B of activations + 32 B of mask "
-                        "bits written (the first activation is not stored)"}
+                 "fwd": "tg_mlp_forward_chain_loss (training passes): 64 B + the per-row loss inputs read; per stored layer 512 B of "
+                        "activations + 32 B of mask bits written (neither the first nor the top activation is stored), 16 B of "
+                        "d loss / d output; the loss head and the head's weight gradient are formed inside"}
         for fam, ls in fam_launches.items():
             if not ls:
                 continue

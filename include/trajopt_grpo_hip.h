@@ -310,15 +310,17 @@ int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_b
  * head output the kernel holds and of per-row inputs, so d loss / d output is written directly (bf16 [rows][8], the backward
  * chain's input) and contracted on chip with the top hidden activation: that activation is NOT written (d_acts[n - 1] may be
  * NULL, as d_acts[0]) and tg_mlp_weight_grad needs no DH job.
- *   kind 0 (actor): d_act (strides in floats), d_logp_old, d_adv, d_norm (or NULL), var[act_dim], epsilon, surr_coef, kl_coef
- *   kind 1 (critic): d_ret, d_norm (or NULL), critic_coef              act_dim <= 4
+ *   kind 0 (actor): d_act (contiguous [rows][act_dim]), d_logp_old, d_adv, var[act_dim], epsilon, surr_coef, kl_coef
+ *   kind 1 (critic): d_ret, critic_coef              act_dim <= 4
+ *   norm_mean / norm_inv: the advantage (actor) / return (critic) enters as (x - norm_mean) * norm_inv (0 and 1: as is)
  *   d_head_slabs  f32 [tg_mlp_forward_chain_blocks()][4][16][H] partial head weight gradients (rows 0..act_dim-1 of each [16][H]);
  *                 d_bias_partial f32 [blocks][4]; d_work f64 [blocks][4] partial sums (surrogate, squared error, KL, count):
  *                 the caller adds the first `grid` = min(blocks, ceil(rows / 256)) of each in order. */
 typedef struct tg_chain_loss {
     int32_t      kind, act_dim;
     const float* d_act; int64_t act_row_stride, act_col_stride;
-    const float* d_logp_old; const float* d_adv; const float* d_ret; const float* d_norm;
+    const float* d_logp_old; const float* d_adv; const float* d_ret;
+    float        norm_mean, norm_inv;
     float        var[4];
     float        epsilon, surr_coef, critic_coef, kl_coef;
     void*        d_dout8; float* d_head_slabs; double* d_work; float* d_bias_partial;

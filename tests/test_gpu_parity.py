@@ -1501,9 +1501,10 @@ def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind,
         for p in net.parameters():
             p.grad = torch.zeros_like(p)
         if kind == 0:
-            s = mlp2.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=norm, var=var, epsilon=eps, surr_coef=sc, kl_coef=kc)
+            s = mlp2.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=norm.tolist()[0:2], var=var, epsilon=eps, surr_coef=sc,
+                                  kl_coef=kc)
         else:
-            s = mlp2.forward_loss(xp, 1, ret=ret, norm=norm, critic_coef=cc)
+            s = mlp2.forward_loss(xp, 1, ret=ret, norm=norm.tolist()[2:4], critic_coef=cc)
         dz = mlp2._dz_head.clone()
         mlp2.backward_fused()
         torch.cuda.synchronize()

@@ -20,6 +20,7 @@ ap.add_argument("--layers", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--no-recompute", action="store_true", help="read the stored first activation (kind HH) instead of recomputing it (HR)")
 ap.add_argument("--no-rh", action="store_true", help="read a stored top-layer dZ (kind HH) instead of rebuilding it from the head gradient (RH)")
+ap.add_argument("--dh", action="store_true", help="include the head's job (kind DH); the learner forms that gradient inside the forward chain")
 ap.add_argument("--hx", action="store_true", help="include the first layer's job (kind HX); the learner forms that gradient inside the backward chain")
 ap.add_argument("--no-gemm", action="store_true", help="skip the split-K GEMM comparison (profiling runs)")
 a_ = ap.parse_args()
@@ -40,7 +41,7 @@ dh = torch.zeros(rows, 8, device=dev, dtype=torch.bfloat16)
 dh[:, :4] = torch.randn(rows, 4, device=dev)
 lin = mlp.linears
 ws = M.weight_grad_workspace(H, dev)
-jobs = [(N.TG_DW_DH, dh, acts[nh], lin[nh].weight.grad, None)]
+jobs = [(N.TG_DW_DH, dh, acts[nh], lin[nh].weight.grad, None)] if a_.dh else []
 for i in range(nh - 1, 0, -1):
     if i == nh - 1 and not a_.no_rh and nh >= 3:
         mlp.forward(xp, keep=True)                # (chain mode: mask bits; the activations are the same)
@@ -60,7 +61,8 @@ def ours():
 
 
 def gemms():
-    mlp._dw_into(lin[nh].weight.grad, dh, acts[nh])
+    if a_.dh:
+        mlp._dw_into(lin[nh].weight.grad, dh, acts[nh])
     for i in range(nh - 1, -1 if a_.hx else 0, -1):
         mlp._dw_into(lin[i].weight.grad, dzs[i], acts[i])
 

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--layers", type=int, default=5)
+    ap.add_argument("--fused-head", action="store_true",
+                    help="time tg_mlp_forward_chain_loss (the learner's training pass: loss head + head gradient inside, no top activation store) only")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     net = tg.NeuralNetwork(20, 4, (a.hidden,) * a.layers, "ReLU").to(dev)
@@ -41,6 +43,23 @@ def main():
     for rows in a.rows:
         xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
         out = {"rows": rows}
+        if a.fused_head:
+            from trajopt_grpo_amd import mlp as M
+            M._FUSE_HEAD = True
+            for p in net.parameters():
+                p.grad = torch.zeros_like(p)
+            act = torch.randn(rows, 4, device=dev)
+            lpo = (-0.5 * torch.rand(rows, device=dev) - 1.0)
+            adv = torch.randn(rows, device=dev)
+            var = torch.full((4,), 0.3)
+            t_c = timed(lambda: mlp.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, var=var, epsilon=0.2, surr_coef=-1.0 / rows,
+                                                 kl_coef=0.5 / rows), a.iters)
+            bpr = 64 + (L - 2) * 2 * H + L * (H // 8) + 16 + 24
+            out.update(chain_keep_us=t_c, chain_nokeep_us=0.0, bytes_per_row=bpr, fused_head=True, chain_keep_GBps=rows * bpr / t_c / 1e3,
+                       chain_keep_frac_of_8TBps=rows * bpr / t_c / 1e3 / 8000, chain_keep_TFLOPs=flop_row * rows / t_c / 1e6,
+                       note="includes the host-side sums of the head slabs (three small torch kernels per call)")
+            res.append(out)
+            continue
         for keep in (True, False):
             chain = mlp._chain
             t_c = timed(lambda: mlp.forward(xp, keep=keep, padded=True), a.iters)

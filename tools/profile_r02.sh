@@ -10,9 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 PROBES=${@:-dw_probe bwd_chain_probe fwd_chain_probe}
 for probe in $PROBES; do
   case $probe in
-    dw_probe) args="--rows 4194304 --iters 5 --no-gemm"; kern="dw_kernel"; bpr=3712 ;;
+    dw_probe) args="--rows 4194304 --iters 5 --no-gemm"; kern="dw_kernel"; bpr=3184 ;;
     bwd_chain_probe) args="--rows 4194304 --iters 5"; kern="mlp_bwd_chain_kernel"; bpr=1776 ;;
-    fwd_chain_probe) args="--rows 4194304 --iters 5"; kern="mlp_fwd_chain_kernel<256, 8, true"; bpr=2304 ;;
+    fwd_chain_probe) args="--rows 4194304 --iters 5 --fused-head"; kern="mlp_fwd_chain_kernel<256, 8, true"; bpr=1800 ;;
   esac
   python3 $R/tools/$probe.py $args > $OUT/r02_$probe.json 2> $OUT/r02_$probe.err
   rm -rf $OUT/p_$probe

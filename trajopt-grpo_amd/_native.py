@@ -60,7 +60,7 @@ class ChainLoss(C.Structure):
     """tg_chain_loss (include/trajopt_grpo_hip.h)."""
     _fields_ = [("kind", C.c_int32), ("act_dim", C.c_int32), ("d_act", C.c_void_p), ("act_row_stride", C.c_int64),
                 ("act_col_stride", C.c_int64), ("d_logp_old", C.c_void_p), ("d_adv", C.c_void_p), ("d_ret", C.c_void_p),
-                ("d_norm", C.c_void_p), ("var", C.c_float * 4), ("epsilon", C.c_float), ("surr_coef", C.c_float),
+                ("norm_mean", C.c_float), ("norm_inv", C.c_float), ("var", C.c_float * 4), ("epsilon", C.c_float), ("surr_coef", C.c_float),
                 ("critic_coef", C.c_float), ("kl_coef", C.c_float), ("d_dout8", C.c_void_p), ("d_head_slabs", C.c_void_p),
                 ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p)]
 

@@ -209,12 +209,19 @@ class GRPO(_GpuLearner):
         for _ in range(self.updates_per_iter):
             self.bucket.zero_()
             sums = torch.zeros(4, dtype=torch.float64, device=X.device)
+            m_actor = self._mlp(actor)
+            fuse = m_actor is not None and m_actor.can_fuse_head()
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
-                mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
-                _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
-                                                   None, None, var, self.epsilon, coef, 0.0, 0.0, want_total=False)
-                self._backward(actor, mean, g_mean)
+                if fuse:        # loss head + head gradient inside the forward chain (tg_mlp_forward_chain_loss)
+                    s = m_actor.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], var=var,
+                                             epsilon=self.epsilon, surr_coef=coef)
+                    m_actor.backward_fused()
+                else:
+                    mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
+                    _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
+                                                       None, None, var, self.epsilon, coef, 0.0, 0.0, want_total=False)
+                    self._backward(actor, mean, g_mean)
                 sums += s
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
             self.optimizer.step()
@@ -268,8 +275,20 @@ class PPO(_GpuLearner):
         actor, critic = self.policy.actor, self.policy.critic
         self.bucket.zero_()
         sums = torch.zeros(4, dtype=torch.float64, device=xin.device)
+        m_a, m_c = self._mlp(actor), self._mlp(critic)
+        fuse = m_a is not None and m_c is not None and m_a.can_fuse_head() and m_c.can_fuse_head()
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
+            if fuse:            # both loss heads + head gradients inside the forward chains (tg_mlp_forward_chain_loss)
+                nh = self._norm_host
+                s = m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2], var=var,
+                                     epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global)
+                m_a.backward_fused()
+                s2 = m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4], critic_coef=self.c1 / n_global)
+                m_c.backward_fused()
+                sums += s
+                sums[1] += s2[1]
+                continue
             mean = self._forward(actor, xin[lo:hi], train=True, view=True)         # the loss kernel takes a row stride
             vout = self._forward(critic, xin[lo:hi], train=True)
             value = vout.reshape(-1).contiguous()
@@ -311,6 +330,7 @@ class PPO(_GpuLearner):
         inv = 1.0 / (std + 1e-8)
         norm = torch.stack([mean[0].float(), inv[0], mean[1].float(), inv[1]]).contiguous()
         n_global = float(cnt[0].item())
+        self._norm_host = norm.tolist()          # (the fused loss head takes the four numbers as kernel arguments)
         adv = adv_full.reshape(-1).index_select(0, idx)
         ret = rtg.reshape(-1).index_select(0, idx)
         old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)

@@ -36,10 +36,11 @@ struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; }
 // same arithmetic), so d loss / d output is known one block after the top activation: the eight waves pass that activation
 // block by block through shared LDS tiles and split the product dOut^T . a_top over the OUTPUT (as mlp_bwd_chain.hip does for the
 // first layer): the top activation is never written (-512 B per row) and tg_mlp_weight_grad has no DH job (-528 B per row).
-struct ChainLoss {
+struct ChainLoss {                          // (kept small: every field is a scalar register for the whole kernel)
     int32_t kind, A;                        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error); A <= 4 outputs
-    const float* act; int64_t act_rs, act_cs;
-    const float* logp_old; const float* adv; const float* ret; const float* norm;
+    const float* act;                       // actor: [rows][A] contiguous;  critic: the returns [rows]
+    const float* logp_old; const float* adv;
+    float n_m, n_i;                         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
     float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
     uint16_t* dout8;                        // out: d loss / d head output, bf16 [rows][8], zero padded (tg_mlp_backward_chain's input)
     float* head_slabs;                      // out: f32 [grid][4][16][H] partial head weight gradients
@@ -130,7 +131,10 @@ __device__ static inline void store_mask_words(uint32_t* __restrict__ g, int64_t
 #pragma unroll
     for (int i = 0; i < MT / 2; ++i) full[i] = w[i] | (uint32_t)__builtin_amdgcn_ds_swizzle((int)w[i], 0x401F);   // xor 0x10
     if ((grp & 1) == 0) {
-        uint32_t* p = g + row * MT + (grp >> 1) * (MT / 2);
+        int half_off = (grp >> 1) * (MT / 2);
+        asm volatile("" : "+v"(half_off));        // (rebuilt at every use: hoisted, the 64-bit lane address is a register pair the
+                                                  // fused-head variant does not have -- it spilled, and a spill reload drains the ring)
+        uint32_t* p = g + row * MT + half_off;
         if constexpr (MT == 8) *reinterpret_cast<uint4*>(p) = uint4{full[0], full[1], full[2], full[3]};
         else *reinterpret_cast<uint2*>(p) = uint2{full[0], full[1]};
     }
@@ -203,11 +207,14 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     uint4* stage = xs + WPW * 128 + wave_of(threadIdx.x) * (32 * 8);    // per wave: 32 rows x 128 B (store_pair)
     // kHead: behind the staging area (which the head phase reuses as the shared tiles T[2][WPW][2 KiB]): per wave 1 KiB of d loss /
     // d output rows ([32][16] bf16), 1 KiB of per-row loss inputs ([8 fields][32 rows] f32), 16 lanes x (4 f64 + 4 f32) of sums
-    char* tiles = reinterpret_cast<char*>(xs + WPW * 128);
-    char* dtiles = tiles + WPW * 32 * 128;
-    float* lin = reinterpret_cast<float*>(dtiles + WPW * 1024) + wave_of(threadIdx.x) * 256;
-    double* sums_d = reinterpret_cast<double*>(dtiles + 2 * WPW * 1024) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4;
-    float* sums_f = reinterpret_cast<float*>(dtiles + 2 * WPW * 1024 + WPW * 16 * 32) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4;
+    // (addresses are rebuilt where they are used: the kernel has no registers to keep them in)
+#define TG_HEAD_LDS                                                                                                              \
+    char* tiles = reinterpret_cast<char*>(xs + WPW * 128);                                                                       \
+    char* dtiles = tiles + WPW * 32 * 128;                                                                                       \
+    [[maybe_unused]] float* lin = reinterpret_cast<float*>(dtiles + WPW * 1024) + wave_of(threadIdx.x) * 256;                    \
+    [[maybe_unused]] double* sums_d = reinterpret_cast<double*>(dtiles + 2 * WPW * 1024) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4; \
+    [[maybe_unused]] float* sums_f = reinterpret_cast<float*>(dtiles + 2 * WPW * 1024 + WPW * 16 * 32) + (wave_of(threadIdx.x) * 16 + (threadIdx.x & 15)) * 4; \
+    [[maybe_unused]] float* hacc = reinterpret_cast<float*>(dtiles + 2 * WPW * 1024 + WPW * 16 * 48) + (wave_of(threadIdx.x) * MT * 16 + (threadIdx.x & 15)) * 4;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, col = lane & 15;
@@ -216,7 +223,10 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 
     for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
     if constexpr (kHead) {
+        TG_HEAD_LDS
         if (grp == 0) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b) *reinterpret_cast<float4*>(hacc + b * 64) = float4{0.f, 0.f, 0.f, 0.f};
             lds_stored2(sums_d, double2{0.0, 0.0});
             lds_stored2(sums_d + 2, double2{0.0, 0.0});
             *reinterpret_cast<float4*>(sums_f) = float4{0.f, 0.f, 0.f, 0.f};
@@ -239,25 +249,24 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 
     // kHead: the round's per-row loss inputs, one float per lane and field (lanes 0..31 = the wave's rows), to lin[field][row]
     [[maybe_unused]] auto dma_loss_inputs = [&](int64_t round) {
+        TG_HEAD_LDS
         if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
             r = r < rows ? r : rows - 1;
             if (L.kind == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < L.A) __builtin_amdgcn_global_load_lds(L.act + r * L.act_rs + k * L.act_cs, (lds_void*)(lin + 32 * k), 4, 0, 0);
+                    if (k < L.A) __builtin_amdgcn_global_load_lds(L.act + r * L.A + k, (lds_void*)(lin + 32 * k), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(L.logp_old + r, (lds_void*)(lin + 32 * 4), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(L.adv + r, (lds_void*)(lin + 32 * 5), 4, 0, 0);
             } else {
-                __builtin_amdgcn_global_load_lds(L.ret + r, (lds_void*)(lin + 32 * 0), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(L.act + r, (lds_void*)(lin + 32 * 0), 4, 0, 0);
             }
         }
     };
-    [[maybe_unused]] f32x4 acch[MT];                  // kHead: this wave's 16 x 16 tiles of the head's weight gradient, one per block
-    if constexpr (kHead) {
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acch[b] = f32x4{};
-    }
+    // kHead: this wave's tiles of the head's weight gradient live in LDS, not in registers (32 more registers spill, and a spill
+    // reload is a vector-memory operation: hipcc then drains the weight ring around it): only outputs 0..3 can be non-zero, i.e.
+    // the 16 lanes g == 0 of every 16 x 16 tile: hacc[wave][block][lane] float4, read-modify-written by its one owner lane
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     dma_x(blockIdx.x);
     if constexpr (kHead) dma_loss_inputs(blockIdx.x);
@@ -386,17 +395,16 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                     *reinterpret_cast<float4*>(out + rowc[c] * out_cols + 4 * grp) = float4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
             }
             if constexpr (kHead) {
+                TG_HEAD_LDS
                 // ---- the loss head (loss_kernels.hip::surrogate_loss_kernel, same arithmetic): the g == 0 lanes hold outputs 0..3 of
                 // their two rows; d loss / d output goes to dout8 (for the backward chain) and, padded to 16 columns, to this
                 // wave's LDS tile (the A operand of the head's weight gradient) ----
                 char* dt = dtiles + wave * 1024;
                 if (grp == 0) {
-                    float n_am = 0.f, n_ai = 1.f, n_rm = 0.f, n_ri = 1.f;
-                    if (L.norm != nullptr) { n_am = L.norm[0]; n_ai = L.norm[1]; n_rm = L.norm[2]; n_ri = L.norm[3]; }
-                    double2 s01 = lds_loadd2(sums_d), s23 = lds_loadd2(sums_d + 2);
-                    float4 gs = *reinterpret_cast<const float4*>(sums_f);
-#pragma unroll
+                    // (few values live at a time: the kernel has no registers to spare, and a spill here costs the whole ring)
+#pragma unroll 1
                     for (int c = 0; c < 2; ++c) {
+                        float c_surr = 0.f, c_crit = 0.f, c_kl = 0.f, c_cnt = 0.f;
                         const int rl = 16 * c + col;
                         const bool valid = row0 + rl < rows;              // clamped duplicates of the last row contribute nothing
                         float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -411,29 +419,39 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                                 }
                                 const float lp = -0.5f * quad + L.logp_const;
                                 const float lpo = lds_loadf(lin + 32 * 4 + rl);
-                                const float adv = (lds_loadf(lin + 32 * 5 + rl) - n_am) * n_ai;
+                                const float adv = (lds_loadf(lin + 32 * 5 + rl) - L.n_m) * L.n_i;
                                 const float rho = expf(lp - lpo);
                                 const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
                                 const float surr1 = rho * adv, surr2 = fminf(fmaxf(rho, lo), hi) * adv;
                                 const bool inside = (rho >= lo) && (rho <= hi);
                                 const float w = inside ? 1.0f : (surr1 < surr2 ? 1.0f : 0.0f);
-                                s01.x += (double)fminf(surr1, surr2);
+                                c_surr = fminf(surr1, surr2);
                                 float dlp = L.surr_coef * adv * rho * w;
                                 if (L.kl_coef != 0.0f) {
                                     const float eo = expf(lpo);
-                                    s23.x += (double)(eo * (lpo - lp));
+                                    c_kl = eo * (lpo - lp);
                                     dlp -= L.kl_coef * eo;
                                 }
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) g[k] = dlp * dmu[k] * L.inv_var[k];
                             } else {
-                                const float d = acc[c][0] - (lds_loadf(lin + rl) - n_rm) * n_ri;
-                                s01.y += (double)(d * d);
+                                const float d = acc[c][0] - (lds_loadf(lin + rl) - L.n_m) * L.n_i;
+                                c_crit = d * d;
                                 g[0] = L.critic_coef * 2.0f * d;
                             }
-                            s23.y += 1.0;
+                            c_cnt = 1.0f;
                         }
-                        gs.x += g[0]; gs.y += g[1]; gs.z += g[2]; gs.w += g[3];
+                        {
+                            double2 t01 = lds_loadd2(sums_d);
+                            t01.x += (double)c_surr; t01.y += (double)c_crit;
+                            lds_stored2(sums_d, t01);
+                            double2 t23 = lds_loadd2(sums_d + 2);
+                            t23.x += (double)c_kl; t23.y += (double)c_cnt;
+                            lds_stored2(sums_d + 2, t23);
+                            float4 gs = lds_float4(sums_f);
+                            gs.x += g[0]; gs.y += g[1]; gs.z += g[2]; gs.w += g[3];
+                            lds_store16(reinterpret_cast<char*>(sums_f), __builtin_bit_cast(uint4, gs));
+                        }
                         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         const uint4 o = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g[0], g[1]}, bf16x2)),
@@ -442,9 +460,6 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                         lds_store16(dt + rl * 32, o);
                         lds_store16(dt + rl * 32 + 16, uint4{0u, 0u, 0u, 0u});
                     }
-                    lds_stored2(sums_d, s01);
-                    lds_stored2(sums_d + 2, s23);
-                    *reinterpret_cast<float4*>(sums_f) = gs;
                 }
                 // ---- the head's weight gradient: the top activation passes through the shared tiles block by block; wave i takes
                 // the 16 features (i & 1) of the block over the rows of waves 2 (i >> 1), 2 (i >> 1) + 1 ----
@@ -464,13 +479,19 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    f32x4 t = {};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const int v = 2 * (wave >> 1) + ks;
                         const char* db = dtiles + v * 1024;
                         const char* tb = tiles + ((b & 1) * WPW + v) * 2048;
                         const bf16x8 fa = tr_frag16(db + d_lo, db + d_hi), fb = tr_frag16(tb + t_lo, tb + t_hi);
-                        acch[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acch[b], 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, t, 0, 0, 0);
+                    }
+                    if (grp == 0) {
+                        const float4 h = lds_float4(hacc + b * 64);
+                        lds_store16(reinterpret_cast<char*>(hacc + b * 64),
+                                    __builtin_bit_cast(uint4, float4{h.x + t[0], h.y + t[1], h.z + t[2], h.w + t[3]}));
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next round's loss inputs overwrite what was read above)
@@ -479,12 +500,18 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         }
     }
     if constexpr (kHead) {
+        TG_HEAD_LDS
         // partial head weight gradient: slab [workgroup][K quarter][16 outputs][H]; outputs 4 g + r (only < 8 are ever non-zero)
         float* slab = L.head_slabs + ((int64_t)blockIdx.x * 4 + (wave >> 1)) * 16 * H;
+        if (grp == 0) {
 #pragma unroll
-        for (int b = 0; b < MT; ++b)
+            for (int b = 0; b < MT; ++b) {
+                const float4 h = lds_float4(hacc + b * 64);
+                const float hv[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[(4 * grp + r) * H + 32 * b + 16 * (wave & 1) + col] = acch[b][r];
+                for (int r = 0; r < 4; ++r) slab[r * H + 32 * b + 16 * (wave & 1) + col] = hv[r];
+            }
+        }
         // loss sums and head bias sums: the 16 g == 0 lanes of every wave, added in a fixed order
         __syncthreads();
         if (threadIdx.x < 8) {
@@ -510,7 +537,7 @@ static int chain_launch(const void* x, const void* wfrag, const float* bias, int
                         int out_cols, hipStream_t st, const ChainLoss& loss = ChainLoss{}) {
     constexpr int WPW = 8, KS = H / 16;
     const size_t shmem = (size_t)D * KS * 1024 + (size_t)(n_hh + 2) * H * sizeof(float) + (size_t)WPW * 2048 +
-                         (size_t)WPW * 32 * 128 + (kHead ? (size_t)2 * WPW * 1024 + (size_t)WPW * 16 * 48 : 0);
+                         (size_t)WPW * 32 * 128 + (kHead ? (size_t)2 * WPW * 1024 + (size_t)WPW * 16 * 48 + (size_t)WPW * (H / 32) * 16 * 16 : 0);
     auto kern = mlp_fwd_chain_kernel<H, WPW, kStore, D, kA0, kHead>;
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_forward_chain")) return rc;
@@ -572,6 +599,8 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
     TG_REQUIRE(loss->d_dout8 && loss->d_head_slabs && loss->d_work && loss->d_bias_partial, "tg_mlp_forward_chain_loss: null output");
     TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && loss->d_logp_old && loss->d_adv),
                "tg_mlp_forward_chain_loss: missing per-row input");
+    TG_REQUIRE(loss->kind == 1 || (loss->act_col_stride == 1 && loss->act_row_stride == loss->act_dim),
+               "tg_mlp_forward_chain_loss: the actions must be contiguous [rows][act_dim]");
     TG_REQUIRE(rows > 0, "tg_mlp_forward_chain_loss: no rows");
     ChainActs acts{};
     for (int l = 0; l < n_hidden_layers; ++l) {
@@ -582,8 +611,9 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
     TG_REQUIRE(!d_acts[0], "tg_mlp_forward_chain_loss: the first activation is recomputed by tg_mlp_weight_grad, not stored");
     ChainLoss L{};
     L.kind = loss->kind; L.A = loss->act_dim;
-    L.act = loss->d_act; L.act_rs = loss->act_row_stride; L.act_cs = loss->act_col_stride;
-    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv; L.ret = loss->d_ret; L.norm = loss->d_norm;
+    L.act = loss->kind == 0 ? loss->d_act : loss->d_ret;
+    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv;
+    L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
     float logdet = 0.f;
     for (int k = 0; k < 4; ++k) {
         L.inv_var[k] = k < loss->act_dim ? 1.0f / loss->var[k] : 0.f;

@@ -32,7 +32,7 @@ import os
 _ROW_BLOCK = 8192
 _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
 _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
-_FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "0") == "1"
+_FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
 
 
 def lin_ok(l) -> bool:
@@ -274,7 +274,7 @@ class GemmMLP:
         if kind == 0:
             N.require_cuda(act, logp_old, adv)
             assert act.dtype == torch.float32 and logp_old.dtype == torch.float32 and adv.dtype == torch.float32
-            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim)
+            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim) and act.is_contiguous()
             a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
             a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
             va = [float(v) for v in (var.tolist() if isinstance(var, torch.Tensor) else var)]
@@ -285,7 +285,8 @@ class GemmMLP:
             assert ret.dtype == torch.float32 and ret.is_contiguous() and self.out_dim == 1
             a.d_ret = ret.data_ptr()
             a.var[0] = 1.0
-        a.d_norm = N.ptr(norm)
+        # (norm = host pair (mean, 1 / (std + eps)) of the advantage / return, or None)
+        a.norm_mean, a.norm_inv = (0.0, 1.0) if norm is None else (float(norm[0]), float(norm[1]))
         a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
         a.d_dout8, a.d_head_slabs, a.d_work, a.d_bias_partial = dz_head.data_ptr(), slabs.data_ptr(), work.data_ptr(), bpart.data_ptr()
         ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid])
