@@ -468,17 +468,23 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                 const int nt = wave & 1;
                 const int t_lo = (2 * grp) * 256 + q4 * 64 + (((2 * nt + (p4 >> 1)) ^ ((2 * grp) & 3)) * 16) + (p4 & 1) * 8;
                 const int t_hi = (2 * grp + 1) * 256 + q4 * 64 + (((2 * nt + (p4 >> 1)) ^ ((2 * grp + 1) & 3)) * 16) + (p4 & 1) * 8;
-#pragma unroll
-                for (int b = 0; b < MT; ++b) {
+                // tile b + 1 is written right behind barrier b (its buffer was last read for block b - 1, and every wave finished
+                // those reads before it arrived at barrier b): the write's latency passes under block b's products
+                auto write_tile = [&](int b) {
                     char* tw = tiles + ((b & 1) * WPW + wave) * 2048;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const int rl = 16 * c + col;
                         lds_store16(tw + (rl >> 2) * 256 + (rl & 3) * 64 + ((grp ^ ((rl >> 2) & 3)) * 16), __builtin_bit_cast(uint4, xin[c][b]));
                     }
+                };
+                write_tile(0);
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    if (b + 1 < MT) write_tile(b + 1);
                     f32x4 t = {};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
