@@ -21,7 +21,10 @@
 //   * vector-memory operations retire in issue order, stores included, so the counted wait of the ring must allow
 //     for the stores issued since the block it waits for.  The stores are unconditional (rows past the end are
 //     clamped to the last row and rewrite it with identical bytes) and their number per block is a compile-time
-//     pattern (4 after every odd block), so every wait site has its own exact count.
+//     pattern (4 after every odd block), so every wait site has its own exact count;
+//   * the learner's training pass (tg_mlp_forward_chain_loss, template flag kHead) also carries the loss head: d loss / d output
+//     per row in place of the head output, the loss sums, and the head's weight / bias gradient contracted on chip with the
+//     top activation, which is then never written (see ChainLoss below).
 #include "mfma_ring.hpp"
 
 namespace tg {
