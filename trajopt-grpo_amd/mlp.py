@@ -304,8 +304,8 @@ class GemmMLP:
             self.fwd_events.append((ev[0], ev[1], rows, per_row, f"tg::mlp_fwd_chain_kernel<{H},8,true,4,false,true>"))
         grid = min(nblk, -(-rows // 256))
         lin = self.linears[-1]
-        hw = slabs[:grid * 4 * 16 * H].view(grid * 4, 16, H).sum(0)               # fixed order: deterministic
-        lin.weight.grad.add_(hw[:self.out_dim])
+        hw = slabs[:grid * 4 * 16 * H].view(grid * 4, 16, H)[:, :self.out_dim].sum(0)          # fixed order: deterministic
+        lin.weight.grad.add_(hw)                                  # (rows >= 4 of a slab are never written)
         lin.bias.grad.add_(bpart[:grid * 4].view(grid, 4).sum(0)[:self.out_dim])
         sums = work[:grid * 4].view(grid, 4).sum(0)
         self._acts = [xp] + hid
