@@ -26,6 +26,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Cache policy of the chain kernels' activation / dZ stores.  Default: non-temporal (written once, read by a later kernel from
+// beyond the caches anyway at the learner's 4 M-row chunks).  -DTG_ACT_STORE_NT=0 builds the default-policy form for the
+// cache-residency probe (tools/mall_probe.py).
+#ifndef TG_ACT_STORE_NT
+#define TG_ACT_STORE_NT 1
+#endif
+// Probe builds only (tools/mall_probe.py --window): -DTG_PROBE_ROW_WINDOW=W (a power of two) folds every row-indexed global
+// address of the chain / weight-gradient kernels into the first W rows of its buffer.  The results are meaningless; the
+// instruction stream and the bytes moved are those of the real launch, but the streams stay cache-resident: what the update
+// would cost if its activation / dZ round trips were served on-die.  -DTG_DW_LOAD_AUX=0: default cache policy for the
+// weight-gradient kernel's panel loads (the product build reads them non-temporal).
+#ifndef TG_PROBE_ROW_WINDOW
+#define TG_PROBE_ROW_WINDOW 0
+#endif
+#ifndef TG_DW_LOAD_AUX
+#define TG_DW_LOAD_AUX 2
+#endif
+__device__ static inline int64_t mem_row(int64_t r) {
+#if TG_PROBE_ROW_WINDOW
+    return r & (int64_t)(TG_PROBE_ROW_WINDOW - 1);
+#else
+    return r;
+#endif
+}
+typedef unsigned int act_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static inline void act_store16(act_u32x4 v, act_u32x4* p) {
+#if TG_ACT_STORE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // ReLU + bf16 pack of 8 accumulators: round first (v_cvt_pk_bf16_f32, 2 per instruction), then clamp the PACKED halves
 // with v_pk_max_i16(x, 0) -- a negative bf16 (and -0) is a negative int16.  relu(round(x)) == round(relu(x)); 4 + 4
 // instructions instead of 8 v_med3_f32 + 4 conversions (A/B on one box: rollout 8.3 -> 8.1 ms, chain with stores -1.5 %).

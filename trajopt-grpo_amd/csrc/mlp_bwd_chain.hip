@@ -69,9 +69,8 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
         const int r = 8 * j + (lane >> 3), ch = lane & 7;
         const uint4 v = st[r * 8 + (ch ^ (r & 7))];
         int64_t row = row0 + r;
-        row = row < rows ? row : rows - 1;
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * ch));
+        row = row < rows ? row : rows - 1; row = mem_row(row);
+        act_store16(act_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<act_u32x4*>(g + row * ld + 8 * ch));
     }
 }
 
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             int64_t r = round * (32 * WPW) + wave * 32 + 16 * pc + (lane >> 2);
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
             __builtin_amdgcn_global_load_lds(ptrs.x + r * 4 + chunk, (lds_void*)(xtiles + (par * WPW + wave) * 2048 + pc * 1024), 16, 0, 0);
         }
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     auto dma_dzh = [&](int64_t round) {
         if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             __builtin_amdgcn_global_load_lds(dzh + r, (lds_void*)my_dzs, 16, 0, 0);
         }
     };
@@ -136,11 +135,11 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
     auto dma_mask = [&](int64_t round, int j, int buf) {
         if constexpr (MT == 8) {
             int64_t r = round * (32 * WPW) + wave * 32 + (lane >> 1);
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             __builtin_amdgcn_global_load_lds(ptrs.mask[j] + r * MT + (lane & 1) * WPL, (lds_void*)(my_mks + buf * 64), 16, 0, 0);
         } else if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             __builtin_amdgcn_global_load_lds(ptrs.mask[j] + r * MT, (lds_void*)(my_mks + buf * 64), 16, 0, 0);
         }
     };

@@ -158,10 +158,10 @@ __device__ static inline void dma_wide(const uint16_t* __restrict__ g, int64_t r
         const int piece = wave * G::NPW + t;
         const int rquad = piece / (G::CG / 4), ch = piece % (G::CG / 4);
         int64_t r = row0 + 4 * rquad + ((lane >> 2) & 3);
-        r = r < rows ? r : rows - 1;
+        r = r < rows ? r : rows - 1; r = mem_row(r);
         const uint4* src = reinterpret_cast<const uint4*>(g) + r * (H / 8) + (4 * ch + (lane >> 4)) * 4 + (lane & 3);
         // aux = 2: non-temporal -- every byte of the wide panels is read once (same-box A/B over the cache-policy bits: -1.3 %)
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(panel + piece * 1024), 16, 0, TG_DW_LOAD_AUX);
     }
 }
 // kSwz (HR, whose recompute reads the panel as MFMA B fragments, 16 rows x one 16-B chunk per 16 lanes: 4 rows share a bank group
@@ -170,14 +170,14 @@ template <bool kSwz>
 __device__ static inline void dma_x(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* xpanel, int wave, int lane) {
     const int pc = wave & 1;                                        // 2 pieces of 16 rows x 64 B; every wave moves one
     int64_t r = row0 + 16 * pc + (lane >> 2);
-    r = r < rows ? r : rows - 1;
+    r = r < rows ? r : rows - 1; r = mem_row(r);
     const int chunk = kSwz ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3);
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r * 4 + chunk, (lds_void*)(xpanel + pc * 1024), 16, 0, 0);
 }
 __device__ static inline void dma_d8(const uint16_t* __restrict__ g, int64_t row0, int64_t rows, char* panel, int lane) {
     if (lane < 32) {                                                // 32 rows x 16 B
         int64_t r = row0 + lane;
-        r = r < rows ? r : rows - 1;
+        r = r < rows ? r : rows - 1; r = mem_row(r);
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g) + r, (lds_void*)panel, 16, 0, 0);
     }
 }
@@ -192,12 +192,12 @@ __device__ static inline void dma_rh_aux(const uint16_t* __restrict__ dout, cons
         dma_d8(dout, row0, rows, aux, lane);
     } else if constexpr (MT == 8) {
         int64_t r = row0 + (lane >> 1);
-        r = r < rows ? r : rows - 1;
+        r = r < rows ? r : rows - 1; r = mem_row(r);
         __builtin_amdgcn_global_load_lds(bits + r * MT + (lane & 1) * (MT / 2), (lds_void*)(aux + 1024), 16, 0, 0);
     } else {
         if (lane < 32) {
             int64_t r = row0 + lane;
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             __builtin_amdgcn_global_load_lds(bits + r * MT, (lds_void*)(aux + 1024), 16, 0, 0);
         }
     }

@@ -93,10 +93,9 @@ __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __res
         const int r = 8 * j + (lane >> 3), ch = lane & 7;
         const uint4 v = st[r * 8 + (ch ^ (r & 7))];
         int64_t row = row0 + r;
-        row = row < rows ? row : rows - 1;
+        row = row < rows ? row : rows - 1; row = mem_row(row);
         // non-temporal: written once, read by a later kernel (A/B: 2.96 -> 2.91 ms per 2^22 rows)
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(g + row * ld + 8 * ch));
+        act_store16(act_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<act_u32x4*>(g + row * ld + 8 * ch));
     }
 }
 
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             int64_t r = base + 16 * p + (lane >> 2);
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(x) + r * 4 + (lane & 3), (lds_void*)(my_xs + 64 * p), 16, 0,
                                              0);
         }
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         TG_HEAD_LDS
         if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
-            r = r < rows ? r : rows - 1;
+            r = r < rows ? r : rows - 1; r = mem_row(r);
             if (L.kind == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             rowc[c] = row0 + 16 * c + col;
-            rowc[c] = rowc[c] < rows ? rowc[c] : rows - 1;
+            rowc[c] = rowc[c] < rows ? rowc[c] : rows - 1; rowc[c] = mem_row(rowc[c]);
         }
         bf16x8 xin[2][K8], xout[2][K8];
 
