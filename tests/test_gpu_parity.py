@@ -584,6 +584,30 @@ def test_rollout_noise_follows_the_policy_covariance_of_the_moment(tg, dev):
     assert float((a1[:128] - mean0).abs().max()) > 0.1               # sigma = 0.71
 
 
+def test_captured_rollout_graph_follows_a_changed_covariance(tg, dev):
+    """tg_rollout_step takes sigma by value, so a captured hipGraph replays the sigma of its capture: the SAME manager (per-step
+    path, use_graph=True) must re-capture when the covariance changed between two rollouts (the learner would
+    otherwise form its ratios with the new variance against actions drawn with the old one)."""
+    torch.manual_seed(0)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (64, 64), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=16), pol, num_workers=2, num_episodes_per_worker=64, seed=3,
+                            fused=False, use_graph=True)
+    t1 = mgr.rollout_device()
+    assert mgr.engine._graph is not None and not mgr.engine.fused
+    g1 = mgr.engine._graph
+    with torch.no_grad():
+        mean0 = pol.actor(t1.obs_rows()[:128].float())
+    assert float((t1.act_rows().float()[:128] - mean0).abs().max()) > 0.1     # sigma = 0.71
+    mgr.rollout_device()
+    assert mgr.engine._graph is g1                                   # unchanged covariance: the capture is reused
+    pol.cov = 1e-8 * torch.eye(1)
+    t3 = mgr.rollout_device()
+    assert mgr.engine._graph is not g1
+    with torch.no_grad():
+        mean3 = pol.actor(t3.obs_rows()[:128].float())
+    assert float((t3.act_rows().float()[:128] - mean3).abs().max()) < 1e-3     # sigma = 1e-4: the action is the mean
+
+
 # --------------------------------------------------------------------------------------------
 # hand-scheduled MLP (GEMM chain + tg_relu_bwd_bias) against torch autograd
 # --------------------------------------------------------------------------------------------
@@ -739,6 +763,10 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
         acts_keep = [None if a is None else a.clone() for a in acts_c]
         mlp._bchain = bchain
         out_s = mlp.forward(xp, keep=True, padded=True)
+        assert mlp._acts[1] is not None                 # no gradient buffers: backward() could not take the chain path, a0 is kept
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        out_s = mlp.forward(xp, keep=True, padded=True)
         assert mlp._acts[1] is None and torch.equal(out_s, out_c)
         for a_s, a_k in zip(mlp._acts[2:], acts_keep[2:]):
             assert torch.equal(a_s, a_k)
@@ -775,7 +803,75 @@ def test_backward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
         assert torch.equal(x, y)                                   # deterministic reductions
     for (n, _), x, y in zip(net.named_parameters(), a, b):
         denom = float(y.norm()) + 1e-12
-        assert float((x - y).norm()) / denom < 2e-2, n            # the head's product is bf16 x bf16 here, fp32 there
+        # (anchored elementwise to fp64 in test_backward_chain_kernel_matches_fp64; here the two HIP paths differ by the head's
+        # product -- bf16 x bf16 in the chain, fp32 dout in the per-layer path -- and one rounding per layer)
+        assert float((x - y).norm()) / denom < 1e-2, n
+
+
+@pytest.mark.parametrize("dims", [(20, 4, (256,) * 5), (5, 1, (128,) * 3), (10, 2, (256,) * 3), (20, 4, (128,) * 6), (12, 3, (256,) * 4)])
+@pytest.mark.parametrize("rows", [1, 257, 70001, 300000])
+def test_backward_chain_kernel_matches_fp64(tg, dev, dims, rows):
+    """tg_mlp_backward_chain / _w0 (torch autograd's backward-data pass, algorithms/ppo.py:181-183) against fp64: from the same
+    bf16 weights, the stored ReLU mask bits and the bf16 d loss / d output, every layer's dZ = (dZ_above . W) * mask evaluated in
+    fp64 from the chain's OWN stored dZ of the layer above, one bf16 rounding per layer: <= 1 bf16 ulp (2^-7 relative) + the fp32
+    accumulation slack, on every stored element.  rows > 65,536: several rounds per workgroup.  The fused first-layer gradient
+    (_w0: dW0 | db0 = dZ_bottom^T . [x | 1]) against the fp64 product of the fp64-derived bottom dZ."""
+    from trajopt_grpo_amd import mlp as M, _native as N
+    S, A, hidden = dims
+    H, nh = hidden[0], len(hidden)
+    torch.manual_seed(rows + S + nh)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    mlp = M.GemmMLP(net, torch.bfloat16)
+    assert mlp._bchain is not None
+    lib = N.load()
+    xp = mlp.prepare_input(torch.randn(rows, S, device=dev))
+    mlp.forward(xp, keep=True)
+    bits = [None if b is None else b.clone() for b in mlp._bits]            # bits[i + 1] masks hidden layer i
+    acts_mask = []
+    # masks as booleans from the stored bits (layout: _pack_mask_bits)
+    f = torch.arange(H, device=dev)
+    mt, hh, r = f >> 5, (f >> 4) & 1, f & 15
+    word, bit = hh * (H // 64) + (mt >> 1), (mt & 1) * 8 + (r >> 1) + 16 * (r & 1)
+    for i in range(nh):
+        w = bits[i + 1].to(torch.int64) & 0xFFFFFFFF
+        acts_mask.append(((w[:, word] >> bit) & 1).bool())
+    dzh = torch.zeros(rows, 8, dtype=torch.bfloat16, device=dev)
+    dzh[:, :A] = (torch.randn(rows, A, device=dev) * 0.05).bfloat16()
+    mlp._fresh("bchain")
+    m_ptrs = (N.C.c_void_p * nh)(*[bits[nh - j].data_ptr() for j in range(nh)])
+    dzs = [torch.full((rows, H), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(nh)]      # top hidden layer first
+    ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+    N.check(lib.tg_mlp_backward_chain(dzh.data_ptr(), mlp._bchain.stream.data_ptr(), H, nh, rows, ptrs, m_ptrs, None,
+                                      N.stream_ptr(dev)), "tg_mlp_backward_chain")
+    torch.cuda.synchronize()
+    lin = mlp.linears                                                        # lin[i]: layer i; lin[nh] the head
+    above = dzh[:, :A].double()
+    for j in range(nh):
+        i = nh - 1 - j                                                       # dzs[j] = dZ of hidden layer i
+        W = lin[i + 1].weight.detach().to(torch.bfloat16).double()           # [out][in]: dA_i = dZ_{i+1} . W_{i+1}
+        ref = (above @ W) * acts_mask[i]
+        slack = 2e-6 * (above.abs() @ W.abs())                               # fp32 accumulation of K <= 256 products
+        got = dzs[j].double()
+        bad = (got - ref).abs() > 2.0 ** -7 * ref.abs() + slack + 1e-30
+        assert not bool(bad.any()), (j, int(bad.sum()), float((got - ref).abs().max()))
+        assert torch.all(got[~acts_mask[i]] == 0)                           # masked entries are exact zeros
+        above = got                                                          # follow the chain's own stored values
+    # ---- the fused first-layer gradient: the bottom dZ is not written; dW0 | db0 from the chain's registers ----
+    if S < 32:
+        slabs = torch.full((2 * lib.tg_mlp_backward_chain_blocks() * H * 32,), float("nan"), dtype=torch.float32, device=dev)
+        nsl = N.C.c_int32(0)
+        dz2 = [torch.full((rows, H), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(nh)]
+        ptrs2 = (N.C.c_void_p * nh)(*[(t.data_ptr() if 0 < j < nh - 1 else None) for j, t in enumerate(dz2)])
+        N.check(lib.tg_mlp_backward_chain_w0(dzh.data_ptr(), mlp._bchain.stream.data_ptr(), H, nh, rows, ptrs2, m_ptrs, xp.data_ptr(),
+                                             slabs.data_ptr(), slabs.numel(), N.C.byref(nsl), N.stream_ptr(dev)), "tg_mlp_backward_chain_w0")
+        torch.cuda.synchronize()
+        for j in range(1, nh - 1):
+            assert torch.equal(dz2[j], dzs[j])                               # the stored layers do not depend on the fusion
+        got0 = slabs[:nsl.value * H * 32].view(nsl.value, H, 32).double().sum(0)
+        ref0 = dzs[nh - 1].double().t() @ xp.double()                        # [H][32]: columns < S = dW0, column 31 = db0
+        tol = 2e-5 * (float(ref0.abs().max()) + 1e-3) * max(1.0, (rows / 1000) ** 0.5)
+        assert float((got0 - ref0).abs().max()) < tol
+        assert float(got0[:, S:31].abs().max()) == 0.0
 
 
 def test_weight_gradient_split_k_paths_agree(tg, dev):
@@ -1412,7 +1508,7 @@ def test_weight_gradient_kernel_recomputes_the_top_layer_dz(tg, dev, H, layers, 
 
 
 @pytest.mark.parametrize("H,layers,S,A", [(256, 5, 20, 4), (128, 3, 5, 1), (256, 3, 10, 2)])
-@pytest.mark.parametrize("rows", [1, 255, 777, 40000])
+@pytest.mark.parametrize("rows", [1, 255, 777, 40000, 70001, 300000])     # > 65,536 rows: several rounds per workgroup
 def test_backward_chain_forms_the_first_layer_gradient(tg, dev, H, layers, S, A, rows):
     """tg_mlp_backward_chain_w0 contracts the bottom layer's dZ with the net input inside the chain (the dZ is not written, the
     weight-gradient kernel has no HX job; the bias gradient is the ones column of the input): same gradients as the stored form
@@ -1454,8 +1550,38 @@ def test_backward_chain_forms_the_first_layer_gradient(tg, dev, H, layers, S, A,
     assert float((w0 - ref[:, :S]).abs().max()) < tol and float((b0 - ref[:, 31]).abs().max()) < tol
 
 
+def test_caller_padded_input_keeps_the_first_layer_bias_gradient(tg, dev):
+    """the fused first-layer gradient takes db0 from the ones column prepare_input() writes.  An input the caller
+    padded with zeros itself (the documented layout before that fusion) must not get a silently zero bias gradient: it takes
+    the HX job of tg_mlp_weight_grad instead."""
+    from trajopt_grpo_amd import mlp as M
+    torch.manual_seed(5)
+    rows, S, A, H = 3000, 20, 4, 256
+    net = tg.NeuralNetwork(S, A, (H,) * 3, "ReLU").to(dev)
+    X, g = torch.randn(rows, S, device=dev), torch.randn(rows, A, device=dev)
+
+    def run(own_padding):
+        mlp = M.GemmMLP(net, torch.bfloat16)
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        if own_padding:
+            xp = torch.zeros(rows, 32, dtype=torch.bfloat16, device=dev)
+            xp[:, :S] = X
+        else:
+            xp = mlp.prepare_input(X)
+        mlp.forward(xp, keep=True)
+        mlp.backward(g)
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+
+    a, b = run(False), run(True)
+    assert float(a[1].abs().max()) > 0
+    for (n, _), x, y in zip(net.named_parameters(), a, b):
+        assert float((x - y).abs().max()) <= 2e-5 * (float(x.abs().max()) + 1e-6) * 2, n
+
+
 @pytest.mark.parametrize("H,layers,S,A,kind", [(256, 5, 20, 4, 0), (256, 5, 20, 1, 1), (128, 3, 5, 1, 0), (128, 3, 5, 1, 1), (256, 3, 10, 2, 0)])
-@pytest.mark.parametrize("rows", [1, 255, 777, 40000])
+@pytest.mark.parametrize("rows", [1, 255, 777, 40000, 70001, 300000])     # > 65,536 rows: several rounds per workgroup
 def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind, rows):
     """tg_mlp_forward_chain_loss: the clipped-surrogate (kind 0) / squared-error (kind 1) gradient formed in the forward kernel, the
     head's weight gradient contracted on chip with the top activation (never written): against forward + tg_surrogate_loss +
@@ -1661,6 +1787,24 @@ def test_lazy_reference_view_copies_only_what_a_visualiser_reads(tg, dev):
     assert buf.group_observations.shape == (G, Eps, T, 5)            # the full copy, once made, serves everyone
     sub = buf.device_traj.to_reference(max_groups=2, max_episodes=3)
     assert sub[0].shape == (2, 3, T, 5) and torch.equal(sub[2], full[2][:2, :3])
+    # the pipeline scopes the slice to the visualiser's render(): inside the block the view is cut, outside it --
+    # a reference-style CPU learner, a Publisher -- every episode is there again
+    buf.limit_reference_view()                                       # (back to the default: everything)
+    buf.sample()
+    full = buf.device_traj.to_reference()
+
+    class _Vis:
+        max_episodes_per_render = 2
+        seen = None
+
+        def render(self):
+            self.seen = buf.group_observations.clone()
+
+    pipe = tg.Pipeline.__new__(tg.Pipeline)
+    pipe.visualizer, pipe.buffer = _Vis(), buf
+    pipe._render()
+    assert pipe.visualizer.seen.shape == (G, 2, T, 5) and torch.equal(pipe.visualizer.seen, full[0][:, :2])
+    assert buf.group_observations.shape == (G, Eps, T, 5) and torch.equal(buf.group_observations, full[0])
 
 
 CONFIG_SHARDS = [

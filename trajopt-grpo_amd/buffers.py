@@ -9,6 +9,7 @@ reduced over ranks from (sum, count) under torch.distributed.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import numpy as np
@@ -48,6 +49,20 @@ class Rollout_Buffer(Buffer):
         self._ref_limits = (max_groups, max_episodes)
         if not self._ref_is_full:
             self._ref = None
+
+    @contextlib.contextmanager
+    def limited_view(self, max_groups=None, max_episodes=None):
+        """`limit_reference_view` for the duration of a `with` block only: Pipeline wraps a visualiser's render() in it, so the
+        slice is what the visualiser sees while every other consumer of `buffer.group_*` (a reference-style CPU learner, a
+        Publisher) still gets the whole trajectory."""
+        saved = self._ref_limits
+        self.limit_reference_view(max_groups, max_episodes)
+        try:
+            yield self
+        finally:
+            self._ref_limits = saved
+            if not self._ref_is_full:
+                self._ref = None              # a sliced cache must not outlive the block
 
     def _materialise(self, full: bool = False):
         if self._ref is not None and (self._ref_is_full or not full):

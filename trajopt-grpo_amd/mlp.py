@@ -35,6 +35,11 @@ _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
 _FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
 
 
+# address ranges of the input buffers some GemmMLP.prepare_input() gave a column of ones (a property of the buffer, shared by
+# the nets that read it: the learner's actor and critic take the same prepared input)
+_ONES_RANGES = []
+
+
 def lin_ok(l) -> bool:
     return l.weight.grad is not None and l.weight.grad.dtype == torch.float32 and l.bias.grad is not None
 _SPLIT_BATCHES = 128
@@ -191,21 +196,39 @@ class GemmMLP:
         xp[:, :self.in_dim].copy_(X)
         if self.in_pad == 32 and self.in_dim < 32:
             # a padding column of ones: the first layer's weights are zero there (the forward pass does not see it), and
-            # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0
+            # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0.  The address range is
+            # remembered: only inputs prepared HERE (or slices of them) take that path -- a caller that pads its own input
+            # with zeros gets the HX job of tg_mlp_weight_grad instead of a silently zero bias gradient.
             xp[:, 31] = 1.0
+            lo = xp.data_ptr()
+            _ONES_RANGES[:] = [r for r in _ONES_RANGES if r[0] != lo][-15:] + [(lo, lo + xp.numel() * xp.element_size())]
         return xp
+
+    def _has_ones_column(self, xin: torch.Tensor) -> bool:
+        p = xin.data_ptr()
+        return xin.is_contiguous() and any(lo <= p and p + xin.numel() * xin.element_size() <= hi for lo, hi in _ONES_RANGES)
+
+    def _chain_backward_ok(self) -> bool:
+        """backward() can take the chain path (tg_mlp_backward_chain + tg_mlp_weight_grad): fp32 gradients with unit column
+        stride on every layer.  forward(keep=True) decides with the SAME predicate whether the first activation may be left out."""
+        return self._bchain is not None and all(
+            l.weight.grad is not None and l.bias.grad is not None and l.weight.grad.dtype == torch.float32
+            and l.weight.grad.stride(1) == 1 and l.bias.grad.dtype == torch.float32 and l.bias.grad.is_contiguous()
+            for l in self.linears)
 
     @torch.no_grad()
     def forward(self, xp: torch.Tensor, keep: bool = True, padded: bool = False) -> torch.Tensor:
         """-> fp32 [rows][out_dim] (contiguous), or the [rows][out_pad] buffer itself with padded=True
-        (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward()."""
+        (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward().
+        `xp`: [rows][in_pad] compute dtype, zero padded -- normally from prepare_input(), whose ones column (31) lets the
+        backward chain form the first layer's bias gradient; a caller-padded input works too (kind HX job instead)."""
         L = len(self.linears)
         if self._chain is not None and xp.shape[0] > 0:
             self._fresh("chain")
             rows, H = xp.shape[0], self._chain.H
             # with the backward chain active the first hidden activation is never read again: tg_mlp_weight_grad
             # recomputes it from the input row (kind HR), so it is not written either (its mask bits still are)
-            skip_a0 = keep and self._bchain is not None and L - 1 >= 2
+            skip_a0 = keep and L - 1 >= 2 and self._chain_backward_ok()
             hid = [None if (i == 0 and skip_a0) else self._ws.get(f"a{i}", rows, H, self.cd, xp.device)
                    for i in range(L - 1)] if keep else []
             # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
@@ -391,7 +414,8 @@ class GemmMLP:
         # the first layer's weight (and, through the ones column of the input, bias) gradient is formed inside the backward chain
         # from the bottom dZ it holds in registers: that dZ is neither written nor read (TG_FUSE_W0=0: the stored form, kind HX)
         xin = acts[0]
-        fuse0 = _FUSE_W0 and xin is not None and xin.shape[1] == 32 and self.in_dim < 32 and lin_ok(self.linears[0])
+        fuse0 = (_FUSE_W0 and xin is not None and xin.shape[1] == 32 and self.in_dim < 32 and lin_ok(self.linears[0])
+                 and self._has_ones_column(xin))
         if fuse0:
             dzs[nh - 1] = None
             dz_ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
@@ -470,12 +494,10 @@ class GemmMLP:
             dz.zero_()
             dz[:, :self.out_dim].copy_(dout)
             lin.bias.grad.add_(dout.sum(0))
-        if (self._bchain is not None and self._bits is not None and all(l.weight.grad.dtype == torch.float32 and
-                                                                        l.weight.grad.stride(1) == 1 and l.bias.grad.is_contiguous()
-                                                                        for l in self.linears)):
+        if self._bits is not None and self._chain_backward_ok():
             self._backward_chain(dz, acts, bits, rows, dout.device)
             return
-        assert all(a is not None for a in acts), "forward() left out the first activation: the backward chain must run"
+        assert all(a is not None for a in acts), "the gradient buffers changed between forward(keep=True) and backward()"
         self._dw_into(lin.weight.grad, dz, acts[L - 1])
         self._fresh("dx")
         is_bf16 = 1 if self.cd == torch.bfloat16 else 0

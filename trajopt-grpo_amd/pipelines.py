@@ -52,9 +52,7 @@ class Pipeline:
         if self.visualizer is not None:
             # the reference's Dashboard reads only the first max_episodes_per_render episodes of each group
             # (visualize/dashboard.py:206-217): copy just those from the device when it renders
-            k = getattr(self.visualizer, "max_episodes_per_render", None)
-            if k is not None and hasattr(self.buffer, "limit_reference_view"):
-                self.buffer.limit_reference_view(max_episodes=int(k))
+            # (scoped to the render call, `_render`: other readers of buffer.group_* keep the whole trajectory)
             self.visualizer.initialize(metadata)
 
     def load(self) -> None:
@@ -104,9 +102,20 @@ class Pipeline:
             if hasattr(self.visualizer, "plot"):
                 self.visualizer.plot()
             if self.visualizer is not None and epoch % self.render_freq == 0:
-                self.visualizer.render()
+                self._render()
             if epoch % self.save_freq == 0:
                 self.save(self.archive_path)
+
+    def _render(self) -> None:
+        """visualizer.render() with the buffer's lazy CPU view cut to what it draws: the reference's Dashboard reads only the
+        first `max_episodes_per_render` episodes of each group (visualize/dashboard.py:206-217) -- a few MB from the device
+        instead of the whole trajectory (1.7 GB at C3) -- for the duration of the call only."""
+        k = getattr(self.visualizer, "max_episodes_per_render", None)
+        if k is not None and hasattr(self.buffer, "limited_view"):
+            with self.buffer.limited_view(max_episodes=int(k)):
+                self.visualizer.render()
+        else:
+            self.visualizer.render()
 
     def test(self) -> None:
         self.buffer.sample()

@@ -70,11 +70,12 @@ class DeviceTrajectory:
         def cut(x, lead):                        # x [lead...][n] -> [lead...][g][e]
             return x.reshape(*lead, G, E)[..., :g, :e]
 
-        obs = cut(self.obs[:, :T, :], (self.S, T)).permute(2, 3, 1, 0).float().cpu().contiguous()
-        act = cut(self.act, (self.A, T)).permute(2, 3, 1, 0).float().cpu().contiguous()
-        rew = cut(self.rew, (T,)).permute(1, 2, 0).float().cpu().contiguous()
-        mask = cut(self.mask, (T,)).permute(1, 2, 0).float().cpu().contiguous()
-        ln = cut(self.len, ()).float().cpu().contiguous()          # float32, like the manager's torch.zeros (:89)
+        # (the permutation runs on the device: a 1.7 GB strided gather is milliseconds there, seconds on the host)
+        obs = cut(self.obs[:, :T, :], (self.S, T)).permute(2, 3, 1, 0).float().contiguous().cpu()
+        act = cut(self.act, (self.A, T)).permute(2, 3, 1, 0).float().contiguous().cpu()
+        rew = cut(self.rew, (T,)).permute(1, 2, 0).float().contiguous().cpu()
+        mask = cut(self.mask, (T,)).permute(1, 2, 0).float().contiguous().cpu()
+        ln = cut(self.len, ()).float().contiguous().cpu()          # float32, like the manager's torch.zeros (:89)
         return obs, act, rew, ln, mask
 
 
@@ -120,6 +121,7 @@ class DeviceRollout:
                           for l in self._linears]
         self.use_graph = use_graph
         self._graph = None
+        self._graph_baked = None
         # fused persistent rollout kernel (csrc/fused_rollout.hip): whole T-step loop in one launch, actor MLP on
         # the matrix cores.  Auto-selected for bf16 policies whose shape it supports; `fused=True` insists.
         H = M.fused_rollout_supported(policy.actor, self.S, self.A)
@@ -280,6 +282,12 @@ class DeviceRollout:
             lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
             N.check(lib.tg_rollout_begin(C.byref(tr), self.S, self.A, st), "tg_rollout_begin")
             self._reset(tr, st)
+            # tg_rollout_step takes sigma (and the env parameters) BY VALUE in its kernel arguments: a captured graph replays the
+            # values of its capture.  A covariance annealed or restored since then (the learner reads policy.var afresh in every
+            # learn(), actor_critic.py:131-136 reads self.cov in every forward) means a new capture.
+            baked = (tuple(self._sigma), bytes(self.params))
+            if self._graph is not None and baked != self._graph_baked:
+                self._graph = None
             if self._graph is None:
                 side = torch.cuda.Stream(self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
@@ -291,6 +299,7 @@ class DeviceRollout:
                 with torch.cuda.graph(g):
                     self._enqueue_steps(sample=True)
                 self._graph = g
+                self._graph_baked = baked
             self._graph.replay()
 
 
