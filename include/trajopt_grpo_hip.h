@@ -300,7 +300,8 @@ int  tg_dx_relu_bias(const void* d_dz_in, const void* d_wfrag, const void* d_act
  *   d_masks  HOST array of n_hidden_layers device pointers, u32 [rows][H / 32] each, or NULL: the ReLU masks of the
  *            stored activations, 1 bit each (all the backward-data kernels need of them).  Per row: [lane half h = 0, 1]
  *            [H / 64 words]; feature 32 mt + 16 h + r is bit (mt & 1) * 8 + (r >> 1) + 16 * (r & 1) of word mt >> 1
- *   d_out    f32 [rows][out_cols], out_cols in {8, 16} (columns >= out hold the padded head rows: zeros + bias 0) */
+ *   d_out    f32 [rows][out_cols], out_cols in {4, 8, 16} (columns >= out hold the padded head rows: zeros + bias 0; 4 for nets
+ *            with <= 4 outputs: a 16-B row, so that tg_rollout_step reads no padding with the policy mean) */
 int  tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden,
                           int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_masks,
                           float* d_out, int32_t out_cols, void* stream);

@@ -58,8 +58,14 @@ class OraclePolicy:
     """Gaussian actor(-critic) with fixed diagonal covariance.
     actor_critic.py:73-215 (actor only), :220-378 (actor-critic)."""
 
-    def __init__(self, input_dim, output_dim, hidden_dims, activation="ReLU", cov=0.1, critic=False):
+    def __init__(self, input_dim, output_dim, hidden_dims, activation="ReLU", cov=0.1, critic=False,
+                 per_step_distribution=False):
+        """per_step_distribution=True: __call__ builds a torch MultivariateNormal on every call, samples from it and evaluates
+        its log-probability, under autograd -- what the reference's forward does on every env step (actor_critic.py:131-136,
+        :279-284; the worker loop has no no_grad, rollout_worker.py:55).  Same draws and values as the closed form (SURVEY
+        App. C); it is there so that the timed CPU baseline pays what the reference pays (bench.py cpu_baseline)."""
         self.input_dim, self.output_dim = input_dim, output_dim
+        self.per_step_distribution = per_step_distribution
         self.var = torch.tensor(cov if isinstance(cov, list) else [cov] * output_dim, dtype=torch.float32)
         self.actor = MLP(input_dim, output_dim, hidden_dims, activation)
         self.critic = MLP(input_dim, 1, hidden_dims, activation) if critic else None
@@ -69,6 +75,11 @@ class OraclePolicy:
         if isinstance(state, np.ndarray):
             state = torch.from_numpy(state).float()
         mean = self.actor(state)
+        if self.per_step_distribution:
+            dist = torch.distributions.MultivariateNormal(mean, torch.diag(self.var))
+            action = dist.sample()
+            value = self.critic(state) if self.critic is not None else None
+            return action.detach().numpy(), dist.log_prob(action), value
         # MultivariateNormal.sample() == mean + sqrt(var) * randn (bit-exact)
         with torch.no_grad():
             action = mean + torch.sqrt(self.var) * torch.randn(mean.shape)

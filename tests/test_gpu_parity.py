@@ -656,7 +656,7 @@ def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
             head = n.startswith(f"network.{2 * len(hidden)}.")
             assert rel <= (5e-6 if head else 3e-3), (n, rel)
     pad = m.forward(m.prepare_input(X), keep=False, padded=True)
-    assert pad.shape[1] % 8 == 0 and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
+    assert pad.shape[1] % 4 == 0 and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
     assert not tg.mlp.supports(tg.NeuralNetwork(S, A, hidden, "Tanh"))
 
 
@@ -755,7 +755,8 @@ def test_forward_chain_kernel_matches_layer_by_layer(tg, dev, dims, rows):
     ref = h @ mlp.linears[-1].weight.to(torch.bfloat16).double().t() + mlp.linears[-1].bias.double()
     np.testing.assert_allclose(out_c[:, :A].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert torch.all(out_c[:, A:] == 0)
-    assert float((out_c - out_l).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
+    assert out_c.shape[1] == (4 if A <= 4 else mlp.out_pad)             # <= 4 outputs: a 16-B row (tg_rollout_step's mean read)
+    assert float((out_c[:, :A] - out_l[:, :A]).abs().max()) <= 2e-2 * float(out_l.abs().max()) + 1e-3
     if bchain is not None:
         # with the backward chain active the first activation is left out (tg_mlp_weight_grad recomputes it); everything
         # else -- later activations, ALL mask bits, the output -- is bit-identical

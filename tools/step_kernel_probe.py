@@ -31,13 +31,13 @@ def main():
     eng = tg.DeviceRollout(env, pol, n // 256, 256, seed=1)
     eng._seed_host, eng._stream_host = 1, 0
     lib, tr, st, p = N_.load(), eng.traj.native(), N_.stream_ptr(dev), C.byref(eng.params)
-    mean = torch.zeros(n, 8, device=dev)
+    mean = torch.zeros(n, 4, device=dev)                 # 16-B mean rows (tg_mlp_forward_chain's output for <= 4 outputs)
     eng._enqueue_prepare(None)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for t in range(T - 1):
-        N_.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), 8, eng._sigma, eng.rng.data_ptr(), 0, st))
+        N_.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), 4, eng._sigma, eng.rng.data_ptr(), 0, st))
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / (T - 1)

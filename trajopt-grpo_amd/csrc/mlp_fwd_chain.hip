@@ -178,7 +178,7 @@ __device__ static inline int wave_of(unsigned tid) { return (int)(tid >> 6); }
 #define TG_CHAIN_ADVANCE(WAITN) TG_RING_ADVANCE(WAITN)
 
 // x [rows][32] bf16 (features >= in_dim zero); acts.p[l] [rows][H] bf16 for hidden layer l (kStore); out f32
-// [rows][out_cols], out_cols in {8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
+// [rows][out_cols], out_cols in {4, 8, 16}; bias f32 [(n_hh + 2)][H] (layer-major, natural feature order, head padded).
 // A wave owns 32 rows as two 16-row MFMA column tiles (c = 0, 1): lane (col = lane & 15, g = lane >> 4) holds, per row
 // 16 c + col and 32-feature block, the 8 consecutive features 8 g .. 8 g + 7 -- as accumulators (4 of half f = 0, 4 of f = 1:
 // mlp.FragmentStream arranges the weight rows so), then packed: 16 B that are both the next layer's B operand for k-step =
@@ -570,7 +570,7 @@ int tg_mlp_forward_chain(const void* d_x, const void* d_wfrag, const float* d_bi
     TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_forward_chain: hidden width %d unsupported (128, 256)", hidden);
     TG_REQUIRE(n_hidden_layers >= 1 && n_hidden_layers <= kChainMaxHidden, "tg_mlp_forward_chain: %d hidden layers outside 1..%d",
                n_hidden_layers, kChainMaxHidden);
-    TG_REQUIRE(out_cols == 8 || out_cols == 16, "tg_mlp_forward_chain: out_cols %d must be 8 or 16", out_cols);
+    TG_REQUIRE(out_cols == 4 || out_cols == 8 || out_cols == 16, "tg_mlp_forward_chain: out_cols %d must be 4, 8 or 16", out_cols);
     TG_REQUIRE(rows >= 0, "tg_mlp_forward_chain: negative row count");
     if (rows == 0) return TG_OK;
     ChainActs acts{};

@@ -218,8 +218,8 @@ class GemmMLP:
 
     @torch.no_grad()
     def forward(self, xp: torch.Tensor, keep: bool = True, padded: bool = False) -> torch.Tensor:
-        """-> fp32 [rows][out_dim] (contiguous), or the [rows][out_pad] buffer itself with padded=True
-        (row stride out_pad; columns >= out_dim are zero).  keep=True stores the activations for backward().
+        """-> fp32 [rows][out_dim] (contiguous), or the padded output buffer itself with padded=True
+        (row stride >= out_dim -- read it from .stride(0); columns >= out_dim are zero).  keep=True stores the activations for backward().
         `xp`: [rows][in_pad] compute dtype, zero padded -- normally from prepare_input(), whose ones column (31) lets the
         backward chain form the first layer's bias gradient; a caller-padded input works too (kind HX job instead)."""
         L = len(self.linears)
@@ -233,7 +233,9 @@ class GemmMLP:
                    for i in range(L - 1)] if keep else []
             # 1 bit per stored activation (its ReLU mask): all the backward-data kernels need of it
             bits = [self._ws.get(f"m{i}", rows, H // 32, torch.int32, xp.device) for i in range(L - 1)] if keep else []
-            out = torch.empty(rows, self.out_pad, dtype=torch.float32, device=xp.device)
+            # (<= 4 outputs: a 16-B output row -- tg_rollout_step then reads the policy mean without padding)
+            oc = 4 if self.out_dim <= 4 else self.out_pad
+            out = torch.empty(rows, oc, dtype=torch.float32, device=xp.device)
             ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid]) if keep else None
             mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
             ev = None
@@ -241,12 +243,12 @@ class GemmMLP:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
-                                                  L - 1, rows, ptrs, mptrs, out.data_ptr(), self.out_pad,
+                                                  L - 1, rows, ptrs, mptrs, out.data_ptr(), oc,
                                                   N.stream_ptr(xp.device)), "tg_mlp_forward_chain")
             if ev is not None:
                 ev[1].record()
                 stored = sum(1 for t in hid if t is not None)
-                self.fwd_events.append((ev[0], ev[1], rows, 2 * self.in_pad + stored * 2 * H + (L - 1) * (H // 8) + 4 * self.out_pad,
+                self.fwd_events.append((ev[0], ev[1], rows, 2 * self.in_pad + stored * 2 * H + (L - 1) * (H // 8) + 4 * oc,
                                         f"tg::mlp_fwd_chain_kernel<{H},8,true,4,{'true' if stored == L - 1 else 'false'}>"))
             self._acts = [xp] + hid if keep else None
             self._bits = [None] + bits if keep else None
