@@ -258,6 +258,10 @@ def main():
                     help="do not bracket the rollout / learner launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing the multi-rank path on a single GPU (ranks share the device)")
+    ap.add_argument("--check", action="store_true",
+                    help="with --gpus N > 1: before the timed run every rank runs the small rank-count cases of tests/dist_product_worker.py "
+                         "twice -- as a rank of the N-rank group and alone (a one-rank subgroup) -- and asserts that its trajectory "
+                         "shard, PPO's global moments and the post-step weights agree (SURVEY 8e); the result rides in the JSON line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -327,6 +331,30 @@ def main():
         else:
             dist.init_process_group("gloo")
     n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+
+    rank_check = None
+    if args.check:
+        if world not in (2, 4):
+            raise SystemExit("--check compares an N-rank run with a one-rank run of 4-group cases: needs --gpus 2 or 4")
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import dist_product_worker as W
+        solo = None
+        for r in range(world):                                  # every rank takes part in every new_group call
+            g = dist.new_group([r])
+            if r == rank:
+                solo = g
+        names = [n for n in W.CASES if not n.endswith("ragged") or world == 2]
+        with torch.cuda.device(dev):
+            # (the worker runs on cuda:0 of the process; under nccl every rank has its own device, so make it current)
+            many = W.run_cases(names, rank, world, None, device=dev)
+            one = W.run_cases(names, 0, 1, solo, device=dev, emulate_world=world)
+        rank_check = {n: W.check_case(one[n], [many[n]], n) for n in names}
+        flag = torch.ones(1, device=dev)
+        dist.all_reduce(flag)                                   # every rank got here: nobody raised
+        assert int(flag.item()) == world
+        progress_early = f"rank-count check passed on {world} ranks: {rank_check}"
+        if rank == 0:
+            print(f"[bench] {progress_early}", file=sys.stderr, flush=True)
 
     G_global = G_local * world
     T = args.horizon
@@ -490,6 +518,7 @@ def main():
             "dtype": "bf16 (f32 accumulate) MLP; f32 env / returns / loss / optimizer" if args.policy_dtype == "bf16" else "f32",
             "policy_dtype": args.policy_dtype, "data": "synthetic",
             "n_ranks_seen": n_ranks_seen,
+            "rank_count_check": rank_check,
             "config": {"workload": workload, "name": args.config, "envs_per_gpu": envs_local, "agents_per_env": agents,
                        "envs_total": envs_local * world, "horizon": T, "updates_per_iter": updates,
                        "parallelism": f"env-shard x{world} (whole groups per rank), 1 grad all-reduce per optimizer step"},

@@ -52,9 +52,10 @@ def union_permutation(m_global, T, n_envs, emulate_world, batch_size, device):
     return torch.cat(out).to(device)
 
 
-def run_cases(names, rank, world, group=None):
+def run_cases(names, rank, world, group=None, device=None, emulate_world=2):
+    """group=None: the default process group (or no group at all); a one-rank subgroup runs the cases alone inside a larger job."""
     import trajopt_grpo_amd as tg
-    dev = torch.device("cuda", 0)
+    dev = device if device is not None else torch.device("cuda", 0)
     out = {}
     for name in names:
         algo_name, env_name, env_kw, S, A, hidden, cdt, G, E, restart, updates, bs = CASES[name]
@@ -83,7 +84,7 @@ def run_cases(names, rank, world, group=None):
                           autocast_dtype=cdt, process_group=group)
             if bs is not None:
                 if world == 1 and name.endswith("_equal"):        # one rank walking the union of a two-rank run's minibatches
-                    algo.permutation_fn = lambda m, d, T=env_kw["max_steps"], n=G * E, b=bs: union_permutation(m, T, n, 2, b, d)
+                    algo.permutation_fn = lambda m, d, T=env_kw["max_steps"], n=G * E, b=bs: union_permutation(m, T, n, emulate_world, b, d)
                 else:
                     algo.permutation_fn = lambda m, d, r=rank, w=world: local_permutation(m, r, w, d)
         else:
@@ -105,6 +106,67 @@ def run_cases(names, rank, world, group=None):
                                 ("gemm" if m is not None else "autograd")))
         out[name] = rec
     return out
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-30)
+
+
+def check_case(one, two, case):
+    """Assert that the two ranks' records `two` equal the one-rank record `one` (see test_distributed_gpu.py); returns the
+    largest relative weight / update differences found.  `two` may hold only this rank's record (bench.py --check)."""
+    assert all(rec["learner_path"] == one["learner_path"] for rec in two)
+    if "bf16" in case:
+        assert one["learner_path"] == "chain"                       # the hot kernels are what is being compared
+    # ---- rollout: each rank's shard is bit-for-bit the one-rank trajectory of its groups (Philox keyed by global indices) ----
+    n_total = one["len"].numel()
+    for rec in two:
+        lo, hi = rec["groups"]
+        per_group = n_total // one["groups"][1]
+        sl = slice(lo * per_group, hi * per_group)
+        assert torch.equal(rec["len"], one["len"][sl]) and torch.equal(rec["mask"], one["mask"][:, sl])
+        assert torch.equal(rec["obs"], one["obs"][:, :, sl]) and torch.equal(rec["act"], one["act"][:, :, sl])
+        assert torch.equal(rec["rew"], one["rew"][:, sl])
+        assert abs(rec["avg_reward"] - one["avg_reward"]) <= 1e-6 * abs(one["avg_reward"])
+    if len(two) > 1:
+        assert sum(rec["n_valid_local"] for rec in two) == one["n_valid_local"]
+        if case.endswith("ragged"):
+            assert two[0]["n_valid_local"] != two[1]["n_valid_local"], "the case is meant to have unequal row counts"
+        # ---- all ranks hold bit-identical weights after learn(), and took the same number of optimizer steps ----
+        for rec in two[1:]:
+            assert rec["optimizer_steps"] == two[0]["optimizer_steps"] and rec["avg_reward"] == two[0]["avg_reward"]
+            for a, b in zip(two[0]["weights"], rec["weights"]):
+                assert torch.equal(a, b)
+    assert two[0]["optimizer_steps"] > 0 and all(torch.isfinite(a).all() for a in two[0]["weights"])
+    if "moments" in one:                                            # PPO: global advantage / return moments (ppo.py:138-139)
+        for rec in two:
+            for x, y in zip(rec["moments"], one["moments"]):
+                assert abs(x - y) <= 1e-6 * (abs(y) + 1e-6), (rec["moments"], one["moments"])
+    if case.endswith("ragged"):
+        # unequal row counts: a one-rank run walks different minibatches (the permutation is rank-local, DESIGN 6); what must
+        # hold is the schedule -- ceil(max rows / ceil(64 / world)) steps on every rank
+        if len(two) > 1:
+            local_bs = -(-64 // len(two))
+            assert two[0]["optimizer_steps"] == max(-(-rec["n_valid_local"] // local_bs) for rec in two)
+        return {"weights": None, "update": None}
+    # ---- ... and they equal the one-rank weights up to the all-reduce's summation order ----
+    assert two[0]["optimizer_steps"] == one["optimizer_steps"]
+    # 1e-6 relative (L2) on every weight tensor; on the UPDATE itself (weights after - before) 1e-4 for the fp32 learner and 1e-3
+    # for the bf16 chain kernels, whose second update re-rounds fp32 masters that may differ in the last bit
+    # (measured: weights 4e-9..7e-8, updates 6e-7..3e-6)
+    w_tol, d_tol = (1e-6, 1e-3) if "bf16" in case else (1e-6, 1e-4)
+    worst_w = worst_d = 0.0
+    for a, b, da, db in zip(two[0]["weights"], one["weights"], two[0]["delta"], one["delta"]):
+        worst_w = max(worst_w, _rel(a, b))
+        assert _rel(a, b) <= w_tol, (_rel(a, b), a.shape)
+        if float(db.norm()) > 0:
+            worst_d = max(worst_d, _rel(da, db))
+            assert _rel(da, db) <= d_tol, (_rel(da, db), a.shape)
+    for k in ("J", "total_loss", "actor_loss", "critic_loss"):
+        if k in one["stats"]:
+            for x, y in zip(two[0]["stats"][k], one["stats"][k]):
+                assert abs(x - y) <= 2e-3 * (abs(y) + 1e-3), (k, x, y)
+    return {"weights": worst_w, "update": worst_d}
 
 
 def main():

@@ -44,56 +44,11 @@ def runs(tmp_path_factory):
     return {w: [torch.load(f, weights_only=False) for f in files] for w, files in outs.items()}
 
 
-def _rel(a, b):
-    return float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-30)
-
-
 @pytest.mark.parametrize("case", ["ppo_bf16_full", "ppo_f32_minibatch_equal", "ppo_f32_minibatch_ragged", "grpo_bf16", "grpo_f32"])
 def test_two_ranks_equal_one_rank_on_the_product_path(runs, case):
-    one, two = runs[1][0][case], [r[case] for r in runs[2]]
-    assert one["learner_path"] == two[0]["learner_path"] == two[1]["learner_path"]
-    if "bf16" in case:
-        assert one["learner_path"] == "chain"                       # the hot kernels are what is being compared
-    # ---- rollout: each rank's shard is bit-for-bit the one-rank trajectory of its groups (Philox keyed by global indices) ----
-    n_total = one["len"].numel()
-    for r, rec in enumerate(two):
-        lo, hi = rec["groups"]
-        per_group = n_total // one["groups"][1]
-        sl = slice(lo * per_group, hi * per_group)
-        assert torch.equal(rec["len"], one["len"][sl]) and torch.equal(rec["mask"], one["mask"][:, sl])
-        assert torch.equal(rec["obs"], one["obs"][:, :, sl]) and torch.equal(rec["act"], one["act"][:, :, sl])
-        assert torch.equal(rec["rew"], one["rew"][:, sl])
-    assert two[0]["n_valid_local"] + two[1]["n_valid_local"] == one["n_valid_local"]
-    assert two[0]["avg_reward"] == two[1]["avg_reward"] and abs(two[0]["avg_reward"] - one["avg_reward"]) <= 1e-6 * abs(one["avg_reward"])
-    if case.endswith("ragged"):
-        assert two[0]["n_valid_local"] != two[1]["n_valid_local"], "the case is meant to have unequal row counts"
-    # ---- both ranks hold bit-identical weights after learn(), and took the same number of optimizer steps ----
-    assert two[0]["optimizer_steps"] == two[1]["optimizer_steps"] > 0
-    for a, b in zip(two[0]["weights"], two[1]["weights"]):
-        assert torch.equal(a, b)
-    for a in two[0]["weights"]:
-        assert torch.isfinite(a).all()
-    if "moments" in one:                                            # PPO: global advantage / return moments (ppo.py:138-139)
-        for rec in two:
-            for x, y in zip(rec["moments"], one["moments"]):
-                assert abs(x - y) <= 1e-6 * (abs(y) + 1e-6), (rec["moments"], one["moments"])
-    if case.endswith("ragged"):
-        # unequal row counts: a one-rank run walks different minibatches (the permutation is rank-local); what must
-        # hold is the schedule -- ceil(max rows / ceil(64 / 2)) steps on both ranks
-        local_bs = 32
-        want = max(-(-rec["n_valid_local"] // local_bs) for rec in two)
-        assert two[0]["optimizer_steps"] == want
-        return
-    # ---- ... and they equal the one-rank weights up to the all-reduce's summation order ----
-    assert two[0]["optimizer_steps"] == one["optimizer_steps"]
-    # fp32 learner: 1e-6 relative on the weights; bf16 chain kernels: the weights of the second update are re-rounded to bf16 from
-    # fp32 masters that differ in the last bit, so the bound is on the UPDATE: 2 % of its norm (1e-5 on the weights)
-    w_tol, d_tol = (1e-5, 2e-2) if "bf16" in case else (1e-6, 1e-3)
-    for a, b, da, db in zip(two[0]["weights"], one["weights"], two[0]["delta"], one["delta"]):
-        assert _rel(a, b) <= w_tol, (_rel(a, b), a.shape)
-        if float(db.norm()) > 0:
-            assert _rel(da, db) <= d_tol, (_rel(da, db), a.shape)
-    for k in ("J", "total_loss", "actor_loss", "critic_loss"):
-        if k in one["stats"]:
-            for x, y in zip(two[0]["stats"][k], one["stats"][k]):
-                assert abs(x - y) <= 2e-3 * (abs(y) + 1e-3), (k, x, y)
+    """Trajectory shards bit-for-bit, PPO's global moments, optimizer-step counts, both ranks bit-identical to each other, post-step
+    weights within 1e-6 (fp32) / the stated bf16 bound of the one-rank run: dist_product_worker.check_case."""
+    sys.path.insert(0, HERE)
+    from dist_product_worker import check_case
+    worst = check_case(runs[1][0][case], [r[case] for r in runs[2]], case)
+    print(case, worst)
