@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 6
+#define TG_ABI_VERSION 7
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -397,6 +397,43 @@ typedef struct tg_dw_job {
 int64_t tg_mlp_weight_grad_workspace(int32_t hidden);
 int  tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag,
                         const float* d_b0, const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- The update in the reference's own precision (fp32) at the reference's own net sizes ----
+ * Linear(S <= 32, H) ReLU [Linear(H, H) ReLU]{0..3} Linear(H, A <= 4), H in {64, 128}: pipelines/cartpole_pipeline_grpo.py:54-76,
+ * cartpole_pipeline_ppo.py:54-79 (models/neural_network.py:67-77); every product is v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
+ *   d_x       f32 [rows][in_pad], in_pad in {8, 16, 24, 32}, columns >= S zero
+ *   d_stream  f32, tg_mlp_f32_stream_floats(H, n_hidden_layers, in_pad) floats (trajopt-grpo_amd/mlp.py `F32ChainStream` documents
+ *             and builds it): [first layer in MFMA fragment order: H x in_pad][hidden biases: n x H][head weights: 4 x H, rows >= A
+ *             zero][head bias: 4][forward blocks of the H x H layers][backward (transposed) blocks, top layer first]
+ * tg_mlp_f32_forward: the no-grad pass (models/neural_network.py:67-77): d_out f32 [rows][4] (columns >= A: zeros + bias 0).
+ * tg_mlp_f32_forward_backward: forward pass + loss head + backward-DATA pass of every row in ONE launch (algorithms/ppo.py:159-183,
+ *   grpo.py:122-145 up to the weight gradients): `loss` as for tg_mlp_forward_chain_loss, except that d_dout8 receives d loss /
+ *   d head output as F32 [rows][4], d_head_slabs / d_bias_partial are not used (the head's gradient is a job of
+ *   tg_mlp_f32_weight_grad) and d_work is f64 [tg_mlp_f32_blocks()][4]; the caller adds the first min(blocks, ceil(rows / 256)).
+ *   d_acts / d_dz: HOST arrays of n_hidden_layers device pointers, f32 [rows][H] each: the post-ReLU outputs of the hidden layers
+ *   and d loss / d their pre-activations (index = layer, 0 = first hidden layer), written for tg_mlp_f32_weight_grad.
+ * tg_mlp_f32_weight_grad: every job's wgrad += P^T Q (and bgrad += column sums of P) in one launch + one fixed-order reduction
+ *   (deterministic, no float atomics).  kind MM: P f32 [rows][H] (a layer's dZ), Q f32 [rows][n_cols] (its input: n_cols = H, or
+ *   the padded net input, n_cols = in_pad), window m_out = H x n_out <= n_cols; kind HEAD: P = d loss / d head output f32
+ *   [rows][4], Q = the top activation f32 [rows][H], window m_out = A x n_out = H, bgrad [A]. */
+int64_t tg_mlp_f32_stream_floats(int32_t hidden, int32_t n_hidden_layers, int32_t in_pad);
+int  tg_mlp_f32_blocks(void);
+int  tg_mlp_f32_forward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
+                        int64_t rows, float* d_out, void* stream);
+int  tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
+                                 int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream);
+enum { TG_F32DW_MM = 0, TG_F32DW_HEAD = 1 };
+typedef struct tg_f32_dw_job {
+    const float* d_p;
+    const float* d_q;
+    float*       d_wgrad;     /* f32, row stride wgrad_ld */
+    float*       d_bgrad;     /* f32 [m_out] or NULL */
+    int64_t      wgrad_ld;
+    int32_t      kind, n_cols, m_out, n_out;
+} tg_f32_dw_job;
+int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
+int  tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
+                            int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

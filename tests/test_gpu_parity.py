@@ -5,6 +5,8 @@ real reference.  Tolerances: bit-exact for indices / lengths / masks / flags; fp
 fp32 returns within 1e-5 (the north-star bar)."""
 import ctypes as C
 
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -1647,6 +1649,125 @@ def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind,
     for (n, _), a, b in zip(net.named_parameters(), ref, got):
         scale = float(a.abs().max()) + 1e-9
         assert float((a - b).abs().max()) <= 2e-5 * scale * max(1.0, (rows / 1000) ** 0.5), n
+
+
+# --------------------------------------------------------------------------------------------
+# the fp32 chain learner (csrc/mlp_f32_chain.hip): the reference's own precision and net sizes
+# --------------------------------------------------------------------------------------------
+F32_SHAPES = [(5, 1, (128, 128)), (20, 4, (128,) * 4), (10, 2, (64,)), (5, 1, (64, 64, 64)), (32, 4, (128, 128, 128)), (3, 1, (128,))]
+
+
+@pytest.mark.parametrize("dims", F32_SHAPES)
+@pytest.mark.parametrize("rows", [1, 257, 70001, 300000])
+def test_f32_chain_forward_matches_fp64(tg, dev, dims, rows):
+    """tg_mlp_f32_forward (models/neural_network.py:67-77 in one launch, fp32 products on the matrix cores) against the same net
+    in fp64: relative 1e-5 of the output scale.  rows > 65,536: several rounds per workgroup."""
+    from trajopt_grpo_amd import mlp as M
+    S, A, hidden = dims
+    torch.manual_seed(rows + S)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    m = M.GemmMLP(net, torch.float32)
+    assert m._f32 is not None and m.in_pad == (S + 7) // 8 * 8
+    X = torch.randn(rows, S, device=dev)
+    xp = m.prepare_input(X)
+    assert xp.shape == (rows, m.in_pad) and xp.dtype == torch.float32
+    out = m.forward(xp, keep=False)
+    pad = m.forward(xp, keep=False, padded=True)
+    torch.cuda.synchronize()
+    ref = copy.deepcopy(net).double()(X.double())
+    scale = float(ref.abs().max()) + 1e-6
+    assert out.shape == (rows, A) and float((out.double() - ref).abs().max()) <= 1e-5 * scale
+    assert pad.shape == (rows, 4) and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
+
+
+@pytest.mark.parametrize("dims", F32_SHAPES)
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("rows", [1, 255, 4000, 70001])
+def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
+    """forward_loss() + backward_fused() of an fp32 net -- tg_mlp_f32_forward_backward (forward, clipped-surrogate / squared-error
+    head as loss_kernels.hip, backward data) and tg_mlp_f32_weight_grad -- against torch autograd of the same loss in fp64
+    (algorithms/ppo.py:159-183, grpo.py:122-145): loss sums to 1e-6, every stored activation / dZ to 1e-5 of its scale, every
+    parameter gradient to 2e-5 (x sqrt(rows / 1000)) of its scale; gradients ACCUMULATE into .grad; bit-identical run to run."""
+    from trajopt_grpo_amd import mlp as M
+    S, A, hidden = dims
+    if kind == 1:
+        A = 1
+    torch.manual_seed(rows + S + kind)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    X = torch.randn(rows, S, device=dev)
+    act = torch.randn(rows, A, device=dev)
+    lpo = (-0.5 * torch.rand(rows, device=dev) - 1.0).contiguous()
+    adv, ret = torch.randn(rows, device=dev), torch.randn(rows, device=dev)
+    norm = [0.1, 1.3, -0.2, 0.7]
+    var = torch.full((A,), 0.3)
+    eps, sc, cc, kc = 0.2, -1.0 / rows, 0.5 / rows, 0.5 / rows
+
+    def run():
+        m = M.GemmMLP(net, torch.float32)
+        for i, p in enumerate(net.parameters()):
+            p.grad = torch.full_like(p, 0.25 * (i + 1))                 # the kernels must ADD to what is there
+        assert m.can_fuse_head()
+        xp = m.prepare_input(X)
+        if kind == 0:
+            s = m.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=norm[0:2], var=var, epsilon=eps, surr_coef=sc, kl_coef=kc)
+        else:
+            s = m.forward_loss(xp, 1, ret=ret, norm=norm[2:4], critic_coef=cc)
+        stored = [t.clone() for t in m._acts[1:]], [t.clone() for t in m._bits], m._dz_head.clone()
+        m.backward_fused()
+        torch.cuda.synchronize()
+        return s.clone(), [p.grad.clone() for p in net.parameters()], stored
+
+    s, got, (acts, dzs, dout) = run()
+    s2, got2, _ = run()
+    assert torch.equal(s, s2) and all(torch.equal(a, b) for a, b in zip(got, got2))
+    # ---- the same update in fp64.  The ReLU masks are the KERNEL's (a pre-activation within fp32 rounding of zero may fall on
+    # the other side of the ReLU in fp64; one such flip moves a weight gradient by a whole row's contribution): they are checked
+    # against the fp64 pre-activations separately, everything else is then compared tightly ----
+    lin = [mod for mod in copy.deepcopy(net).double().network if isinstance(mod, torch.nn.Linear)]
+    W = [l.weight.detach() for l in lin]
+    B = [l.bias.detach() for l in lin]
+    masks = [(a > 0) for a in acts]
+    hs, h = [], X.double()
+    for l in range(len(hidden)):
+        z = h @ W[l].t() + B[l]
+        flips = (z > 0) != masks[l]
+        assert float(flips.float().mean()) <= 1e-4 and (not bool(flips.any()) or float(z[flips].abs().max()) <= 1e-5 * (1.0 + float(z.abs().max()))), l
+        h = z * masks[l]
+        hs.append(h)
+    out = (h @ W[-1].t() + B[-1]).requires_grad_()
+    if kind == 0:
+        logp = -0.5 * (((act.double() - out) ** 2) / var.double().to(dev)).sum(1) - 0.5 * A * np.log(2 * np.pi) - 0.5 * float(torch.log(var.double()).sum())
+        rho = torch.exp(logp - lpo.double())
+        an = (adv.double() - norm[0]) * norm[1]
+        surr = torch.minimum(rho * an, torch.clamp(rho, 1 - eps, 1 + eps) * an)
+        kl = torch.exp(lpo.double()) * (lpo.double() - logp)
+        total = sc * surr.sum() + kc * kl.sum()
+        want = {0: float(surr.sum()), 2: float(kl.sum()), 3: float(rows)}
+    else:
+        d = out[:, 0] - (ret.double() - norm[2]) * norm[3]
+        total = cc * (d * d).sum()
+        want = {1: float((d * d).sum()), 3: float(rows)}
+    total.backward()
+    g = out.grad
+    for k, v in want.items():
+        assert abs(float(s[k]) - v) <= 2e-6 * (abs(v) + 1.0), (k, float(s[k]), v)
+    for i, (a, hh) in enumerate(zip(acts, hs)):
+        assert float((a.double() - hh).abs().max()) <= 1e-5 * (float(hh.abs().max()) + 1e-6), i
+    assert float((dout[:, :A].double() - g).abs().max()) <= 2e-5 * (float(g.abs().max()) + 1e-30) and torch.all(dout[:, A:] == 0)
+    nh = len(hidden)
+    ref_w, ref_b = [None] * (nh + 1), [None] * (nh + 1)
+    ref_w[nh], ref_b[nh] = g.t() @ hs[-1], g.sum(0)
+    dh = g @ W[nh]
+    for l in range(nh - 1, -1, -1):
+        dz = dh * masks[l]
+        assert float((dzs[l].double() - dz).abs().max()) <= 2e-5 * (float(dz.abs().max()) + 1e-30), l
+        ref_w[l], ref_b[l] = dz.t() @ (hs[l - 1] if l > 0 else X.double()), dz.sum(0)
+        dh = dz @ W[l]
+    ref = [t for pair in zip(ref_w, ref_b) for t in pair]                # parameters(): weight, bias per layer
+    for i, (gg, r) in enumerate(zip(got, ref)):
+        base = 0.25 * (i + 1)
+        scale = float(r.abs().max()) + 1e-12
+        assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (i, rows)
 
 
 # --------------------------------------------------------------------------------------------

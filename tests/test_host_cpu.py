@@ -32,3 +32,76 @@ def test_retrieve_returns_the_five_stored_tensors():
     t = tuple(torch.from_numpy(g[f"reset_{k}"]) for k in ("obs", "act", "rew", "len", "mask"))
     buf.store(*t)
     assert all(a is b for a, b in zip(buf.retrieve(), t)) and buf.group_observations is t[0]
+
+
+def _emulate_f32_chain(fs, x):
+    """What tg_mlp_f32_forward computes from mlp.F32ChainStream's stream, restated on the host from the kernel's documented
+    operand layout (v_mfma_f32_32x32x2_f32: A lane (i, kk) = A[i][kk], B lane (j, kk) = B[kk][j]; accumulator register r of lane
+    half h of tile mt is feature 32 mt + F(r, h)): fp64, one row."""
+    H, nh, K2, MT = fs.H, fs.n_hidden, fs.in_pad // 2, fs.H // 32
+    st = fs.stream.double().numpy()
+    o = 0
+    w0 = st[o:o + H * fs.in_pad].reshape(MT, K2 // 4, 64, 4); o += H * fs.in_pad
+    bias = st[o:o + nh * H].reshape(nh, H); o += nh * H
+    wh = st[o:o + 4 * H].reshape(4, H); o += 4 * H
+    bh = st[o:o + 4]; o += 4
+    n_hh = nh - 1
+    blocks = st[o:].reshape(2 * n_hh, MT, H // 8, 64, 4)
+    F = lambda t, kk: (t & 3) + 8 * (t >> 2) + 4 * kk
+    xp = np.zeros(fs.in_pad)
+    xp[:fs.in_dim] = x
+    a = np.zeros(H)
+    for mo in range(MT):
+        for i in range(32):
+            a[32 * mo + i] = bias[0, 32 * mo + i] + sum(w0[mo, s // 4, i + 32 * kk, s % 4] * xp[kk * K2 + s] for s in range(K2) for kk in range(2))
+    a = np.maximum(a, 0)
+    acts = [a]
+    for l in range(1, nh):
+        nxt = np.zeros(H)
+        for mo in range(MT):
+            blk = blocks[(l - 1), mo]
+            for i in range(32):
+                nxt[32 * mo + i] = bias[l, 32 * mo + i] + sum(blk[s // 4, i + 32 * kk, s % 4] * a[32 * (s // 16) + F(s % 16, kk)]
+                                                                for s in range(H // 2) for kk in range(2))
+        a = np.maximum(nxt, 0)
+        acts.append(a)
+    out = wh @ a + bh
+    # backward-data blocks: dA_{l-1} = W_l^T dZ_l, top layer first
+    dz = np.arange(H, dtype=np.float64) / H - 0.3
+    back = []
+    for k, l in enumerate(range(nh - 1, 0, -1)):
+        nxt = np.zeros(H)
+        for ko in range(MT):
+            blk = blocks[n_hh + k, ko]
+            for i in range(32):
+                nxt[32 * ko + i] = sum(blk[s // 4, i + 32 * kk, s % 4] * dz[32 * (s // 16) + F(s % 16, kk)] for s in range(H // 2) for kk in range(2))
+        back.append((l, dz.copy(), nxt))
+        dz = nxt
+    return out, acts, back
+
+
+def test_f32_chain_weight_stream_layout():
+    """mlp.F32ChainStream (the operand order tg_mlp_f32_forward / _forward_backward consume) against torch on the CPU: forward
+    blocks, the first layer's padded k pairs, the natural-order tables and the transposed (backward) blocks."""
+    from trajopt_grpo_amd import mlp as M
+    for S, A, hidden in [(5, 1, (64, 64)), (20, 4, (128, 128, 128)), (9, 2, (64,))]:
+        torch.manual_seed(S)
+        net = tg.NeuralNetwork(S, A, hidden, "ReLU")
+        H = M.f32_chain_supported(net)
+        assert H == hidden[0]
+        fs = M.F32ChainStream(net, H)
+        x = torch.randn(S)
+        out, acts, back = _emulate_f32_chain(fs, x.numpy().astype(np.float64))
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        h = x.double()
+        for l, a in zip(lin[:-1], acts):
+            h = torch.relu(l.weight.double() @ h + l.bias.double())
+            np.testing.assert_allclose(a, h.detach().numpy(), rtol=1e-12, atol=1e-12)
+        ref = (lin[-1].weight.double() @ h + lin[-1].bias.double()).detach().numpy()
+        np.testing.assert_allclose(out[:A], ref, rtol=1e-12, atol=1e-12)
+        assert np.all(out[A:] == 0)
+        for l, dz, got in back:
+            np.testing.assert_allclose(got, (lin[l].weight.double().t() @ torch.from_numpy(dz)).detach().numpy(), rtol=1e-12, atol=1e-12)
+    assert M.f32_chain_supported(tg.NeuralNetwork(5, 1, (32, 32), "ReLU")) == 0
+    assert M.f32_chain_supported(tg.NeuralNetwork(5, 8, (64, 64), "ReLU")) == 0
+    assert M.f32_chain_supported(tg.NeuralNetwork(5, 1, (128,) * 5, "ReLU")) == 0

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TG_NATIVE_LIB: another build of the same library (probe builds with different compile-time flags, tools/mall_probe.py)
 LIB_PATH = os.environ.get("TG_NATIVE_LIB") or os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 6                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 7                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -55,6 +55,15 @@ class DwJob(C.Structure):
 
 
 TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR, TG_DW_RH = 0, 1, 2, 3, 4
+
+
+class F32DwJob(C.Structure):
+    """tg_f32_dw_job (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("d_p", C.c_void_p), ("d_q", C.c_void_p), ("d_wgrad", C.c_void_p), ("d_bgrad", C.c_void_p),
+                ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("n_cols", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32)]
+
+
+TG_F32DW_MM, TG_F32DW_HEAD = 0, 1
 
 
 class ChainLoss(C.Structure):
@@ -112,6 +121,13 @@ SIGNATURES = {
     "tg_mlp_forward_chain_blocks": (C.c_int, []),
     "tg_mlp_forward_chain_loss": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(ChainLoss), _VP]),
+    "tg_mlp_f32_stream_floats": (C.c_int64, [_I32, _I32, _I32]),
+    "tg_mlp_f32_blocks": (C.c_int, []),
+    "tg_mlp_f32_forward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, _VP, _VP]),
+    "tg_mlp_f32_forward_backward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(ChainLoss), _VP]),
+    "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),
+    "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP]),
 }
 
 _lib = None

@@ -1,0 +1,748 @@
+// The learner's update in the REFERENCE'S OWN PRECISION (fp32) at the reference's own net sizes -- Linear(S<=32, H) ReLU
+// [Linear(H, H) ReLU]{0..3} Linear(H, A<=4), H in {64, 128}: what pipelines/cartpole_pipeline_grpo.py:54-76,
+// cartpole_pipeline_ppo.py:54-79 and BASELINE configs[1] build (models/neural_network.py:67-77) -- as TWO launches per net and
+// update instead of ~60 (per-layer hipBLASLt GEMMs + glue kernels; 94 % of C2's step in round 2):
+//
+//   tg_mlp_f32_forward_backward   forward pass, loss head (algorithms/ppo.py:159-179, grpo.py:122-140: the arithmetic of
+//                                 loss_kernels.hip) and backward-DATA pass of a row in one go: a wave owns 32 rows from the
+//                                 input to d loss / d first-layer pre-activation; activations and dZ are only WRITTEN (for the
+//                                 weight gradients), the ReLU masks never leave the chip;
+//   tg_mlp_f32_weight_grad        every weight and bias gradient of the net (what `loss.backward()` leaves in .grad,
+//                                 algorithms/ppo.py:181-183) in one launch + a fixed-order slab reduction.
+//   tg_mlp_f32_forward            the no-grad pass (old log-probs, values, per-step rollout): forward only.
+//
+// All products are v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 155 TFLOP/s chip-wide = 1/16 of the bf16 rate): these
+// kernels are bound by the fp32 matrix pipe, not by HBM.  Transposed form Y^T = W . X^T as in the bf16 chain kernels: the 32
+// columns of a tile are 32 rows of the batch, so a row never leaves its wave, and lane (row j, half h) of an accumulator tile
+// holds features F(r, h) = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15 -- register r of the two halves IS the B operand of MFMA step
+// (tile, r) of the next layer (k pair F(r, 0), F(r, 1)); the k order this implies is folded into the weight stream
+// (mlp.F32ChainStream).  The backward pass is the same machine on W^T with a mask multiply instead of bias + ReLU.
+// Weights: the first layer, biases and head stay in LDS; the H x H layers stream L2 -> registers -> LDS in 32-feature blocks
+// (H/2 MFMA steps x 64 lanes x 4 B = 16 KiB at H = 128) through two buffers, one plain workgroup barrier per block: a block is
+// 64 MFMAs x 64 cycles per wave, so nothing about the staging needs to be clever.
+#include "tg_common.hpp"
+
+namespace tg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kF32MaxHidden = 4;
+
+struct F32Net {
+    const uint4* w0;        // first layer, fragment order [H/32 tiles][k2/4][64 lanes] x 16 B (4 consecutive MFMA steps per lane)
+    const float* bias;      // [n_hh + 1][H] hidden biases, natural order
+    const float* wh;        // [4][H] head weights (rows >= A zero), natural order
+    const float* bh;        // [4] head bias
+    const uint4* blocks;    // H x H layers: forward blocks [n_hh][H/32][H/8][64] x 16 B, then the backward (transposed) blocks, top layer first
+    int32_t n_hh;           // H x H layers (hidden layers - 1)
+    int32_t k2;             // first-layer k pairs = padded input width / 2 (multiple of 4, <= 16)
+};
+
+struct F32Loss {            // the loss head (as ChainLoss of mlp_fwd_chain.hip)
+    int32_t kind, A;        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error)
+    const float* act;       // actor: [rows][A] contiguous; critic: the returns [rows]
+    const float* logp_old; const float* adv;
+    float n_m, n_i;         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
+    float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
+    float* dout4;           // out: d loss / d head output, f32 [rows][4] (columns >= A zero)
+    double* work;           // out: f64 [grid][4] partial loss sums (surrogate, squared error, KL, count)
+};
+
+struct F32ChainArgs {
+    const float* x;         // [rows][2 k2] f32, zero padded
+    int64_t rows;
+    F32Net net;
+    float* acts[kF32MaxHidden];   // kTrain: post-ReLU outputs of the hidden layers, f32 [rows][H]
+    float* dz[kF32MaxHidden];     // kTrain: d loss / d pre-activation of the hidden layers, f32 [rows][H]
+    float* out;             // !kTrain: head output f32 [rows][4]
+    F32Loss loss;
+};
+
+__device__ static inline f32x16 bias_rows(const float* __restrict__ b) {     // b = table + 32 tile + 4 h
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b + 8 * q);
+        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+    }
+    return acc;
+}
+
+// the lane's 16 values of tile `mt` (features 32 mt + 8 q + 4 h + 0..3) to row-major [rows][H]
+template <int H>
+__device__ static inline void store_tile(float* __restrict__ g, int64_t row, int mt, int h, const f32x16& v) {
+    float* p = g + row * H + 32 * mt + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(p + 8 * q) = float4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
+template <int H, bool kTrain>
+__global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
+    constexpr int MT = H / 32;                  // 32-feature tiles per layer
+    constexpr int G4 = H / 8;                   // groups of 4 MFMA steps per H x H block
+    constexpr int BLK = G4 * 64;                // uint4 per block
+    constexpr int SQ = BLK / 512;               // uint4 per thread and block (2 at H = 128, 1 at H = 64)
+    static_assert(BLK % 512 == 0, "a block is a whole number of 16-B pieces per thread");
+    extern __shared__ uint4 lds[];
+    uint4* ring = lds;                                              // 2 x BLK
+    uint4* w0s = ring + 2 * BLK;                                    // MT x 4 x 64 (k2 <= 16)
+    float* bias_s = reinterpret_cast<float*>(w0s + MT * 4 * 64);    // kF32MaxHidden x H
+    float* wh_s = bias_s + kF32MaxHidden * H;                       // 4 x H
+    float* bh_s = wh_s + 4 * H;                                     // 4 (+ 12 pad)
+    uint32_t* bits_s = reinterpret_cast<uint32_t*>(bh_s + 16);      // kTrain: [layer][wave][MT / 2 words][64 lanes]: ReLU masks
+    double* red_s = reinterpret_cast<double*>(bits_s + kF32MaxHidden * 8 * (MT / 2 > 0 ? MT / 2 : 1) * 64);   // 8 waves x 4
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const F32Net& net = a.net;
+    const int n_hh = net.n_hh, K2 = net.k2;
+    const int64_t rows = a.rows;
+    const int64_t n_rounds = (rows + 255) / 256;
+
+    // ---- resident tables ----
+    for (int q = tid; q < MT * (K2 / 4) * 64; q += 512) w0s[q] = net.w0[q];
+    for (int q = tid; q < (n_hh + 1) * H; q += 512) bias_s[q] = net.bias[q];
+    for (int q = tid; q < 4 * H; q += 512) wh_s[q] = net.wh[q];
+    if (tid < 4) bh_s[tid] = net.bh[tid];
+
+    // ---- block stream: two LDS buffers, register staging one block ahead ----
+    const int n_stream = n_hh * MT * (kTrain ? 2 : 1);              // blocks per round (the same sequence every round)
+    static_assert(SQ == 1 || SQ == 2, "one or two 16-B pieces per thread and block");
+    uint4 stg0 = {}, stg1 = {};                                     // (named, not an array: hipcc put a 2-element array in scratch)
+    int pos = 0, buf = 0;
+    auto load_block = [&]() {
+        const uint4* src = net.blocks + (int64_t)pos * BLK + tid;
+        stg0 = src[0];
+        if constexpr (SQ == 2) stg1 = src[512];
+        pos = pos + 1 == n_stream ? 0 : pos + 1;
+    };
+    auto write_block = [&](int b) {
+        uint4* dst = ring + b * BLK + tid;
+        dst[0] = stg0;
+        if constexpr (SQ == 2) dst[512] = stg1;
+    };
+    if (n_stream > 0) {
+        load_block();
+        write_block(0);
+        load_block();
+    }
+    __syncthreads();
+    // a block's life: BEGIN hands the next block (in registers since the previous BEGIN) to the idle buffer and requests the one
+    // after; the products read `cur`; END is the workgroup barrier that retires `cur` and publishes the buffer just written
+#define TG_F32_BLOCK_BEGIN              \
+    write_block(buf ^ 1);               \
+    load_block();                       \
+    const uint4* cur = ring + buf * BLK;
+#define TG_F32_BLOCK_END                \
+    __syncthreads();                    \
+    buf ^= 1;
+
+    // one 32-feature output tile against a whole H-wide operand: H / 2 MFMA steps; step (mt, t) multiplies the block's k pair
+    // F(t, 0 / 1) of input tile mt = register t of the two lane halves
+    auto tile_products = [&](const uint4* __restrict__ cur, const f32x16 (&xin)[MT], f32x16 acc) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 w4 = cur[(4 * mt + q) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.x), xin[mt][4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.y), xin[mt][4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.z), xin[mt][4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.w), xin[mt][4 * q + 3], acc, 0, 0, 0);
+            }
+        return acc;
+    };
+    // ReLU in place + its mask as 16 bits
+    auto relu_bits = [&](f32x16& v) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            m |= (v[r] > 0.0f ? 1u : 0u) << r;
+            v[r] = fmaxf(v[r], 0.0f);
+        }
+        return m;
+    };
+    auto bits_slot = [&](int layer, int word) { return bits_s + ((layer * 8 + wave) * (MT / 2) + word) * 64 + lane; };
+
+    double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
+
+    for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+        const int64_t row = round * 256 + wave * 32 + j;
+        const bool valid = row < rows;
+        const int64_t rowc = valid ? row : rows - 1;
+        f32x16 xin[MT], xout[MT];
+
+        // ---- layer 0: K = 2 k2 <= 32 inputs; lane half h holds x[h k2 .. h k2 + k2) (step t pairs columns t and k2 + t) ----
+        {
+            float xr[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = float4{0.f, 0.f, 0.f, 0.f};
+                if (4 * q < K2) v = *reinterpret_cast<const float4*>(a.x + rowc * (2 * K2) + h * K2 + 4 * q);
+                xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                f32x16 acc = bias_rows(bias_s + 32 * mo + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * q < K2) {
+                        const uint4 w4 = w0s[(mo * (K2 / 4) + q) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.x), xr[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.y), xr[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.z), xr[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w4.w), xr[4 * q + 3], acc, 0, 0, 0);
+                    }
+                const uint32_t m = relu_bits(acc);
+                xin[mo] = acc;
+                if constexpr (kTrain) {
+                    if (mo & 1) *bits_slot(0, mo >> 1) |= m << 16; else *bits_slot(0, mo >> 1) = m;
+                    if (valid) store_tile<H>(a.acts[0], row, mo, h, acc);
+                }
+            }
+        }
+        // ---- hidden H x H layers: one streamed block per 32 output features ----
+        for (int l = 1; l <= n_hh; ++l) {
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                TG_F32_BLOCK_BEGIN
+                f32x16 acc = tile_products(cur, xin, bias_rows(bias_s + l * H + 32 * mo + 4 * h));
+                const uint32_t m = relu_bits(acc);
+                xout[mo] = acc;
+                if constexpr (kTrain) {
+                    if (mo & 1) *bits_slot(l, mo >> 1) |= m << 16; else *bits_slot(l, mo >> 1) = m;
+                    if (valid) store_tile<H>(a.acts[l], row, mo, h, acc);
+                }
+                TG_F32_BLOCK_END
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xin[mt] = xout[mt];
+        }
+        // ---- head: <= 4 outputs as fp32 dot products over the lane's features, the two halves added by one exchange ----
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const int A = kTrain ? a.loss.A : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < A) {
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w = *reinterpret_cast<const float4*>(wh_s + k * H + 32 * mt + 8 * q + 4 * h);
+                        s = fmaf(xin[mt][4 * q + 0], w.x, s);
+                        s = fmaf(xin[mt][4 * q + 1], w.y, s);
+                        s = fmaf(xin[mt][4 * q + 2], w.z, s);
+                        s = fmaf(xin[mt][4 * q + 3], w.w, s);
+                    }
+                // fixed order: half 0 + half 1 (both halves end up with the same bits)
+                const float other = __shfl_xor(s, 32, 64);
+                o[k] = (h ? other + s : s + other) + bh_s[k];
+            }
+        if constexpr (!kTrain) {
+            if (valid && h == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
+        } else {
+            // ---- loss head (loss_kernels.hip::surrogate_loss_kernel, same arithmetic), evaluated by both lane halves ----
+            const F32Loss& L = a.loss;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            float c_surr = 0.f, c_crit = 0.f, c_kl = 0.f;
+            if (L.kind == 0) {
+                float quad = 0.f, dmu[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = (k < L.A ? L.act[rowc * L.A + k] : 0.f) - o[k];
+                    dmu[k] = d;
+                    quad += d * d * L.inv_var[k];
+                }
+                const float lp = -0.5f * quad + L.logp_const;
+                const float lpo = L.logp_old[rowc];
+                const float adv = (L.adv[rowc] - L.n_m) * L.n_i;
+                const float rho = expf(lp - lpo);
+                const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
+                const float surr1 = rho * adv, surr2 = fminf(fmaxf(rho, lo), hi) * adv;
+                const bool inside = (rho >= lo) && (rho <= hi);
+                const float w = inside ? 1.0f : (surr1 < surr2 ? 1.0f : 0.0f);
+                c_surr = fminf(surr1, surr2);
+                float dlp = L.surr_coef * adv * rho * w;
+                if (L.kl_coef != 0.0f) {
+                    const float eo = expf(lpo);
+                    c_kl = eo * (lpo - lp);
+                    dlp -= L.kl_coef * eo;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = dlp * dmu[k] * L.inv_var[k];
+            } else {
+                const float d = o[0] - (L.act[rowc] - L.n_m) * L.n_i;
+                c_crit = d * d;
+                g[0] = L.critic_coef * 2.0f * d;
+            }
+            if (!valid) { g[0] = g[1] = g[2] = g[3] = 0.f; }
+            if (valid && h == 0) {
+                s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
+                *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{g[0], g[1], g[2], g[3]};
+            }
+            // ---- backward: dZ_top = (g . W_head) * (a_top > 0), then dZ_below = (W^T . dZ) * mask per layer, top down ----
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint32_t mw = *bits_slot(n_hh, mt >> 1) >> (16 * (mt & 1));
+                f32x16 d;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 s = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < L.A) {
+                            const float4 w = *reinterpret_cast<const float4*>(wh_s + k * H + 32 * mt + 8 * q + 4 * h);
+                            s.x = fmaf(g[k], w.x, s.x); s.y = fmaf(g[k], w.y, s.y); s.z = fmaf(g[k], w.z, s.z); s.w = fmaf(g[k], w.w, s.w);
+                        }
+                    d[4 * q + 0] = (mw >> (4 * q + 0)) & 1u ? s.x : 0.f;
+                    d[4 * q + 1] = (mw >> (4 * q + 1)) & 1u ? s.y : 0.f;
+                    d[4 * q + 2] = (mw >> (4 * q + 2)) & 1u ? s.z : 0.f;
+                    d[4 * q + 3] = (mw >> (4 * q + 3)) & 1u ? s.w : 0.f;
+                }
+                xin[mt] = d;
+                if (valid) store_tile<H>(a.dz[n_hh], row, mt, h, d);
+            }
+            for (int l = n_hh; l >= 1; --l) {
+#pragma unroll
+                for (int ko = 0; ko < MT; ++ko) {
+                    TG_F32_BLOCK_BEGIN
+                    f32x16 acc = tile_products(cur, xin, f32x16{});
+                    const uint32_t mw = *bits_slot(l - 1, ko >> 1) >> (16 * (ko & 1));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = (mw >> r) & 1u ? acc[r] : 0.f;
+                    xout[ko] = acc;
+                    if (valid) store_tile<H>(a.dz[l - 1], row, ko, h, acc);
+                    TG_F32_BLOCK_END
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xin[mt] = xout[mt];
+            }
+        }
+    }
+#undef TG_F32_BLOCK_BEGIN
+#undef TG_F32_BLOCK_END
+    if constexpr (kTrain) {
+        // loss sums: lanes -> wave (fixed shuffle tree) -> workgroup (waves in order): deterministic
+        double v[4] = {s_surr, s_crit, s_kl, s_cnt};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red_s[wave * 4 + k] = v[k];
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double t = 0.0;
+            for (int w = 0; w < 8; ++w) t += red_s[w * 4 + tid];
+            a.loss.work[(int64_t)blockIdx.x * 4 + tid] = t;
+        }
+    }
+}
+
+template <int H>
+static size_t f32_chain_lds() {
+    constexpr int MT = H / 32, BLK = (H / 8) * 64;
+    return (size_t)2 * BLK * 16 + (size_t)MT * 4 * 64 * 16 + (size_t)(kF32MaxHidden * H + 4 * H + 16) * 4 +
+           (size_t)kF32MaxHidden * 8 * (MT / 2) * 64 * 4 + 8 * 4 * 8;
+}
+
+static int f32_chain_grid(int64_t rows) {
+    const int64_t n_rounds = ceil_div(rows, 256);
+    const int cus = device_cus();
+    return (int)(n_rounds < cus ? n_rounds : cus);
+}
+
+template <int H, bool kTrain>
+static int launch_f32_chain(const F32ChainArgs& args, hipStream_t st) {
+    auto kern = mlp_f32_chain_kernel<H, kTrain>;
+    const size_t shmem = f32_chain_lds<H>();
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_forward")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)f32_chain_grid(args.rows)), dim3(512), shmem, st, args);
+    TG_LAUNCH_CHECK("tg_mlp_f32_forward");
+    return TG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradients: dW_l = dZ_l^T . A_{l-1} (A_{-1} = the input), db_l = column sums of dZ_l, head: dW_h = g^T . A_top, db_h.
+// The contraction runs over ROWS: A operand lane (i, kk) = P[row 2 s + kk][m0 + i], B operand lane (j, kk) = Q[row 2 s + kk][n0 + j]
+// straight out of row-major LDS panels (one conflict-free ds_read_b32 per operand and MFMA).  A workgroup (4 waves) owns ONE
+// job (layer) for a share of the 32-row stages and keeps that layer's whole gradient in accumulator registers; panels come in
+// through registers one stage ahead (the products of a stage take 64 MFMAs x 64 cycles per wave: nothing to hide behind).
+// Bias sums and the head's gradient (4 x H) are fp32 vector arithmetic beside the matrix work.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kF32DwMaxJobs = 8;
+enum : int32_t { F32DW_MM = 0, F32DW_HEAD = 1 };
+struct F32DwJob {
+    const float* p;         // MM: dZ f32 [rows][M = H];            HEAD: g f32 [rows][4]
+    const float* q;         // MM: A  f32 [rows][N] (N = H, or the padded input width <= 32);  HEAD: A_top f32 [rows][H]
+    int32_t kind, n;        // n: columns of q
+    int32_t first_block, n_blocks, slab_len;
+    int64_t slab_off;
+};
+struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
+
+template <int H>
+__global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int64_t rows, float* __restrict__ ws) {
+    constexpr int MT = H / 32;
+    constexpr int TW = MT >= 4 ? 2 : 1;                 // a wave's block of output tiles is TW x TW (H = 128: 2 x 2; H = 64: 1 x 1)
+    constexpr int PF4 = 32 * H / 4 / 256;               // float4 per thread and wide panel (4 at H = 128, 2 at H = 64)
+    extern __shared__ uint4 lds[];
+    float* panel = reinterpret_cast<float*>(lds);       // [2 buffers][P panel 32 x H | Q panel 32 x H]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    int jb = 0;
+#pragma unroll
+    for (int t = 1; t < kF32DwMaxJobs; ++t)
+        if (t < args.n_jobs && (int)blockIdx.x >= args.job[t].first_block) jb = t;
+    const F32DwJob job = args.job[jb];
+    const int my = (int)blockIdx.x - job.first_block, nb = job.n_blocks;
+    const int64_t n_st = (rows + 31) / 32;
+    const bool head = job.kind == F32DW_HEAD;
+    const int N = job.n;                                // Q columns
+    const bool narrow = !head && N <= 32;               // first-layer job: Q = the padded input rows
+
+    // ---- staging: registers one stage ahead ----
+    float4 sp[PF4], sq[PF4];
+    auto fetch = [&](int64_t sg) {
+        const int64_t r0 = sg * 32;
+#pragma unroll
+        for (int t = 0; t < PF4; ++t) {
+            const int e = t * 256 + tid;                // float4 index within a [32][H] panel
+            const int r = e / (H / 4), c4 = e % (H / 4);
+            const bool ok = r0 + r < rows;
+            sp[t] = float4{0.f, 0.f, 0.f, 0.f};
+            sq[t] = float4{0.f, 0.f, 0.f, 0.f};
+            if (head) {
+                if (e < 32 && r0 + e < rows) sp[t] = *reinterpret_cast<const float4*>(job.p + (r0 + e) * 4);       // g rows: 32 float4
+            } else if (ok) {
+                sp[t] = *reinterpret_cast<const float4*>(job.p + (r0 + r) * H + 4 * c4);
+            }
+            if (narrow) {
+                const int rn = e / 8, cn = e % 8;       // Q image [32][32]: 8 float4 per row, zero beyond N
+                if (e < 256 && r0 + rn < rows && 4 * cn < N) sq[t] = *reinterpret_cast<const float4*>(job.q + (r0 + rn) * N + 4 * cn);
+            } else if (ok) {
+                sq[t] = *reinterpret_cast<const float4*>(job.q + (r0 + r) * H + 4 * c4);
+            }
+        }
+    };
+    auto commit = [&](int b) {
+        float* P = panel + b * (2 * 32 * H);
+        float* Q = P + 32 * H;
+#pragma unroll
+        for (int t = 0; t < PF4; ++t) {
+            const int e = t * 256 + tid;
+            if (head) { if (e < 32) *reinterpret_cast<float4*>(P + 4 * e) = sp[t]; }
+            else *reinterpret_cast<float4*>(P + 4 * e) = sp[t];
+            if (narrow) { if (e < 256) *reinterpret_cast<float4*>(Q + 4 * e) = sq[t]; }
+            else *reinterpret_cast<float4*>(Q + 4 * e) = sq[t];
+        }
+    };
+
+    // wave -> output tiles.  wide job: tiles (TW wm + a, TW wn + b); narrow job: m-tile `wave` (waves < MT), one n-tile
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[TW][TW];
+#pragma unroll
+    for (int x = 0; x < TW; ++x)
+#pragma unroll
+        for (int y = 0; y < TW; ++y) acc[x][y] = f32x16{};
+    float bsum = 0.f;                                   // bias gradient of column `tid` (tid < H); head: of output `tid` (tid < 4)
+    float hacc[4] = {0.f, 0.f, 0.f, 0.f};               // head: dW_h[a][tid]
+
+    int64_t sg = my;
+    if (sg < n_st) fetch(sg);
+    int b = 0;
+    for (; sg < n_st; sg += nb) {
+        __syncthreads();                                // everyone is done with buffer b (read two stages ago)
+        commit(b);
+        __syncthreads();
+        if (sg + nb < n_st) fetch(sg + nb);
+        const float* P = panel + b * (2 * 32 * H);
+        const float* Q = P + 32 * H;
+        if (head) {
+            if (tid < H) {
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(P + 4 * r);
+                    const float qv = Q[r * H + tid];
+                    hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
+                    hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
+                }
+            }
+            if (tid < 4) {
+                for (int r = 0; r < 32; ++r) bsum += P[4 * r + tid];
+            }
+        } else {
+            if (narrow) {
+                if (wave < MT) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float av = P[(2 * s + kk) * H + 32 * wave + i];
+                        const float bv = Q[(2 * s + kk) * 32 + i];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    float av[TW], bv[TW];
+#pragma unroll
+                    for (int x = 0; x < TW; ++x) {
+                        av[x] = P[(2 * s + kk) * H + 32 * (TW * wm + x) + i];
+                        bv[x] = Q[(2 * s + kk) * H + 32 * (TW * wn + x) + i];
+                    }
+#pragma unroll
+                    for (int x = 0; x < TW; ++x)
+#pragma unroll
+                        for (int y = 0; y < TW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+                }
+            }
+            if (tid < H) {
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) bsum += P[r * H + tid];
+            }
+        }
+        b ^= 1;
+    }
+
+    // ---- this workgroup's slab ----
+    float* slab = ws + job.slab_off + (int64_t)my * job.slab_len;
+    const int col = lane & 31, hh = lane >> 5;
+    if (head) {
+        if (tid < H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) slab[k * H + tid] = hacc[k];
+        }
+        if (tid < 4) slab[4 * H + tid] = bsum;
+    } else if (narrow) {
+        if (wave < MT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[0][0][r];
+        }
+        if (tid < H) slab[H * 32 + tid] = bsum;
+    } else {
+        if (TW == 2 || wave < MT * MT) {
+#pragma unroll
+            for (int x = 0; x < TW; ++x)
+#pragma unroll
+                for (int y = 0; y < TW; ++y) {
+                    const int m0 = 32 * (TW * wm + x), n0 = 32 * (TW * wn + y);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[x][y][r];
+                }
+        }
+        if (tid < H) slab[H * H + tid] = bsum;
+    }
+}
+
+// grad[m][n] += sum over the job's slabs, in slab order (as dw_finish_all_kernel of mlp_dw.hip)
+struct F32FinishDesc {
+    const float* slab; float* grad; int64_t grad_ld;
+    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
+};
+struct F32FinishArgs { F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total; };
+
+__global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= fa.total) return;
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < 2 * kF32DwMaxJobs; ++t)
+        if (t < fa.n && e >= fa.d[t].first_elem) k = t;
+    const F32FinishDesc d = fa.d[k];
+    const int le = e - d.first_elem;
+    const int m = le / d.n_out, n = le - m * d.n_out;
+    const float* src = d.slab + (int64_t)m * d.N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= d.n_slabs; b += 4) {
+        const float v0 = src[(int64_t)b * d.slab_len], v1 = src[(int64_t)(b + 1) * d.slab_len];
+        const float v2 = src[(int64_t)(b + 2) * d.slab_len], v3 = src[(int64_t)(b + 3) * d.slab_len];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < d.n_slabs; ++b) s0 += src[(int64_t)b * d.slab_len];
+    d.grad[(int64_t)m * d.grad_ld + n] += (s0 + s1) + (s2 + s3);
+}
+
+static int f32_dw_max_blocks() { return 2 * device_cus(); }
+static int f32_dw_slab_len(int H, int kind, int n) { return kind == F32DW_HEAD ? 4 * H + 4 : (n <= 32 ? H * 32 + H : H * H + H); }
+
+}  // namespace tg
+
+using namespace tg;
+
+static int fill_f32_net(F32Net& net, const float* d_stream, int hidden, int n_hidden_layers, int in_pad, const char* what) {
+    if (!(hidden == 64 || hidden == 128)) return set_error(TG_ERR_ARG, "%s: hidden width %d unsupported (64, 128)", what, hidden);
+    if (!(n_hidden_layers >= 1 && n_hidden_layers <= kF32MaxHidden))
+        return set_error(TG_ERR_ARG, "%s: %d hidden layers outside 1..%d", what, n_hidden_layers, kF32MaxHidden);
+    if (!(in_pad >= 8 && in_pad <= 32 && in_pad % 8 == 0)) return set_error(TG_ERR_ARG, "%s: padded input width %d must be 8, 16, 24 or 32", what, in_pad);
+    const int H = hidden, MT = H / 32, n_hh = n_hidden_layers - 1;
+    const float* p = d_stream;
+    net.w0 = reinterpret_cast<const uint4*>(p); p += (size_t)H * in_pad;
+    net.bias = p; p += (size_t)n_hidden_layers * H;
+    net.wh = p; p += (size_t)4 * H;
+    net.bh = p; p += 4;
+    net.blocks = reinterpret_cast<const uint4*>(p);
+    net.n_hh = n_hh;
+    net.k2 = in_pad / 2;
+    (void)MT;
+    return TG_OK;
+}
+
+extern "C" {
+
+int64_t tg_mlp_f32_stream_floats(int32_t hidden, int32_t n_hidden_layers, int32_t in_pad) {
+    if (!(hidden == 64 || hidden == 128) || n_hidden_layers < 1 || n_hidden_layers > kF32MaxHidden || in_pad < 8 || in_pad > 32 || in_pad % 8) return 0;
+    const int64_t H = hidden, n_hh = n_hidden_layers - 1;
+    return H * in_pad + n_hidden_layers * H + 4 * H + 4 + 2 * n_hh * H * H;
+}
+
+int tg_mlp_f32_blocks(void) { return device_cus(); }
+
+int tg_mlp_f32_forward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers, int64_t rows,
+                       float* d_out, void* stream) {
+    TG_REQUIRE(d_x && d_stream && d_out, "tg_mlp_f32_forward: null pointer");
+    TG_REQUIRE(rows >= 0, "tg_mlp_f32_forward: negative row count");
+    F32ChainArgs a{};
+    if (int rc = fill_f32_net(a.net, d_stream, hidden, n_hidden_layers, in_pad, "tg_mlp_f32_forward")) return rc;
+    if (rows == 0) return TG_OK;
+    a.x = d_x; a.rows = rows; a.out = d_out;
+    hipStream_t st = (hipStream_t)stream;
+    return hidden == 128 ? launch_f32_chain<128, false>(a, st) : launch_f32_chain<64, false>(a, st);
+}
+
+int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
+                                int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream) {
+    TG_REQUIRE(d_x && d_stream && d_acts && d_dz && loss, "tg_mlp_f32_forward_backward: null pointer");
+    TG_REQUIRE(rows > 0, "tg_mlp_f32_forward_backward: no rows");
+    TG_REQUIRE(loss->kind == 0 || loss->kind == 1, "tg_mlp_f32_forward_backward: kind %d", loss->kind);
+    TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_f32_forward_backward: %d outputs unsupported (1..4)", loss->act_dim);
+    TG_REQUIRE(loss->d_dout8 && loss->d_work, "tg_mlp_f32_forward_backward: null output");
+    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && loss->d_logp_old && loss->d_adv),
+               "tg_mlp_f32_forward_backward: missing per-row input");
+    TG_REQUIRE(loss->kind == 1 || (loss->act_col_stride == 1 && loss->act_row_stride == loss->act_dim),
+               "tg_mlp_f32_forward_backward: the actions must be contiguous [rows][act_dim]");
+    F32ChainArgs a{};
+    if (int rc = fill_f32_net(a.net, d_stream, hidden, n_hidden_layers, in_pad, "tg_mlp_f32_forward_backward")) return rc;
+    for (int l = 0; l < n_hidden_layers; ++l) {
+        TG_REQUIRE(d_acts[l] && d_dz[l], "tg_mlp_f32_forward_backward: buffer %d is null", l);
+        a.acts[l] = (float*)d_acts[l];
+        a.dz[l] = (float*)d_dz[l];
+    }
+    a.x = d_x; a.rows = rows;
+    F32Loss& L = a.loss;
+    L.kind = loss->kind; L.A = loss->act_dim;
+    L.act = loss->kind == 0 ? loss->d_act : loss->d_ret;
+    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv;
+    L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
+    float logdet = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        L.inv_var[k] = k < loss->act_dim ? 1.0f / loss->var[k] : 0.f;
+        if (k < loss->act_dim) logdet += logf(loss->var[k]);
+    }
+    L.logp_const = -0.5f * (float)loss->act_dim * 1.8378770664093453f - 0.5f * logdet;
+    L.epsilon = loss->epsilon; L.surr_coef = loss->surr_coef; L.critic_coef = loss->critic_coef; L.kl_coef = loss->kl_coef;
+    L.dout4 = (float*)loss->d_dout8; L.work = loss->d_work;
+    hipStream_t st = (hipStream_t)stream;
+    return hidden == 128 ? launch_f32_chain<128, true>(a, st) : launch_f32_chain<64, true>(a, st);
+}
+
+int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
+    if (hidden != 64 && hidden != 128) return 0;
+    return (int64_t)f32_dw_max_blocks() * (hidden * hidden + hidden) * (int64_t)sizeof(float);
+}
+
+int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
+                           int64_t workspace_bytes, void* stream) {
+    TG_REQUIRE(jobs && d_workspace, "tg_mlp_f32_weight_grad: null pointer");
+    TG_REQUIRE(hidden == 64 || hidden == 128, "tg_mlp_f32_weight_grad: hidden width %d unsupported (64, 128)", hidden);
+    TG_REQUIRE(n_jobs >= 1 && n_jobs <= kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d jobs outside 1..%d", n_jobs, kF32DwMaxJobs);
+    TG_REQUIRE(rows >= 0, "tg_mlp_f32_weight_grad: negative row count");
+    TG_REQUIRE(workspace_bytes >= tg_mlp_f32_weight_grad_workspace(hidden), "tg_mlp_f32_weight_grad: workspace of %lld B is smaller than %lld B",
+               (long long)workspace_bytes, (long long)tg_mlp_f32_weight_grad_workspace(hidden));
+    if (rows == 0) return TG_OK;
+    const int H = hidden, MT = H / 32;
+    int64_t cost[kF32DwMaxJobs], csum = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const tg_f32_dw_job& jb = jobs[j];
+        TG_REQUIRE(jb.kind == F32DW_MM || jb.kind == F32DW_HEAD, "tg_mlp_f32_weight_grad: job %d has kind %d", j, jb.kind);
+        TG_REQUIRE(jb.d_p && jb.d_q && jb.d_wgrad, "tg_mlp_f32_weight_grad: job %d has a null pointer", j);
+        if (jb.kind == F32DW_HEAD) {
+            TG_REQUIRE(jb.n_cols == H && jb.m_out >= 1 && jb.m_out <= 4 && jb.n_out == H && jb.wgrad_ld >= H, "tg_mlp_f32_weight_grad: job %d: bad head window", j);
+            cost[j] = 6;                                    // vector arithmetic of two waves: about a third of a tile row of products
+        } else {
+            TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
+            TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
+            cost[j] = jb.n_cols == H ? (H == 128 ? 64 : 16) : 16;   // MFMAs per wave and stage on the critical wave
+        }
+        csum += cost[j];
+    }
+    const int64_t n_st = ceil_div(rows, (int64_t)32);
+    const int cap = (int)(n_st < 8 ? 1 : (n_st / 8 > 1 << 20 ? 1 << 20 : n_st / 8));     // at least 8 stages per workgroup
+    const int max_blocks = f32_dw_max_blocks();
+    int alloc[kF32DwMaxJobs], used = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        alloc[j] = (int)(cost[j] * max_blocks / csum);
+        if (alloc[j] < 1) alloc[j] = 1;
+        used += alloc[j];
+    }
+    while (used > max_blocks) {                              // (the minimum of one per job may overshoot)
+        int big = 0;
+        for (int j = 1; j < n_jobs; ++j)
+            if (alloc[j] > alloc[big]) big = j;
+        --alloc[big];
+        --used;
+    }
+    F32DwArgs args{};
+    args.n_jobs = n_jobs;
+    F32FinishArgs fa{};
+    int grid = 0, elems = 0;
+    int64_t off = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const tg_f32_dw_job& jb = jobs[j];
+        F32DwJob& dj = args.job[j];
+        dj.p = jb.d_p; dj.q = jb.d_q; dj.kind = jb.kind; dj.n = jb.n_cols;
+        dj.first_block = grid;
+        dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;
+        dj.slab_len = f32_dw_slab_len(H, jb.kind, jb.n_cols);
+        dj.slab_off = off;
+        grid += dj.n_blocks;
+        const int Nslab = jb.kind == F32DW_HEAD ? H : (jb.n_cols <= 32 ? 32 : H);
+        F32FinishDesc& fd = fa.d[fa.n++];
+        fd = F32FinishDesc{(const float*)d_workspace + off, jb.d_wgrad, jb.wgrad_ld, dj.slab_len, dj.n_blocks, Nslab, jb.m_out, jb.n_out, elems};
+        elems += jb.m_out * jb.n_out;
+        if (jb.d_bgrad) {
+            const int boff = jb.kind == F32DW_HEAD ? 4 * H : (jb.n_cols <= 32 ? H * 32 : H * H);
+            F32FinishDesc& fb = fa.d[fa.n++];
+            fb = F32FinishDesc{(const float*)d_workspace + off + boff, jb.d_bgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.m_out, elems};
+            elems += jb.m_out;
+        }
+        off += (int64_t)dj.n_blocks * dj.slab_len;
+    }
+    fa.total = elems;
+    (void)MT;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shmem = (size_t)2 * 2 * 32 * H * sizeof(float);
+    if (hidden == 128) {
+        auto kern = mlp_f32_dw_kernel<128>;
+        static LdsOptIn opt_in;
+        if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_weight_grad")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, st, args, rows, (float*)d_workspace);
+    } else {
+        auto kern = mlp_f32_dw_kernel<64>;
+        static LdsOptIn opt_in;
+        if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_weight_grad")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, st, args, rows, (float*)d_workspace);
+    }
+    TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad");
+    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, fa);
+    TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad (finish)");
+    return TG_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,7 @@ _ROW_BLOCK = 8192
 _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
 _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
 _FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
+_F32_CHAIN = os.environ.get("TG_F32_CHAIN", "1") == "1"       # 0: fp32 nets on the per-layer GEMM path (A/B runs)
 
 
 # address ranges of the input buffers some GemmMLP.prepare_input() gave a column of ones (a property of the buffer, shared by
@@ -117,7 +118,11 @@ class GemmMLP:
         self.linears = [m for m in net.network if isinstance(m, torch.nn.Linear)]
         dev = self.linears[0].weight.device
         self.in_dim, self.out_dim = self.linears[0].in_features, self.linears[-1].out_features
-        self.in_pad = _round_up(self.in_dim, 32)
+        # fp32 nets of the reference's own shapes: the fp32 chain learner (tg_mlp_f32_forward / _forward_backward / _weight_grad)
+        self._f32 = None
+        if compute_dtype == torch.float32 and _F32_CHAIN and f32_chain_supported(net):
+            self._f32 = F32ChainStream(net, f32_chain_supported(net))
+        self.in_pad = _round_up(self.in_dim, 32) if self._f32 is None else self._f32.in_pad
         self.out_pad = _round_up(self.out_dim, 8)
         self.w, self.b = [], []
         for i, l in enumerate(self.linears):
@@ -166,7 +171,7 @@ class GemmMLP:
         """The fp32 master weights changed: every derived operand (padded compute-dtype copies, chain streams, packed
         backward-data fragments) is rebuilt the next time the path that reads it runs -- with the chain kernels active
         the per-layer copies are never touched (17 of 36 tiny launches per update and net)."""
-        self._stale = {"w", "chain", "bchain", "dx"}
+        self._stale = {"w", "chain", "bchain", "dx", "f32"}
 
     def _fresh(self, what: str):
         if what not in self._stale:
@@ -182,6 +187,8 @@ class GemmMLP:
                 self._chain.refresh()
             elif what == "bchain":
                 self._bchain.refresh()
+            elif what == "f32":
+                self._f32.refresh()
             elif what == "dx":
                 self._fresh("w")
                 for w, frag in zip(self.w, self._dxfrag):
@@ -194,7 +201,7 @@ class GemmMLP:
         (into `out` when given: a [M][in_pad] buffer of the compute dtype)."""
         xp = torch.zeros(X.shape[0], self.in_pad, dtype=self.cd, device=X.device) if out is None else out.zero_()
         xp[:, :self.in_dim].copy_(X)
-        if self.in_pad == 32 and self.in_dim < 32:
+        if self.in_pad == 32 and self.in_dim < 32 and self._f32 is None:
             # a padding column of ones: the first layer's weights are zero there (the forward pass does not see it), and
             # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0.  The address range is
             # remembered: only inputs prepared HERE (or slices of them) take that path -- a caller that pads its own input
@@ -223,6 +230,16 @@ class GemmMLP:
         `xp`: [rows][in_pad] compute dtype, zero padded -- normally from prepare_input(), whose ones column (31) lets the
         backward chain form the first layer's bias gradient; a caller-padded input works too (kind HX job instead)."""
         L = len(self.linears)
+        if self._f32 is not None and not keep and xp.shape[0] > 0:
+            # the no-grad pass of an fp32 net (old log-probs, values, the per-step rollout's policy mean): one launch
+            self._fresh("f32")
+            f = self._f32
+            assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
+            out = torch.empty(xp.shape[0], 4, dtype=torch.float32, device=xp.device)
+            N.check(N.load().tg_mlp_f32_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.H, f.n_hidden, xp.shape[0],
+                                                out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32_forward")
+            self._acts = self._bits = None
+            return out if padded else out[:, :self.out_dim].contiguous()
         if self._chain is not None and xp.shape[0] > 0:
             self._fresh("chain")
             rows, H = xp.shape[0], self._chain.H
@@ -271,6 +288,8 @@ class GemmMLP:
     def can_fuse_head(self) -> bool:
         """The loss head + the head's weight gradient inside the forward chain (tg_mlp_forward_chain_loss): chain shapes with the
         backward chain active, at most 4 outputs, fp32 gradient windows."""
+        if self._f32 is not None:
+            return all(lin_ok(l) and l.weight.grad.stride(1) == 1 and l.bias.grad.is_contiguous() for l in self.linears)
         return (_FUSE_HEAD and self._chain is not None and self._bchain is not None and self.cd == torch.bfloat16
                 and len(self.linears) - 1 >= 3 and self.out_dim <= 4 and all(lin_ok(l) for l in self.linears)
                 and self.linears[-1].weight.grad.stride(1) == 1)
@@ -282,6 +301,8 @@ class GemmMLP:
         Stores what backward_fused() needs, adds the head's weight / bias gradient into their windows and returns the f64 sums
         [surrogate, squared error, KL, count] of these rows."""
         lib = N.load()
+        if self._f32 is not None:
+            return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef)
         self._fresh("chain")
         L = len(self.linears)
         rows, H, dev = xp.shape[0], self._chain.H, xp.device
@@ -338,9 +359,90 @@ class GemmMLP:
         self._dz_head = dz_head
         return sums
 
+    def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef) -> "N.ChainLoss":
+        a = N.ChainLoss()
+        a.kind, a.act_dim = kind, self.out_dim
+        if kind == 0:
+            N.require_cuda(act, logp_old, adv)
+            assert act.dtype == torch.float32 and logp_old.dtype == torch.float32 and adv.dtype == torch.float32
+            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim) and act.is_contiguous()
+            a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
+            a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
+            va = [float(v) for v in (var.tolist() if isinstance(var, torch.Tensor) else var)]
+            for i in range(self.out_dim):
+                a.var[i] = va[i]
+        else:
+            N.require_cuda(ret)
+            assert ret.dtype == torch.float32 and ret.is_contiguous() and self.out_dim == 1
+            a.d_ret = ret.data_ptr()
+            a.var[0] = 1.0
+        a.norm_mean, a.norm_inv = (0.0, 1.0) if norm is None else (float(norm[0]), float(norm[1]))
+        a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
+        return a
+
+    def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
+        """forward_loss() of an fp32 net: forward + loss head + backward-data pass in ONE launch (tg_mlp_f32_forward_backward);
+        every hidden layer's activation and dZ is written for backward_fused() (tg_mlp_f32_weight_grad)."""
+        lib = N.load()
+        self._fresh("f32")
+        f = self._f32
+        rows, H, dev, nh = xp.shape[0], f.H, xp.device, f.n_hidden
+        assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
+        acts = [self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
+        dzs = [self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
+        dout = self._ws.get("fz_head", rows, 4, torch.float32, dev)
+        nblk = lib.tg_mlp_f32_blocks()
+        if self._head_ws is None:
+            self._head_ws = torch.empty(nblk * 4, dtype=torch.float64, device=dev)
+        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef)
+        a.d_dout8, a.d_work = dout.data_ptr(), self._head_ws.data_ptr()
+        ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in acts])
+        zptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+        ev = None
+        if self.fwd_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.C.byref(a),
+                                                N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
+        if ev is not None:
+            ev[1].record()
+            # matrix-core flops per row: first layer + forward and backward products of the H x H layers (head: vector unit)
+            self.fwd_events.append((ev[0], ev[1], rows, 2 * H * f.in_pad + 4 * (nh - 1) * H * H, f"tg::mlp_f32_chain_kernel<{H},true>"))
+        grid = min(nblk, -(-rows // 256))
+        self._acts, self._bits, self._dz_head = [xp] + acts, dzs, dout
+        return self._head_ws[:grid * 4].view(grid, 4).sum(0)
+
+    def _backward_fused_f32(self):
+        f = self._f32
+        xp, acts, dzs, dout = self._acts[0], self._acts[1:], self._bits, self._dz_head
+        rows, H, nh, lin = xp.shape[0], f.H, f.n_hidden, self.linears
+        if self._dw_ws is None:
+            self._dw_ws = torch.empty(N.load().tg_mlp_f32_weight_grad_workspace(H) // 4, dtype=torch.float32, device=xp.device)
+        specs = [(N.TG_F32DW_MM, dzs[i], acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H) for i in range(nh - 1, 0, -1)]
+        specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim))
+        specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H))
+        arr = (N.F32DwJob * len(specs))()
+        for slot, (kind, p, q, ncols, wg, bg, m_out, n_out) in zip(arr, specs):
+            assert wg.dtype == torch.float32 and wg.stride(1) == 1 and bg.dtype == torch.float32 and bg.is_contiguous()
+            slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wg.data_ptr(), bg.data_ptr()
+            slot.wgrad_ld, slot.kind, slot.n_cols, slot.m_out, slot.n_out = wg.stride(0), kind, ncols, m_out, n_out
+        ev = None
+        if self.dw_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        N.check(N.load().tg_mlp_f32_weight_grad(H, arr, len(specs), rows, self._dw_ws.data_ptr(),
+                                                self._dw_ws.numel() * 4, N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
+        if ev is not None:
+            ev[1].record()
+            self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * 32, f"tg::mlp_f32_dw_kernel<{H}>"))
+        self._acts = self._bits = self._dz_head = None
+
     @torch.no_grad()
     def backward_fused(self):
         """The rest of the backward pass after forward_loss(): the backward chain and the weight gradients (no head job)."""
+        if self._f32 is not None:
+            assert self._acts is not None and self._dz_head is not None, "backward_fused() needs forward_loss()"
+            return self._backward_fused_f32()
         acts, bits = self._acts, self._bits
         assert acts is not None and self._dz_head is not None, "backward_fused() needs forward_loss()"
         self._backward_chain(self._dz_head, acts, bits, acts[0].shape[0], acts[0].device)
@@ -722,3 +824,90 @@ class RegisterStreamF32:
         hw = self.table[n_hidden * H:n_hidden * H + 4 * H].view(4, H)
         hw[:head.out_features].copy_(head.weight)
         self.table[n_hidden * H + 4 * H:n_hidden * H + 4 * H + head.out_features].copy_(head.bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 chain learner (csrc/mlp_f32_chain.hip): weight stream of tg_mlp_f32_forward / _forward_backward
+# ---------------------------------------------------------------------------------------------
+def f32_chain_supported(net) -> int:
+    """Hidden width H if `net` is Linear(S<=32, H) ReLU [Linear(H, H) ReLU]{0..3} Linear(H, A<=4) with H in {64, 128} -- the
+    reference's own policy shapes (pipelines/cartpole_pipeline_grpo.py:54-76, cartpole_pipeline_ppo.py:54-79) -- else 0."""
+    if not supports(net):
+        return 0
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
+    if H not in (64, 128) or not (1 <= len(lin) - 1 <= 4) or lin[0].in_features > 32 or lin[-1].out_features > 4:
+        return 0
+    if any(l.out_features != H for l in lin[:-1]) or any(l.in_features != H for l in lin[1:]):
+        return 0
+    return H
+
+
+class F32ChainStream:
+    """The fp32 weight stream of the chain learner, refreshed from the master weights with ONE gather:
+      [first layer, MFMA fragment order: H/32 tiles x k2/4 groups x 64 lanes x 4]  lane (i, kk), step s = 4 g + e of tile mo holds
+                                                                                 W0[32 mo + i][s + kk k2]   (k2 = in_pad / 2)
+      [hidden biases: n_hidden x H]  [head weights: 4 x H, rows >= A zero]  [head bias: 4]          (natural order)
+      [forward blocks]   layer l = 1..n_hh, output tile mo: H/8 groups x 64 lanes x 4; step s = 16 mt + t holds
+                         W_l[32 mo + i][32 mt + F(t, kk)],  F(t, kk) = (t & 3) + 8 (t >> 2) + 4 kk  -- register t of the two lane
+                         halves of the previous layer's accumulator tile mt (v_mfma_f32_32x32x2_f32: see the kernel's header)
+      [backward blocks]  layer l = n_hh..1 (top first), output tile ko over the layer's INPUT features:
+                         W_l[32 mt + F(t, kk)][32 ko + i]"""
+
+    def __init__(self, net, H: int):
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        self.lin, self.H = lin, H
+        dev = lin[0].weight.device
+        nh = len(lin) - 1
+        self.n_hidden, self.in_dim, self.out_dim = nh, lin[0].in_features, lin[-1].out_features
+        self.in_pad = _round_up(self.in_dim, 8)
+        K2, MT = self.in_pad // 2, H // 32
+        woff, off = [], 0
+        for l in lin:
+            woff.append(off)
+            off += l.weight.numel()
+        boff = []
+        for l in lin:
+            boff.append(off)
+            off += l.bias.numel()
+        zero_at = off
+        lane = torch.arange(64, device=dev).view(1, 64, 1)
+        i, kk = lane & 31, lane >> 5
+        e = torch.arange(4, device=dev).view(1, 1, 4)
+        idx = []
+        # first layer
+        g = torch.arange(K2 // 4, device=dev).view(-1, 1, 1)
+        col = (4 * g + e) + kk * K2
+        for mo in range(MT):
+            row = (32 * mo + i).expand(K2 // 4, 64, 4)
+            src = woff[0] + row * self.in_dim + col
+            idx.append(torch.where(col.expand_as(src) < self.in_dim, src, torch.full_like(src, zero_at)).reshape(-1))
+        # hidden biases, head weights (4 rows), head bias (4)
+        for l in range(nh):
+            idx.append(boff[l] + torch.arange(H, device=dev))
+        for a in range(4):
+            idx.append(woff[nh] + a * H + torch.arange(H, device=dev) if a < self.out_dim else torch.full((H,), zero_at, device=dev))
+        idx.append(torch.tensor([boff[nh] + a if a < self.out_dim else zero_at for a in range(4)], device=dev))
+        # H x H blocks
+        g = torch.arange(H // 8, device=dev).view(-1, 1, 1)
+        s = 4 * g + e
+        mt, t = s // 16, s % 16
+        feat = (32 * mt + (t & 3) + 8 * (t >> 2) + 4 * kk).expand(H // 8, 64, 4)      # the contraction index of step s, lane half kk
+        for l in range(1, nh):                                                          # forward: W_l[32 mo + i][feat]
+            for mo in range(MT):
+                idx.append((woff[l] + (32 * mo + i) * H + feat).reshape(-1))
+        for l in range(nh - 1, 0, -1):                                                  # backward: W_l[feat][32 ko + i]
+            for ko in range(MT):
+                idx.append((woff[l] + feat * H + (32 * ko + i)).reshape(-1))
+        self._idx = torch.cat([x.reshape(-1) for x in idx])
+        n = N.load().tg_mlp_f32_stream_floats(H, nh, self.in_pad)
+        assert self._idx.numel() == n, (self._idx.numel(), n)
+        self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.stream = torch.empty(n, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Two launches: concatenate the master tensors, gather."""
+        src = torch.cat([l.weight.reshape(-1) for l in self.lin] + [l.bias for l in self.lin] + [self._zero])
+        torch.index_select(src if src.dtype == torch.float32 else src.float(), 0, self._idx, out=self.stream)
