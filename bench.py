@@ -579,6 +579,22 @@ def main():
         for fam, ls in fam_launches.items():
             if not ls:
                 continue
+            if "mlp_f32" in ls[0][3]:
+                # the fp32 chain learner (the reference's own precision): bound by the fp32 matrix pipe (v_mfma_f32_32x32x2_f32,
+                # 157.3 TFLOP/s dense = 1/16 of the bf16 rate); the events carry matrix-core flops per row, not bytes
+                dur = sum(d for d, _, _, _ in ls) * 1e-3
+                nflop = sum(b for _, b, _, _ in ls)
+                nrows = sum(r for _, _, r, _ in ls)
+                ach = nflop / dur / 1e12
+                kernels[fam] = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                                "kernel": ls[0][3], "flops_per_row": nflop / nrows, "launches": len(ls),
+                                "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
+                                "total_ms_per_step": 1e3 * dur / args.steps,
+                                "note": {"fwd": "tg_mlp_f32_forward_backward: forward + loss head + backward-data pass of every row in one launch; "
+                                                "flops = matrix-core products only (first layer + 2 x the H x H layers; the <= 4-output head runs on the vector unit)",
+                                         "dw": "tg_mlp_f32_weight_grad: every weight / bias gradient of the net in one launch; flops = the H x H layers' "
+                                               "and the first layer's (padded to 32 columns) products; head and bias sums on the vector unit"}.get(fam)}
+                continue
             dur = sum(d for d, _, _, _ in ls) * 1e-3
             nbytes = sum(b for _, b, _, _ in ls)
             nrows = sum(r for _, _, r, _ in ls)

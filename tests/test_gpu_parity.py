@@ -658,7 +658,11 @@ def test_gemm_mlp_matches_autograd(tg, dev, cd, dims):
             head = n.startswith(f"network.{2 * len(hidden)}.")
             assert rel <= (5e-6 if head else 3e-3), (n, rel)
     pad = m.forward(m.prepare_input(X), keep=False, padded=True)
-    assert pad.shape[1] % 4 == 0 and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
+    # (an fp32 net of the chain learner's shapes runs its no-grad pass on tg_mlp_f32_forward, its keep=True pass on the per-layer
+    # GEMMs: same values to fp32 rounding, not the same bits)
+    same = torch.equal(pad[:, :A].contiguous(), out) if m._f32 is None else \
+        float((pad[:, :A] - out).abs().max()) <= 2e-6 * float(out.abs().max())
+    assert pad.shape[1] % 4 == 0 and same and torch.all(pad[:, A:] == 0)
     assert not tg.mlp.supports(tg.NeuralNetwork(S, A, hidden, "Tanh"))
 
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# per-kernel time of the C2 step (CartPole GRPO, 4,096 envs, fp32 5-128-128-1): rocprofv3 kernel trace of bench.py --config c2
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/r03
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/c2prof
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c2prof -- python3 $R/bench.py --config c2 --steps 20 --warmup 5 > $OUT/bench_c2_under_rocprof.json 2> $OUT/bench_c2_under_rocprof.err
+cp $(find /tmp/c2prof -name "*kernel_stats.csv" | head -1) $OUT/bench_c2_kernel_stats.csv
+head -25 $OUT/bench_c2_kernel_stats.csv | cut -c1-220

@@ -20,7 +20,16 @@
 // Weights: the first layer, biases and head stay in LDS; the H x H layers stream L2 -> registers -> LDS in 32-feature blocks
 // (H/2 MFMA steps x 64 lanes x 4 B = 16 KiB at H = 128) through two buffers, one plain workgroup barrier per block: a block is
 // 64 MFMAs x 64 cycles per wave, so nothing about the staging needs to be clever.
+#include <stdlib.h>
+
 #include "tg_common.hpp"
+
+#ifndef TG_F32DW_STAMPS
+#define TG_F32DW_STAMPS 0          /* diagnostic build: s_memtime stamps around the phases of the wide job's stage loop (never in the product) */
+#endif
+#ifndef TG_F32DW_ABLATE
+#define TG_F32DW_ABLATE 0          /* timing-only probe builds of the wide weight-gradient job: 1 = no products, 2 = no stream */
+#endif
 
 namespace tg {
 
@@ -129,12 +138,20 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     __syncthreads();
     // a block's life: BEGIN hands the next block (in registers since the previous BEGIN) to the idle buffer and requests the one
     // after; the products read `cur`; END is the workgroup barrier that retires `cur` and publishes the buffer just written
+    // The stores of a hidden tile are DEFERRED to the next block's BEGIN, in front of that block's stream loads: vector-memory
+    // operations retire in order, so the wait for those loads (one block later) then implies stores that have had a whole block
+    // to complete, instead of stores issued a moment ago (+25 % on the kernel when each block waited for its own stores).
 #define TG_F32_BLOCK_BEGIN              \
     write_block(buf ^ 1);               \
+    flush_store();                      \
     load_block();                       \
     const uint4* cur = ring + buf * BLK;
-#define TG_F32_BLOCK_END                \
-    __syncthreads();                    \
+    // (not __syncthreads(): its fence would also wait for the activation / dZ stores issued a moment ago -- a memory round trip
+    // per block; the barrier only orders LDS traffic: this wave's ring writes have landed, everyone's reads of `cur` are done)
+#define TG_F32_BLOCK_END                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();                               \
+    asm volatile("" ::: "memory");                              \
     buf ^= 1;
 
     // one 32-feature output tile against a whole H-wide operand: H / 2 MFMA steps; step (mt, t) multiplies the block's k pair
@@ -165,10 +182,24 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     auto bits_slot = [&](int layer, int word) { return bits_s + ((layer * 8 + wave) * (MT / 2) + word) * 64 + lane; };
 
     double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
+    f32x16 pend_v = {};
+    float* pend_g = nullptr;                            // (wave-uniform) destination of the deferred tile, or null
+    int pend_mt = 0;
+    int64_t pend_row = 0;
+    bool pend_valid = false;
+    auto flush_store = [&]() {
+        if (pend_g != nullptr) {
+            if (pend_valid) store_tile<H>(pend_g, pend_row, pend_mt, h, pend_v);
+            pend_g = nullptr;
+        }
+    };
 
     for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
         const int64_t row = round * 256 + wave * 32 + j;
         const bool valid = row < rows;
+        auto defer_store = [&](float* g, int mt, const f32x16& v) {
+            pend_g = g; pend_mt = mt; pend_v = v; pend_row = row; pend_valid = valid;
+        };
         const int64_t rowc = valid ? row : rows - 1;
         f32x16 xin[MT], xout[MT];
 
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
                 xout[mo] = acc;
                 if constexpr (kTrain) {
                     if (mo & 1) *bits_slot(l, mo >> 1) |= m << 16; else *bits_slot(l, mo >> 1) = m;
-                    if (valid) store_tile<H>(a.acts[l], row, mo, h, acc);
+                    defer_store(a.acts[l], mo, acc);
                 }
                 TG_F32_BLOCK_END
             }
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = (mw >> r) & 1u ? acc[r] : 0.f;
                     xout[ko] = acc;
-                    if (valid) store_tile<H>(a.dz[l - 1], row, ko, h, acc);
+                    defer_store(a.dz[l - 1], ko, acc);
                     TG_F32_BLOCK_END
                 }
 #pragma unroll
@@ -320,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
             }
         }
     }
+    if constexpr (kTrain) flush_store();
 #undef TG_F32_BLOCK_BEGIN
 #undef TG_F32_BLOCK_END
     if constexpr (kTrain) {
@@ -387,13 +419,55 @@ struct F32DwJob {
 };
 struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 
+// Stages flow HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no staging registers) through a ring of kSlots slots with
+// kSlots - 1 stages in flight, counted `s_waitcnt vmcnt` + ONE raw `s_barrier` per stage (mfma_ring.hpp's discipline: every
+// wave issues the same number of DMA instructions per stage -- stages past the end re-read the last row, whose products are
+// masked -- and every LDS read in the loop goes through a `__restrict__` helper, or hipcc drains the ring before it).
+//   wide job (H x H layer): stage = SRW rows of P and of Q (16 KiB), 4 slots;
+//   light job (first layer: P = dZ_0, narrow Q = the input rows; head: wide Q = the top activation, narrow P = d loss / d
+//   output): stage = SRL rows of the wide operand (16 KiB) + the narrow operand as a zero-padded [SRL][32] image (4-8 KiB), 3 slots.
+__device__ uint4 g_f32_zero16;
+#if TG_F32DW_STAMPS
+__device__ unsigned long long g_f32_stamps[4096 * 4];      // per wave: cycles in [wait + bias][arrive][products + reads], stages
+#endif                             // 16 zero bytes: the source of an image's padding lanes
+
+typedef __attribute__((address_space(3))) void f32_lds_void;
+__device__ static inline float lds_f(const float* __restrict__ p) { return *p; }
+__device__ static inline float4 lds_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int H>
+struct F32DwGeom {
+    static constexpr int SRW = H == 128 ? 16 : 32;          // rows per stage of a wide job (P + Q = 16 KiB)
+    static constexpr int SRL = H == 128 ? 32 : 64;          // rows per stage of a light job (wide operand = 16 KiB)
+    static constexpr int LPR = H / 4;                       // lanes (16 B each) per wide row
+    static constexpr int RPP = 64 / LPR;                    // wide rows per 1-KiB piece
+    static constexpr int WIDE_SLOT = 16384, LIGHT_SLOT = 16384 + SRL * 128;
+    static constexpr int WIDE_SLOTS = 4, LIGHT_SLOTS = 3;
+    static constexpr int NG_WIDE = 4, NG_LIGHT = 4 + SRL / 32;      // DMA instructions per wave and stage
+    static constexpr int LDS_BYTES = WIDE_SLOT * WIDE_SLOTS > LIGHT_SLOT * LIGHT_SLOTS ? WIDE_SLOT * WIDE_SLOTS : LIGHT_SLOT * LIGHT_SLOTS;
+};
+
+// `rows_in` rows x H floats from `g` (row-major) starting at row r0 into a linear LDS panel: this wave's 4 pieces of the 16
+template <int H>
+__device__ static inline void f32_dma_wide(const float* __restrict__ g, int64_t r0, int64_t rows, char* panel, int first_piece,
+                                           int wave, int lane) {
+    using G = F32DwGeom<H>;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int piece = first_piece + 2 * wave + t;       // 8 pieces per 8-KiB half: waves take 2 each
+        int64_t r = r0 + (int64_t)(piece - first_piece) * G::RPP + lane / G::LPR;
+        r = r < rows ? r : rows - 1;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g + r * H) + lane % G::LPR, (f32_lds_void*)(panel + piece * 1024), 16, 0, 0);
+    }
+}
+
 template <int H>
 __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int64_t rows, float* __restrict__ ws) {
+    using G = F32DwGeom<H>;
     constexpr int MT = H / 32;
     constexpr int TW = MT >= 4 ? 2 : 1;                 // a wave's block of output tiles is TW x TW (H = 128: 2 x 2; H = 64: 1 x 1)
-    constexpr int PF4 = 32 * H / 4 / 256;               // float4 per thread and wide panel (4 at H = 128, 2 at H = 64)
     extern __shared__ uint4 lds[];
-    float* panel = reinterpret_cast<float*>(lds);       // [2 buffers][P panel 32 x H | Q panel 32 x H]
+    char* lds_c = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     int jb = 0;
@@ -402,112 +476,243 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         if (t < args.n_jobs && (int)blockIdx.x >= args.job[t].first_block) jb = t;
     const F32DwJob job = args.job[jb];
     const int my = (int)blockIdx.x - job.first_block, nb = job.n_blocks;
-    const int64_t n_st = (rows + 31) / 32;
     const bool head = job.kind == F32DW_HEAD;
     const int N = job.n;                                // Q columns
     const bool narrow = !head && N <= 32;               // first-layer job: Q = the padded input rows
-
-    // ---- staging: registers one stage ahead ----
-    float4 sp[PF4], sq[PF4];
-    auto fetch = [&](int64_t sg) {
-        const int64_t r0 = sg * 32;
-#pragma unroll
-        for (int t = 0; t < PF4; ++t) {
-            const int e = t * 256 + tid;                // float4 index within a [32][H] panel
-            const int r = e / (H / 4), c4 = e % (H / 4);
-            const bool ok = r0 + r < rows;
-            sp[t] = float4{0.f, 0.f, 0.f, 0.f};
-            sq[t] = float4{0.f, 0.f, 0.f, 0.f};
-            if (head) {
-                if (e < 32 && r0 + e < rows) sp[t] = *reinterpret_cast<const float4*>(job.p + (r0 + e) * 4);       // g rows: 32 float4
-            } else if (ok) {
-                sp[t] = *reinterpret_cast<const float4*>(job.p + (r0 + r) * H + 4 * c4);
-            }
-            if (narrow) {
-                const int rn = e / 8, cn = e % 8;       // Q image [32][32]: 8 float4 per row, zero beyond N
-                if (e < 256 && r0 + rn < rows && 4 * cn < N) sq[t] = *reinterpret_cast<const float4*>(job.q + (r0 + rn) * N + 4 * cn);
-            } else if (ok) {
-                sq[t] = *reinterpret_cast<const float4*>(job.q + (r0 + r) * H + 4 * c4);
-            }
-        }
-    };
-    auto commit = [&](int b) {
-        float* P = panel + b * (2 * 32 * H);
-        float* Q = P + 32 * H;
-#pragma unroll
-        for (int t = 0; t < PF4; ++t) {
-            const int e = t * 256 + tid;
-            if (head) { if (e < 32) *reinterpret_cast<float4*>(P + 4 * e) = sp[t]; }
-            else *reinterpret_cast<float4*>(P + 4 * e) = sp[t];
-            if (narrow) { if (e < 256) *reinterpret_cast<float4*>(Q + 4 * e) = sq[t]; }
-            else *reinterpret_cast<float4*>(Q + 4 * e) = sq[t];
-        }
-    };
-
-    // wave -> output tiles.  wide job: tiles (TW wm + a, TW wn + b); narrow job: m-tile `wave` (waves < MT), one n-tile
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[TW][TW];
 #pragma unroll
     for (int x = 0; x < TW; ++x)
 #pragma unroll
         for (int y = 0; y < TW; ++y) acc[x][y] = f32x16{};
-    float bsum = 0.f;                                   // bias gradient of column `tid` (tid < H); head: of output `tid` (tid < 4)
+    float bsum = 0.f;                                   // bias gradient of one column (see the roles below)
     float hacc[4] = {0.f, 0.f, 0.f, 0.f};               // head: dW_h[a][tid]
 
-    int64_t sg = my;
-    if (sg < n_st) fetch(sg);
-    int b = 0;
-    for (; sg < n_st; sg += nb) {
-        __syncthreads();                                // everyone is done with buffer b (read two stages ago)
-        commit(b);
-        __syncthreads();
-        if (sg + nb < n_st) fetch(sg + nb);
-        const float* P = panel + b * (2 * 32 * H);
-        const float* Q = P + 32 * H;
-        if (head) {
-            if (tid < H) {
-#pragma unroll 8
-                for (int r = 0; r < 32; ++r) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(P + 4 * r);
-                    const float qv = Q[r * H + tid];
-                    hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
-                    hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
+    if (!head && !narrow) {
+        // ================= wide job: dW = P^T Q over H x H, SRW rows per stage =================
+        constexpr int SR = G::SRW, D = G::WIDE_SLOTS, P_ = D - 1, NG = G::NG_WIDE;
+        const int64_t n_st = (rows + SR - 1) / SR;
+        auto issue = [&](int64_t sg, int slot) {
+            char* sb = lds_c + slot * G::WIDE_SLOT;
+            f32_dma_wide<H>(job.p, sg * SR, rows, sb, 0, wave, lane);
+            f32_dma_wide<H>(job.q, sg * SR, rows, sb, 8, wave, lane);
+        };
+        int64_t sg_issue = my;
+        int slot_issue = 0, slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < P_; ++t) {
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        }
+        // Software pipeline over stages: a stage's operands (SR / 2 x 2 TW registers) and bias terms are read from LDS while the
+        // PREVIOUS stage's products run -- an MFMA leaves the wave ~56 issue cycles, and read back to back in front of the
+        // products, wait, barrier, DMA issue and bias sums were 1,350 exposed cycles per 2,048 cycles of products.
+        constexpr int RG = 256 / H, RPG = SR / RG;                          // bias sums: row groups, rows per group
+        const int cb = tid % H, rg = tid / H;
+        float av[SR / 2][TW], bv[SR / 2][TW], an[SR / 2][TW], bn[SR / 2][TW], bt[RPG];
+        auto arrive = [&]() {                                               // the next stage of the ring is complete; refill the freed slot
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P_ - 1) * NG) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#if TG_F32DW_ABLATE != 2                                    /* probe build 2: no stream (the ring keeps its prologue's data) */
+            issue(sg_issue, slot_issue);
+#endif
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        };
+        int64_t sg = my;
+        if (sg < n_st) {
+            arrive();
+            const float* P = reinterpret_cast<const float*>(lds_c + slot * G::WIDE_SLOT);
+            const float* Q = P + SR * H;
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s)
+#pragma unroll
+                for (int x = 0; x < TW; ++x) {
+                    an[s][x] = lds_f(P + (2 * s + kk) * H + 32 * (TW * wm + x) + i);
+                    bn[s][x] = lds_f(Q + (2 * s + kk) * H + 32 * (TW * wn + x) + i);
+                }
+#pragma unroll
+            for (int r = 0; r < RPG; ++r) bt[r] = lds_f(P + (rg * RPG + r) * H + cb);
+            slot = slot + 1 == D ? 0 : slot + 1;
+        }
+#if TG_F32DW_STAMPS
+        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0;
+#endif
+#pragma unroll 1
+        for (; sg < n_st; sg += nb) {
+            const int64_t r0 = sg * SR;
+#if TG_F32DW_STAMPS
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+            // (every read of the previous stage's slot has landed in registers before this wave passes the barrier in arrive())
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const int nr = rows - r0 < SR ? (int)(rows - r0) : SR;
+#pragma unroll
+                for (int r = 0; r < RPG; ++r) bsum += rg * RPG + r < nr ? bt[r] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s) {
+                const bool ok = r0 + 2 * s + kk < rows;             // rows past the end are clamped re-reads: their products are zeroed
+#pragma unroll
+                for (int x = 0; x < TW; ++x) {
+                    av[s][x] = ok ? an[s][x] : 0.f;
+                    bv[s][x] = bn[s][x];
                 }
             }
-            if (tid < 4) {
-                for (int r = 0; r < 32; ++r) bsum += P[4 * r + tid];
-            }
-        } else {
-            if (narrow) {
-                if (wave < MT) {
+            const bool more = sg + nb < n_st;
+#if TG_F32DW_STAMPS
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+            if (more) arrive();
+#if TG_F32DW_STAMPS
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+            const float* P = reinterpret_cast<const float*>(lds_c + slot * G::WIDE_SLOT);
+            const float* Q = P + SR * H;
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const float av = P[(2 * s + kk) * H + 32 * wave + i];
-                        const float bv = Q[(2 * s + kk) * 32 + i];
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
+            for (int s = 0; s < SR / 2; ++s) {
+#pragma unroll
+                for (int x = 0; x < TW; ++x)
+#pragma unroll
+                    for (int y = 0; y < TW; ++y) {
+#if TG_F32DW_ABLATE == 1                                    /* probe build: no products (operands kept live) */
+                        asm volatile("" :: "v"(av[s][x]), "v"(bv[s][y]));
+#else
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][x], bv[s][y], acc[x][y], 0, 0, 0);
+#endif
+                    }
+                if (more) {                                         // the next stage's step-s operands, in the shadow of these products
+#pragma unroll
+                    for (int x = 0; x < TW; ++x) {
+                        an[s][x] = lds_f(P + (2 * s + kk) * H + 32 * (TW * wm + x) + i);
+                        bn[s][x] = lds_f(Q + (2 * s + kk) * H + 32 * (TW * wn + x) + i);
+                    }
+                    if (s < RPG) bt[s] = lds_f(P + (rg * RPG + s) * H + cb);
+                }
+            }
+            static_assert(RPG <= SR / 2, "the bias reads ride on the steps");
+            if (more) slot = slot + 1 == D ? 0 : slot + 1;
+#if TG_F32DW_STAMPS
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_n += 1;
+#endif
+        }
+#if TG_F32DW_STAMPS
+        if (lane == 0 && blockIdx.x < 1024) {
+            unsigned long long* o = g_f32_stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_n;
+        }
+#endif
+    } else {
+        // ================= light job: one wide operand, SRL rows per stage =================
+        constexpr int SR = G::SRL, D = G::LIGHT_SLOTS, P_ = D - 1, NG = G::NG_LIGHT;
+        const int64_t n_st = (rows + SR - 1) / SR;
+        const float* wide = head ? job.q : job.p;       // head: the top activation; first layer: the bottom dZ
+        const float* thin = head ? job.p : job.q;       // head: g [rows][4]; first layer: x [rows][N]
+        const int thin_f4 = head ? 1 : N / 4;           // float4 per row of the narrow operand
+        auto issue = [&](int64_t sg, int slot) {
+            char* sb = lds_c + slot * G::LIGHT_SLOT;
+            const int64_t r0 = sg * SR;
+            f32_dma_wide<H>(wide, r0, rows, sb, 0, wave, lane);
+            f32_dma_wide<H>(wide, r0 + SR / 2, rows, sb, 8, wave, lane);
+            // the narrow operand as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece, SR / 8 pieces
+#pragma unroll
+            for (int t = 0; t < SR / 32; ++t) {
+                const int piece = (SR / 32) * wave + t;
+                int64_t r = r0 + piece * 8 + (lane >> 3);
+                r = r < rows ? r : rows - 1;
+                const int c4 = lane & 7;
+                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : &g_f32_zero16;
+                __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + piece * 1024), 16, 0, 0);
+            }
+        };
+        int64_t sg_issue = my;
+        int slot_issue = 0, slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < P_; ++t) {
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        }
+#pragma unroll 1
+        for (int64_t sg = my; sg < n_st; sg += nb) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P_ - 1) * NG) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+            const float* W = reinterpret_cast<const float*>(lds_c + slot * G::LIGHT_SLOT);
+            const float* T = W + 4096;                  // the narrow image [SR][32]
+            slot = slot + 1 == D ? 0 : slot + 1;
+            const int64_t r0 = sg * SR;
+            const int nr = rows - r0 < SR ? (int)(rows - r0) : SR;
+            if (head) {
+                // thread (column cb, row group rg): fully unrolled, rows past the end carry g = 0 (masked), loads issued together
+                constexpr int RG = 256 / H, RPG = SR / RG;
+                const int cb = tid % H, rg = tid / H;
+#pragma unroll 8
+                for (int r = 0; r < RPG; ++r) {
+                    const int rr = rg * RPG + r;
+                    float4 g4 = lds_f4(T + 32 * rr);
+                    if (rr >= nr) g4 = float4{0.f, 0.f, 0.f, 0.f};
+                    const float qv = lds_f(W + rr * H + cb);
+                    hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
+                    hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
+                    if (cb < 4) {                       // head bias: column sums of g, by the threads whose column index is an output
+                        const float gk = cb == 0 ? g4.x : (cb == 1 ? g4.y : (cb == 2 ? g4.z : g4.w));
+                        bsum += gk;
                     }
                 }
             } else {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    float av[TW], bv[TW];
-#pragma unroll
-                    for (int x = 0; x < TW; ++x) {
-                        av[x] = P[(2 * s + kk) * H + 32 * (TW * wm + x) + i];
-                        bv[x] = Q[(2 * s + kk) * H + 32 * (TW * wn + x) + i];
+                if (wave < MT) {
+#pragma unroll 8
+                    for (int s = 0; s < SR / 2; ++s) {
+                        float av = lds_f(W + (2 * s + kk) * H + 32 * wave + i);
+                        av = 2 * s + kk < nr ? av : 0.f;
+                        const float bv = lds_f(T + (2 * s + kk) * 32 + i);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
                     }
+                }
+                {
+                    constexpr int RG = 256 / H, RPG = SR / RG;
+                    const int cb = tid % H, rg = tid / H;
+                    float v[RPG];
 #pragma unroll
-                    for (int x = 0; x < TW; ++x)
+                    for (int r = 0; r < RPG; ++r) v[r] = lds_f(W + (rg * RPG + r) * H + cb);
 #pragma unroll
-                        for (int y = 0; y < TW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+                    for (int r = 0; r < RPG; ++r) bsum += rg * RPG + r < nr ? v[r] : 0.f;
                 }
             }
-            if (tid < H) {
-#pragma unroll 8
-                for (int r = 0; r < 32; ++r) bsum += P[r * H + tid];
-            }
         }
-        b ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+
+    // ---- the row groups' partial sums (bias, head) meet in LDS and are added in group order ----
+    {
+        constexpr int RG = 256 / H;
+        float* red = reinterpret_cast<float*>(lds_c);                       // [5][256]
+        __syncthreads();
+        red[tid] = bsum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(k + 1) * 256 + tid] = hacc[k];
+        __syncthreads();
+        if (tid < H) {
+            float t = red[tid];
+            float hk[4] = {red[256 + tid], red[512 + tid], red[768 + tid], red[1024 + tid]};
+#pragma unroll
+            for (int g = 1; g < RG; ++g) {
+                t += red[g * H + tid];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hk[k] += red[(k + 1) * 256 + g * H + tid];
+            }
+            bsum = t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hacc[k] = hk[k];
+        }
     }
 
     // ---- this workgroup's slab ----
@@ -517,8 +722,8 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         if (tid < H) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) slab[k * H + tid] = hacc[k];
+            if (tid < 4) slab[4 * H + tid] = bsum;
         }
-        if (tid < 4) slab[4 * H + tid] = bsum;
     } else if (narrow) {
         if (wave < MT) {
 #pragma unroll
@@ -526,50 +731,70 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         }
         if (tid < H) slab[H * 32 + tid] = bsum;
     } else {
-        if (TW == 2 || wave < MT * MT) {
 #pragma unroll
-            for (int x = 0; x < TW; ++x)
+        for (int x = 0; x < TW; ++x)
 #pragma unroll
-                for (int y = 0; y < TW; ++y) {
-                    const int m0 = 32 * (TW * wm + x), n0 = 32 * (TW * wn + y);
+            for (int y = 0; y < TW; ++y) {
+                const int m0 = 32 * (TW * wm + x), n0 = 32 * (TW * wn + y);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[x][y][r];
-                }
-        }
+                for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[x][y][r];
+            }
         if (tid < H) slab[H * H + tid] = bsum;
     }
 }
 
-// grad[m][n] += sum over the job's slabs, in slab order (as dw_finish_all_kernel of mlp_dw.hip)
+// grad[m][n] += sum over the job's slabs, in a fixed order.
 struct F32FinishDesc {
     const float* slab; float* grad; int64_t grad_ld;
     int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
 };
 struct F32FinishArgs { F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total; };
 
+// A workgroup = 32 consecutive output elements x 8 slab chunks: thread (el, c) adds slabs c, c + 8, ... of its element (8 loads in
+// flight), the 8 chunk sums meet in LDS and are added in chunk order: a fixed order whatever the launch, and ~400 slabs of 64 KB
+// are read at memory speed (one thread per element walking all of them was a 100-us chain of dependent loads).
 __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= fa.total) return;
-    int k = 0;
+    __shared__ float part[8][32];
+    const int el = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    float sum = 0.f;
+    float* dst = nullptr;
+    if (e < fa.total) {
+        int k = 0;
 #pragma unroll
-    for (int t = 1; t < 2 * kF32DwMaxJobs; ++t)
-        if (t < fa.n && e >= fa.d[t].first_elem) k = t;
-    const F32FinishDesc d = fa.d[k];
-    const int le = e - d.first_elem;
-    const int m = le / d.n_out, n = le - m * d.n_out;
-    const float* src = d.slab + (int64_t)m * d.N + n;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= d.n_slabs; b += 4) {
-        const float v0 = src[(int64_t)b * d.slab_len], v1 = src[(int64_t)(b + 1) * d.slab_len];
-        const float v2 = src[(int64_t)(b + 2) * d.slab_len], v3 = src[(int64_t)(b + 3) * d.slab_len];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        for (int t = 1; t < 2 * kF32DwMaxJobs; ++t)
+            if (t < fa.n && e >= fa.d[t].first_elem) k = t;
+        const F32FinishDesc d = fa.d[k];
+        const int le = e - d.first_elem;
+        const int m = le / d.n_out, n = le - m * d.n_out;
+        const float* src = d.slab + (int64_t)m * d.N + n;
+        dst = d.grad + (int64_t)m * d.grad_ld + n;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = c;
+        for (; b + 56 < d.n_slabs; b += 64) {               // slabs b, b + 8, ..., b + 56
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 8 * u) * d.slab_len];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += v[u];
+        }
+        for (; b < d.n_slabs; b += 8) s[0] += src[(int64_t)b * d.slab_len];
+        sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
-    for (; b < d.n_slabs; ++b) s0 += src[(int64_t)b * d.slab_len];
-    d.grad[(int64_t)m * d.grad_ld + n] += (s0 + s1) + (s2 + s3);
+    part[c][el] = sum;
+    __syncthreads();
+    if (c == 0 && dst) {
+        float t = part[0][el];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += part[u][el];
+        *dst += t;
+    }
 }
 
-static int f32_dw_max_blocks() { return 2 * device_cus(); }
+static int f32_dw_max_blocks() {
+    static const int forced = [] { const char* e = getenv("TG_F32DW_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning knob (<= 2 per CU)
+    return forced > 0 && forced <= 2 * device_cus() ? forced : 2 * device_cus();
+}
 static int f32_dw_slab_len(int H, int kind, int n) { return kind == F32DW_HEAD ? 4 * H + 4 : (n <= 32 ? H * 32 + H : H * H + H); }
 
 }  // namespace tg
@@ -652,6 +877,12 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
     return hidden == 128 ? launch_f32_chain<128, true>(a, st) : launch_f32_chain<64, true>(a, st);
 }
 
+#if TG_F32DW_STAMPS
+int tg_debug_f32_stamps(unsigned long long* host_out) {    /* diagnostic builds only: not part of the ABI */
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
     if (hidden != 64 && hidden != 128) return 0;
     return (int64_t)f32_dw_max_blocks() * (hidden * hidden + hidden) * (int64_t)sizeof(float);
@@ -666,28 +897,45 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
     TG_REQUIRE(workspace_bytes >= tg_mlp_f32_weight_grad_workspace(hidden), "tg_mlp_f32_weight_grad: workspace of %lld B is smaller than %lld B",
                (long long)workspace_bytes, (long long)tg_mlp_f32_weight_grad_workspace(hidden));
     if (rows == 0) return TG_OK;
-    const int H = hidden, MT = H / 32;
-    int64_t cost[kF32DwMaxJobs], csum = 0;
+    const int H = hidden;
+    // Workgroup slots: two per CU.  The wide jobs (one H x H layer each) are bound by the fp32 matrix pipe, the light ones (first
+    // layer: 16 products per 64 rows; head: vector arithmetic) by the bytes they stream: the wide jobs share HALF the slots -- one
+    // wide workgroup per CU keeps every SIMD's matrix pipe busy -- and the light jobs share the rest in proportion to their bytes
+    // per row, so that a CU streams a light job beside a wide job's products.
+    int64_t bytes[kF32DwMaxJobs], light_sum = 0;
+    int n_wide = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const tg_f32_dw_job& jb = jobs[j];
         TG_REQUIRE(jb.kind == F32DW_MM || jb.kind == F32DW_HEAD, "tg_mlp_f32_weight_grad: job %d has kind %d", j, jb.kind);
         TG_REQUIRE(jb.d_p && jb.d_q && jb.d_wgrad, "tg_mlp_f32_weight_grad: job %d has a null pointer", j);
         if (jb.kind == F32DW_HEAD) {
             TG_REQUIRE(jb.n_cols == H && jb.m_out >= 1 && jb.m_out <= 4 && jb.n_out == H && jb.wgrad_ld >= H, "tg_mlp_f32_weight_grad: job %d: bad head window", j);
-            cost[j] = 6;                                    // vector arithmetic of two waves: about a third of a tile row of products
+            bytes[j] = 4 * H + 16;
         } else {
             TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
             TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
-            cost[j] = jb.n_cols == H ? (H == 128 ? 64 : 16) : 16;   // MFMAs per wave and stage on the critical wave
+            bytes[j] = jb.n_cols == H ? 0 : 4 * H + 4 * jb.n_cols;
+            n_wide += jb.n_cols == H;
         }
-        csum += cost[j];
+        light_sum += bytes[j];
     }
-    const int64_t n_st = ceil_div(rows, (int64_t)32);
-    const int cap = (int)(n_st < 8 ? 1 : (n_st / 8 > 1 << 20 ? 1 << 20 : n_st / 8));     // at least 8 stages per workgroup
     const int max_blocks = f32_dw_max_blocks();
+    // share of the slots that goes to the wide jobs: in proportion to estimated time per row -- a wide job's products at ~70 % of
+    // the fp32 matrix rate of one workgroup per CU against a light job's bytes at the ~12 GB/s one workgroup streams
+    // (TG_F32DW_WIDE_PCT overrides: a tuning knob, read once)
+    static const int forced_pct = [] { const char* e = getenv("TG_F32DW_WIDE_PCT"); return e ? atoi(e) : 0; }();
+    const double t_wide = n_wide * (H == 128 ? 0.085 : 0.085 / 4), t_light = (double)light_sum / 12000.0;
+    int wide_slots = 0;
+    if (n_wide) {
+        const double share = forced_pct > 0 ? forced_pct / 100.0 : t_wide / (t_wide + t_light);
+        wide_slots = n_wide < n_jobs ? (int)(share * max_blocks + 0.5) : max_blocks;
+        if (wide_slots < n_wide) wide_slots = n_wide;
+        if (wide_slots > max_blocks - (n_jobs - n_wide)) wide_slots = max_blocks - (n_jobs - n_wide);
+    }
+    const int light_slots = max_blocks - wide_slots;
     int alloc[kF32DwMaxJobs], used = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        alloc[j] = (int)(cost[j] * max_blocks / csum);
+        alloc[j] = bytes[j] == 0 ? wide_slots / n_wide : (int)(bytes[j] * light_slots / light_sum);
         if (alloc[j] < 1) alloc[j] = 1;
         used += alloc[j];
     }
@@ -708,6 +956,9 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         F32DwJob& dj = args.job[j];
         dj.p = jb.d_p; dj.q = jb.d_q; dj.kind = jb.kind; dj.n = jb.n_cols;
         dj.first_block = grid;
+        // at least 4 stages per workgroup
+        const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H == 128 ? 16 : 32) : (H == 128 ? 32 : 64)));
+        const int cap = (int)(n_st < 4 ? 1 : (n_st / 4 > 1 << 20 ? 1 << 20 : n_st / 4));
         dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;
         dj.slab_len = f32_dw_slab_len(H, jb.kind, jb.n_cols);
         dj.slab_off = off;
@@ -725,9 +976,8 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
     fa.total = elems;
-    (void)MT;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shmem = (size_t)2 * 2 * 32 * H * sizeof(float);
+    const size_t shmem = H == 128 ? (size_t)F32DwGeom<128>::LDS_BYTES : (size_t)F32DwGeom<64>::LDS_BYTES;
     if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
         static LdsOptIn opt_in;
@@ -740,7 +990,7 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, st, args, rows, (float*)d_workspace);
     }
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad");
-    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(256), 0, st, fa);
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad (finish)");
     return TG_OK;
 }
