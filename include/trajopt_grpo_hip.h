@@ -435,6 +435,22 @@ int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
 int  tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* ---- Optimizer step and derived weight layouts (pipelines: torch.optim.Adam; algorithms/grpo.py:145, ppo.py:183) ----
+ * tg_adam_step: torch.optim.Adam's DEFAULT update (foreach path: no amsgrad, weight decay, maximize, capturable) of n_tensors
+ *   fp32 tensors in one launch, the same fp32 operation sequence per element as torch's kernels (bit-identical results).
+ *   d_table: DEVICE array of n_tensors descriptors (param, grad, exp_avg, exp_avg_sq device pointers; `first` = the running
+ *   element offset of the tensor in the launch's index space, ascending; total = the sum of the sizes).  step = the 1-based
+ *   step number AFTER the increment (torch's state['step']).
+ * tg_gather_streams: dst[j] = master tensor (code[j] >> 24) element (code[j] & 0xFFFFFF), or 0 where code[j] < 0, converted
+ *   to bf16 (is_bf16) or kept f32, for every segment in one launch (d_segments: DEVICE array, `first` as above; the master
+ *   tensors are the `p` pointers of d_table).  Rebuilds every derived weight layout after a step. */
+typedef struct tg_adam_tensor { float* p; const float* g; float* m; float* v; int64_t first; } tg_adam_tensor;
+typedef struct tg_gather_segment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; } tg_gather_segment;
+int  tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
+                  int64_t step, void* stream);
+int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

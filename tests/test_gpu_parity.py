@@ -1656,6 +1656,102 @@ def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind,
 
 
 # --------------------------------------------------------------------------------------------
+# optimizer step + derived weight layouts as two launches (csrc/optim_kernels.hip)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lr,betas,eps", [(3e-4, (0.9, 0.999), 1e-8), (2e-4, (0.8, 0.99), 1e-6)])
+def test_fused_adam_is_bit_identical_to_torch(tg, dev, lr, betas, eps):
+    """optim.FusedAdam (tg_adam_step: one launch on the optimizer's own state tensors) against torch.optim.Adam.step() -- the
+    reference's optimizer (pipelines/*_pipeline_*.py) -- over 10 steps with fresh random gradients: weights, both moments and the
+    step counters BIT-identical, and the state dict loads back into a plain torch Adam."""
+    from trajopt_grpo_amd import optim as O
+    torch.manual_seed(7)
+    pol_a = tg.GaussianActorCritic_NeuralNetwork(20, 4, (256, 256, 256), cov=0.3, device=dev)
+    pol_b = copy.deepcopy(pol_a)
+    opt_a = torch.optim.Adam(pol_a.parameters(), lr=lr, betas=betas, eps=eps)
+    opt_b = torch.optim.Adam(pol_b.parameters(), lr=lr, betas=betas, eps=eps)
+    fused = O.FusedAdam(opt_a)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for it in range(10):
+        for pa, pb in zip(pol_a.parameters(), pol_b.parameters()):
+            g = torch.randn(pa.shape, device=dev, generator=gen) * (10.0 ** float(torch.randint(-6, 2, (1,)).item()))
+            if it == 3:
+                g[g.abs() < 0.5 * g.abs().mean()] = 0.0                      # exact zeros: sqrt(0) + eps paths
+            pa.grad, pb.grad = g.clone(), g.clone()
+        assert fused.step()
+        opt_b.step()
+        for pa, pb in zip(pol_a.parameters(), pol_b.parameters()):
+            assert torch.equal(pa, pb), it
+            sa, sb = opt_a.state[pa], opt_b.state[pb]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), it
+            assert float(sa["step"]) == float(sb["step"]) == it + 1
+    opt_c = torch.optim.Adam(pol_b.parameters(), lr=lr, betas=betas, eps=eps)
+    opt_c.load_state_dict(opt_a.state_dict())                               # the checkpoint format is torch's own
+    # anything but a plain default Adam keeps torch's own step()
+    assert not O.FusedAdam(torch.optim.Adam(pol_a.parameters(), lr=lr, amsgrad=True)).usable()
+    assert not O.FusedAdam(torch.optim.AdamW(pol_a.parameters(), lr=lr)).usable()
+    patched = torch.optim.Adam(pol_a.parameters(), lr=lr)
+    patched.step = lambda *a, **k: None
+    assert not O.FusedAdam(patched).usable()
+
+
+@pytest.mark.parametrize("cdt,hidden", [(torch.bfloat16, (256,) * 5), (torch.bfloat16, (128,) * 3), (None, (128, 128)), (None, (64,) * 4)])
+def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden):
+    """optim.StreamRefresher (tg_gather_streams: every derived weight layout of actor and critic in one launch) leaves exactly the
+    bytes FragmentStream.refresh() / F32ChainStream.refresh() build, and learn() with the fused optimizer step equals learn() with
+    torch's step bit for bit."""
+    from trajopt_grpo_amd import mlp as M, optim as O, algorithms as ALG
+    torch.manual_seed(11)
+    S, A = (20, 4) if cdt is not None else (5, 1)
+    pol = tg.GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
+    opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+    for p in pol.parameters():
+        p.grad = torch.randn_like(p) * 1e-3
+    mlps = [M.GemmMLP(pol.actor, cdt or torch.float32), M.GemmMLP(pol.critic, cdt or torch.float32)]
+    fused = O.FusedAdam(opt)
+    assert fused.step()
+    ref = O.StreamRefresher(fused, mlps)
+    for m in mlps:
+        m.refresh()
+    assert ref.run()
+    got = []
+    for m in mlps:
+        for name in ("_chain", "_bchain", "_f32"):
+            st = getattr(m, name)
+            if st is not None:
+                assert name[1:] not in m._stale
+                got.append((st, st.stream.clone(), st.bias.clone() if hasattr(st, "bias") else None))
+    assert got
+    for st, stream, bias in got:
+        st.stream.zero_()
+        st.refresh()
+        assert torch.equal(st.stream, stream)
+        if bias is not None and not getattr(st, "transposed", False):
+            assert torch.equal(st.bias, bias)
+
+    def learn(fused_flag):
+        torch.manual_seed(5)
+        pol2 = tg.GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
+        env = (lambda: tg.QuadPole(max_steps=16)) if S == 20 else (lambda: tg.CartPole(max_steps=16))
+        mgr = tg.RolloutManager(env, pol2, num_workers=4, num_episodes_per_worker=32, seed=3, compute_dtype=cdt)
+        buf = tg.Rollout_Buffer(mgr)
+        buf.sample()
+        old = ALG._FUSED_ADAM
+        ALG._FUSED_ADAM = fused_flag
+        try:
+            algo = tg.PPO(epsilon=0.2, policy=pol2, optimizer=torch.optim.Adam(pol2.parameters(), lr=3e-4), ref_model=None,
+                          updates_per_iter=3, gamma=0.99, batch_size=None, autocast_dtype=cdt)
+            algo.learn(buf)
+            assert bool(algo._fused_adam) == fused_flag
+        finally:
+            ALG._FUSED_ADAM = old
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in pol2.parameters()], algo.last_stats["total_loss"]
+
+    (wa, la), (wb, lb) = learn(True), learn(False)
+    assert la == lb and all(torch.equal(a, b) for a, b in zip(wa, wb))
+
+
+# --------------------------------------------------------------------------------------------
 # the fp32 chain learner (csrc/mlp_f32_chain.hip): the reference's own precision and net sizes
 # --------------------------------------------------------------------------------------------
 F32_SHAPES = [(5, 1, (128, 128)), (20, 4, (128,) * 4), (10, 2, (64,)), (5, 1, (64, 64, 64)), (32, 4, (128, 128, 128)), (3, 1, (128,))]

@@ -128,6 +128,8 @@ SIGNATURES = {
                                               C.POINTER(ChainLoss), _VP]),
     "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP]),
+    "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _VP]),
+    "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
 }
 
 _lib = None

@@ -27,7 +27,11 @@ import torch
 from . import distributed as D
 from . import hip_ops as K
 from . import mlp as M
+from . import optim as O
 from .rollout import DeviceTrajectory
+
+
+_FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
 
 
 class Algorithm(ABC):
@@ -88,6 +92,8 @@ class _GpuLearner(Algorithm):
         self.process_group = process_group
         self.fused_mlp = fused_mlp
         self._bucket = None
+        self._fused_adam = None
+        self._refresher = None
         self._mlps = {}
         self._ws = M._Workspace()       # per-iteration tensors whose size follows the number of valid rows
         self.last_stats = {}
@@ -123,6 +129,22 @@ class _GpuLearner(Algorithm):
             m = self._mlp(net)
             if m is not None:
                 m.refresh()
+
+    def _optimizer_step(self, *nets):
+        """`optimizer.step()` (grpo.py:145, ppo.py:183) and the refresh of every weight layout derived from `nets`.  A plain default
+        torch.optim.Adam takes ONE launch on its own state tensors (optim.FusedAdam: bit-identical to torch's ~8) and one gather
+        rebuilds all layouts; anything else -- hooks, a patched step, another optimizer -- runs as written, layouts refreshed lazily."""
+        if self._fused_adam is None:
+            self._fused_adam = O.FusedAdam(self.optimizer) if _FUSED_ADAM else False
+        stepped = bool(self._fused_adam) and self._fused_adam.step()
+        if not stepped:
+            self.optimizer.step()
+        self._refresh(*nets)
+        if stepped:
+            key = tuple(id(n) for n in nets)
+            if self._refresher is None or self._refresher[0] != key:
+                self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets]))
+            self._refresher[1].run()
 
     def _prep(self, net, X, cap_rows=0):
         m = self._mlp(net)
@@ -224,8 +246,7 @@ class GRPO(_GpuLearner):
                     self._backward(actor, mean, g_mean)
                 sums += s
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
-            self.optimizer.step()
-            self._refresh(actor)
+            self._optimizer_step(actor)
             Js.append(sums)
         self.old_policy.load_state_dict(self.policy.state_dict())           # grpo.py:148
         if Js:
@@ -299,8 +320,7 @@ class PPO(_GpuLearner):
             self._backward(critic, vout, g_val.view_as(vout))
             sums += s
         self.bucket.allreduce(self.process_group)                            # one RCCL all-reduce / step
-        self.optimizer.step()
-        self._refresh(actor, critic)
+        self._optimizer_step(actor, critic)
         sums_out.append(sums)
 
     def _learn(self, buffer) -> None:

@@ -1,0 +1,102 @@
+// One launch per optimizer step, one more for every derived weight layout -- instead of torch.optim.Adam's ~8 multi-tensor
+// launches plus cat / gather / convert per weight stream (pipelines/*: `torch.optim.Adam(policy.parameters(), lr=...)`,
+// algorithms/grpo.py:145 / ppo.py:183 `optimizer.step()`): at C2's 0.45 ms per update those ~20 small launches were a fifth of
+// the step.
+//
+//   tg_adam_step      torch.optim.Adam's default (foreach, non-capturable, no amsgrad / weight decay / maximize) update of up to 64
+//                     tensors in one launch, the SAME fp32 operation sequence per element -- lerp, mul, addcmul, sqrt, div, add,
+//                     addcdiv, each rounded where torch's separate kernels round -- so the weights stay bit-identical to
+//                     `optimizer.step()` (tests/test_gpu_parity.py::test_fused_adam_is_bit_identical_to_torch);
+//   tg_gather_streams every derived layout of the weights (the chain kernels' bf16 fragment streams and f32 bias tables, the fp32
+//                     chain stream) rebuilt from the fp32 masters by one gather: element j of segment s = master
+//                     tensor (code >> 24), offset (code & 0xFFFFFF), or zero.
+#include "tg_common.hpp"
+
+namespace tg {
+
+struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t first; };   // first = index of element 0 in the launch
+constexpr int kAdamMaxTensors = 64;
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total,
+                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size) {
+#pragma clang fp contract(off)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int k = 0;
+    for (int t = 1; t < n_tensors; ++t)
+        if (e >= table[t].first) k = t;
+    const AdamTensor d = table[k];
+    const int64_t i = e - d.first;
+    const float g = d.g[i];
+    float m = d.m[i], v = d.v[i], p = d.p[i];
+    // torch._foreach_lerp_(exp_avg, grad, 1 - beta1): weight < 0.5 -> self + weight * (end - self), the product fused into the sum
+    m = fmaf(w1, g - m, m);
+    // torch._foreach_mul_(exp_avg_sq, beta2); torch._foreach_addcmul_(exp_avg_sq, grad, grad, 1 - beta2): self + value * t1 * t2
+    // (measured against torch 2.10's kernels on gfx950: the square is rounded, then value * square is fused into the sum)
+    v = v * beta2;
+    v = fmaf(w2, g * g, v);
+    // sqrt -> / sqrt(bias_correction2) -> + eps: three kernels in torch, three roundings here.  The divisor comes in as a LIST of
+    // scalars (one per tensor): that overload divides (a / float(b)); the single-scalar overload would multiply by float(1 / b)
+    float s = sqrtf(v);
+    s = s / bc2_sqrt;
+    s = s + eps;
+    // torch._foreach_addcdiv_(param, exp_avg, denom, step_size): self + value * (t1 / t2)
+    p = fmaf(step_size, m / s, p);
+    d.m[i] = m; d.v[i] = v; d.p[i] = p;
+}
+
+struct GatherSegment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; };
+constexpr int kGatherMaxSegments = 32;
+
+__global__ __launch_bounds__(256) void gather_streams_kernel(const GatherSegment* __restrict__ seg, int32_t n_seg, int64_t total,
+                                                             const AdamTensor* __restrict__ table) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int k = 0;
+    for (int t = 1; t < n_seg; ++t)
+        if (e >= seg[t].first) k = t;
+    const GatherSegment s = seg[k];
+    const int64_t j = e - s.first;
+    const int32_t c = s.code[j];
+    const float v = c < 0 ? 0.0f : table[c >> 24].p[c & 0xFFFFFF];
+    if (s.is_bf16) reinterpret_cast<__bf16*>(s.dst)[j] = (__bf16)v;
+    else reinterpret_cast<float*>(s.dst)[j] = v;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
+                 int64_t step, void* stream) {
+    TG_REQUIRE(d_table, "tg_adam_step: null table");
+    TG_REQUIRE(n_tensors >= 1 && n_tensors <= kAdamMaxTensors, "tg_adam_step: %d tensors outside 1..%d", n_tensors, kAdamMaxTensors);
+    TG_REQUIRE(total >= 0 && step >= 1, "tg_adam_step: bad sizes (total %lld, step %lld)", (long long)total, (long long)step);
+    TG_REQUIRE(1.0 - beta1 < 0.5, "tg_adam_step: beta1 = %g: lerp's other branch (weight >= 0.5) is not implemented", beta1);
+    if (total == 0) return TG_OK;
+    // the scalars exactly as torch/optim/adam.py::_multi_tensor_adam forms them (Python doubles, cast to float by the kernels)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = (lr / bc1) * -1.0, bc2_sqrt = pow(bc2, 0.5);
+    static_assert(sizeof(tg_adam_tensor) == sizeof(AdamTensor), "ABI struct and kernel struct must agree");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)bc2_sqrt, (float)eps, (float)step_size);
+    TG_LAUNCH_CHECK("tg_adam_step");
+    return TG_OK;
+}
+
+int tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table, void* stream) {
+    TG_REQUIRE(d_segments && d_table, "tg_gather_streams: null pointer");
+    TG_REQUIRE(n_segments >= 1 && n_segments <= kGatherMaxSegments, "tg_gather_streams: %d segments outside 1..%d", n_segments, kGatherMaxSegments);
+    TG_REQUIRE(total >= 0, "tg_gather_streams: negative size");
+    if (total == 0) return TG_OK;
+    static_assert(sizeof(tg_gather_segment) == sizeof(GatherSegment), "ABI struct and kernel struct must agree");
+    hipLaunchKernelGGL(gather_streams_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const GatherSegment*>(d_segments), n_segments, total, reinterpret_cast<const AdamTensor*>(d_table));
+    TG_LAUNCH_CHECK("tg_gather_streams");
+    return TG_OK;
+}
+
+}  // extern "C"

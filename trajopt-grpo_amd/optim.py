@@ -1,0 +1,180 @@
+"""The optimizer step and the derived weight layouts as two HIP launches (csrc/optim_kernels.hip).
+
+The reference builds `torch.optim.Adam(policy.parameters(), lr=...)` in its factories (pipelines/*_pipeline_*.py) and calls
+`optimizer.step()` once per update (algorithms/grpo.py:145, ppo.py:183).  On the GPU that call is ~8 multi-tensor launches, and
+every weight layout the kernels consume (bf16 fragment streams, fp32 chain stream) costs a cat + gather (+ convert) each: ~20 small
+launches per update -- a fifth of C2's step.  `FusedAdam.step()` performs the SAME update on the optimizer's OWN state tensors
+(so `optimizer.state_dict()` / `optimizer.pt` stay what torch writes) with bit-identical results; `StreamRefresher.run()`
+rebuilds all layouts of all nets in one gather.
+
+Nothing here changes semantics: anything other than a plain default `torch.optim.Adam` (hooks, a patched `step`, amsgrad,
+weight decay, ...) keeps torch's own `optimizer.step()` and the per-stream refresh.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+
+
+class FusedAdam:
+    """tg_adam_step on the state of an existing torch.optim.Adam.  `usable()` is re-checked at every step."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+        self._sig = None
+        self._tables = None          # per param group: (device int64 [T][5] table, n_tensors, total elements)
+        self.tensor_ids = {}         # id(param) -> (group index, tensor index in the group's table)
+
+    @staticmethod
+    def _plain_adam(opt) -> bool:
+        if type(opt) is not torch.optim.Adam or "step" in opt.__dict__:                  # a patched instance (tests, LR schedulers)
+            return False
+        if opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks:
+            return False
+        from torch.optim import optimizer as _o
+        if getattr(_o, "_global_optimizer_pre_hooks", None) or getattr(_o, "_global_optimizer_post_hooks", None):
+            return False
+        return True
+
+    def usable(self) -> bool:
+        opt = self.opt
+        if not self._plain_adam(opt):
+            return False
+        for g in opt.param_groups:
+            if g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+                return False
+            if g.get("fused") or g.get("foreach") is False or g.get("decoupled_weight_decay"):
+                return False
+            if not isinstance(g["lr"], float) or not all(isinstance(b, float) for b in g["betas"]) or 1.0 - g["betas"][0] >= 0.5:
+                return False
+            if not g["params"] or len(g["params"]) > 64:
+                return False
+            for p in g["params"]:
+                if (p.grad is None or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32
+                        or not p.grad.is_contiguous() or p.grad.is_sparse or p.numel() >= 1 << 24):
+                    return False
+        return True
+
+    def _init_state(self):
+        """State as torch.optim.Adam._init_group creates it on the first step (CPU float32 step counter, zero moments)."""
+        for g in self.opt.param_groups:
+            for p in g["params"]:
+                st = self.opt.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _build(self):
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.opt.state[p]["exp_avg"].data_ptr(), self.opt.state[p]["exp_avg_sq"].data_ptr())
+                    for g in self.opt.param_groups for p in g["params"])
+        if sig == self._sig:
+            return
+        self._sig, self._tables, self.tensor_ids = sig, [], {}
+        for gi, g in enumerate(self.opt.param_groups):
+            rows, first = [], 0
+            for ti, p in enumerate(g["params"]):
+                st = self.opt.state[p]
+                assert st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].dtype == torch.float32
+                rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), first])
+                self.tensor_ids[id(p)] = (gi, ti)
+                first += p.numel()
+            dev = g["params"][0].device
+            self._tables.append((torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first))
+
+    def table(self, group: int = 0):
+        return self._tables[group]
+
+    @torch.no_grad()
+    def step(self) -> bool:
+        """One optimizer step; False (nothing done) when the fused form does not apply -- the caller then runs optimizer.step()."""
+        if not self.usable():
+            return False
+        self._init_state()
+        for g in self.opt.param_groups:
+            steps = {float(self.opt.state[p]["step"]) for p in g["params"]}
+            if len(steps) != 1 or not isinstance(self.opt.state[g["params"][0]]["step"], torch.Tensor) or self.opt.state[g["params"][0]]["step"].is_cuda:
+                return False
+        self._build()
+        lib = N.load()
+        for (tab, n, total), g in zip(self._tables, self.opt.param_groups):
+            for p in g["params"]:
+                self.opt.state[p]["step"] += 1
+            step = int(self.opt.state[g["params"][0]]["step"])
+            dev = g["params"][0].device
+            with torch.cuda.device(dev):
+                N.check(lib.tg_adam_step(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
+                                         N.stream_ptr(dev)), "tg_adam_step")
+        return True
+
+
+class StreamRefresher:
+    """All derived weight layouts of a set of GemmMLPs rebuilt from the fp32 masters in ONE launch (tg_gather_streams).  Built
+    against a FusedAdam's tensor table (the masters' pointers); rebuilt when that table changes."""
+
+    def __init__(self, adam: FusedAdam, mlps):
+        self.adam, self.mlps = adam, [m for m in mlps if m is not None]
+        self._sig = None
+        self._seg = None
+
+    def _codes(self, stream_obj, group):
+        """int32 code per element of `stream_obj._idx` (FragmentStream / F32ChainStream): master tensor << 24 | offset, -1 = zero."""
+        lin = stream_obj.lin
+        parts = []
+        for l in lin:
+            gi, ti = self.adam.tensor_ids[id(l.weight)]
+            assert gi == group
+            parts.append((ti << 24) + torch.arange(l.weight.numel(), dtype=torch.int64))
+        for l in lin:
+            gi, ti = self.adam.tensor_ids[id(l.bias)]
+            assert gi == group
+            parts.append((ti << 24) + torch.arange(l.bias.numel(), dtype=torch.int64))
+        parts.append(torch.tensor([-1], dtype=torch.int64))
+        src = torch.cat(parts).to(stream_obj._idx.device)
+        return src[stream_obj._idx].to(torch.int32)
+
+    def _build(self):
+        if self.adam._sig == self._sig and self._seg is not None:
+            return True
+        self._sig, self._seg, self._marks = self.adam._sig, None, []
+        segs, keep, first = [], [], 0
+        dev = None
+        for m in self.mlps:
+            streams = []
+            if m._chain is not None:
+                c = self._codes(m._chain, 0)
+                ns = m._chain._n_stream
+                streams += [(m._chain.stream, c[:ns].contiguous(), 1), (m._chain.bias.view(-1), c[ns:].contiguous(), 0)]
+                self._marks.append((m, "chain"))
+            if m._bchain is not None:
+                streams += [(m._bchain.stream, self._codes(m._bchain, 0).contiguous(), 1)]
+                self._marks.append((m, "bchain"))
+            if m._f32 is not None:
+                streams += [(m._f32.stream, self._codes(m._f32, 0).contiguous(), 0)]
+                self._marks.append((m, "f32"))
+            for dst, code, is_bf16 in streams:
+                assert code.numel() == dst.numel() and dst.is_contiguous()
+                segs.append([dst.data_ptr(), code.data_ptr(), first, is_bf16])      # (is_bf16 | pad) share one int64: little endian
+                keep.append(code)
+                first += dst.numel()
+                dev = dst.device
+        if not segs or len(segs) > 32:
+            return False
+        self._seg = (torch.tensor(segs, dtype=torch.int64).to(dev), len(segs), first, keep, dev)
+        return True
+
+    def run(self) -> bool:
+        """Rebuild the layouts (and mark them fresh in their GemmMLP); False when there is nothing this launch covers."""
+        try:
+            if not self._build():
+                return False
+        except (KeyError, AssertionError):
+            return False                                  # a net whose parameters are not in the optimizer's first group
+        seg, n, total, _, dev = self._seg
+        tab, _, _ = self.adam.table(0)
+        with torch.cuda.device(dev):
+            N.check(N.load().tg_gather_streams(seg.data_ptr(), n, total, tab.data_ptr(), N.stream_ptr(dev)), "tg_gather_streams")
+        for m, what in self._marks:
+            m._stale.discard(what)
+        return True
