@@ -23,11 +23,12 @@ Only ReLU hidden activations take this path; anything else stays on torch autogr
 """
 from __future__ import annotations
 
+import logging
+import os
+
 import torch
 
 from . import _native as N
-
-import os
 
 _ROW_BLOCK = 8192
 _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
@@ -35,6 +36,9 @@ _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
 _FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
 _F32_CHAIN = os.environ.get("TG_F32_CHAIN", "1") == "1"       # 0: fp32 nets on the per-layer GEMM path (A/B runs)
 
+
+_LOG = logging.getLogger("trajopt_grpo_amd")
+_LOGGED_SHAPES = set()
 
 # address ranges of the input buffers some GemmMLP.prepare_input() gave a column of ones (a property of the buffer, shared by
 # the nets that read it: the learner's actor and critic take the same prepared input)
@@ -165,7 +169,28 @@ class GemmMLP:
             if H in (128, 256) and self.out_pad == 8 and 3 <= len(self.linears) - 1 <= 6:     # 6: the kernel's LDS budget
                 self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
+        self._log_path(net)
         self.refresh()
+
+    def _log_path(self, net):
+        """One INFO line per net shape (logger `trajopt_grpo_amd`) saying which kernels run it, and a WARNING when a net falls off the
+        hand-written chain kernels onto library GEMMs + per-layer glue (that used to be silent)."""
+        lin = self.linears
+        shape = f"{self.in_dim}-" + "-".join(str(l.out_features) for l in lin[:-1]) + f"-{self.out_dim} {str(self.cd).replace('torch.', '')}"
+        if shape in _LOGGED_SHAPES:
+            return
+        _LOGGED_SHAPES.add(shape)
+        if self._f32 is not None:
+            _LOG.info("%s: fp32 chain learner (tg_mlp_f32_forward / _forward_backward / _weight_grad)", shape)
+        elif self._chain is not None and self._bchain is not None:
+            _LOG.info("%s: bf16 chain kernels (tg_mlp_forward_chain[_loss] / tg_mlp_backward_chain / tg_mlp_weight_grad)", shape)
+        else:
+            why = ("fp32 chain learner: hidden width 64 / 128, 1-4 equal hidden layers, <= 32 inputs, <= 4 outputs"
+                   if self.cd == torch.float32 else
+                   "bf16 chain kernels: hidden width 128 / 256, 3-6 equal hidden layers, <= 32 inputs, <= 8 outputs"
+                   + ("; the forward chain alone covers this net" if self._chain is not None else ""))
+            _LOG.warning("%s is outside the hand-written learner kernels' shapes (%s): its update runs on hipBLASLt GEMMs + per-layer "
+                         "HIP kernels, several times slower per row", shape, why)
 
     def refresh(self):
         """The fp32 master weights changed: every derived operand (padded compute-dtype copies, chain streams, packed
