@@ -64,6 +64,7 @@ struct F32ChainArgs {
     float* acts[kF32MaxHidden];   // kTrain: post-ReLU outputs of the hidden layers, f32 [rows][H]
     float* dz[kF32MaxHidden];     // kTrain: d loss / d pre-activation of the hidden layers, f32 [rows][H]
     float* out;             // !kTrain: head output f32 [rows][4]
+    int32_t resident;       // the whole H x H block stream fits the LDS beside the tables: loaded once, no ring, no block barriers
     F32Loss loss;
 };
 
@@ -93,18 +94,22 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     constexpr int SQ = BLK / 512;               // uint4 per thread and block (2 at H = 128, 1 at H = 64)
     static_assert(BLK % 512 == 0, "a block is a whole number of 16-B pieces per thread");
     extern __shared__ uint4 lds[];
-    uint4* ring = lds;                                              // 2 x BLK
-    uint4* w0s = ring + 2 * BLK;                                    // MT x 4 x 64 (k2 <= 16)
-    float* bias_s = reinterpret_cast<float*>(w0s + MT * 4 * 64);    // kF32MaxHidden x H
-    float* wh_s = bias_s + kF32MaxHidden * H;                       // 4 x H
-    float* bh_s = wh_s + 4 * H;                                     // 4 (+ 12 pad)
-    uint32_t* bits_s = reinterpret_cast<uint32_t*>(bh_s + 16);      // kTrain: [layer][wave][MT / 2 words][64 lanes]: ReLU masks
-    double* red_s = reinterpret_cast<double*>(bits_s + kF32MaxHidden * 8 * (MT / 2 > 0 ? MT / 2 : 1) * 64);   // 8 waves x 4
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const F32Net& net = a.net;
     const int n_hh = net.n_hh, K2 = net.k2;
+    const int n_stream = n_hh * MT * (kTrain ? 2 : 1);              // blocks per round (the same sequence every round)
+    const bool resident = a.resident != 0;
+    // LDS (f32_chain_lds() on the host computes the same sizes): the block ring (2 blocks) or the whole resident stream, the
+    // first layer's fragments, bias / head tables, the ReLU mask bits of the (n_hh + 1) hidden layers, the loss-sum scratch
+    uint4* ring = lds;
+    uint4* w0s = ring + (resident ? n_stream : 2) * BLK;            // MT x (k2 / 4) x 64
+    float* bias_s = reinterpret_cast<float*>(w0s + MT * (K2 / 4) * 64);    // kF32MaxHidden x H
+    float* wh_s = bias_s + kF32MaxHidden * H;                       // 4 x H
+    float* bh_s = wh_s + 4 * H;                                     // 4 (+ 12 pad)
+    uint32_t* bits_s = reinterpret_cast<uint32_t*>(bh_s + 16);      // kTrain: [layer][wave][MT / 2 words][64 lanes]: ReLU masks
+    double* red_s = reinterpret_cast<double*>(bits_s + (n_hh + 1) * 8 * (MT / 2) * 64);   // 8 waves x 4
+
     const int64_t rows = a.rows;
     const int64_t n_rounds = (rows + 255) / 256;
 
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     for (int q = tid; q < 4 * H; q += 512) wh_s[q] = net.wh[q];
     if (tid < 4) bh_s[tid] = net.bh[tid];
 
-    // ---- block stream: two LDS buffers, register staging one block ahead ----
-    const int n_stream = n_hh * MT * (kTrain ? 2 : 1);              // blocks per round (the same sequence every round)
+    // ---- block stream: resident in LDS when it fits (C2's 5-128-128-1: 128 KiB), else two LDS buffers with register staging one
+    // block ahead ----
     static_assert(SQ == 1 || SQ == 2, "one or two 16-B pieces per thread and block");
     uint4 stg0 = {}, stg1 = {};                                     // (named, not an array: hipcc put a 2-element array in scratch)
     int pos = 0, buf = 0;
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
         dst[0] = stg0;
         if constexpr (SQ == 2) dst[512] = stg1;
     };
-    if (n_stream > 0) {
+    if (resident) {
+        for (int q = tid; q < n_stream * BLK; q += 512) ring[q] = net.blocks[q];
+    } else if (n_stream > 0) {
         load_block();
         write_block(0);
         load_block();
@@ -141,18 +148,28 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     // The stores of a hidden tile are DEFERRED to the next block's BEGIN, in front of that block's stream loads: vector-memory
     // operations retire in order, so the wait for those loads (one block later) then implies stores that have had a whole block
     // to complete, instead of stores issued a moment ago (+25 % on the kernel when each block waited for its own stores).
-#define TG_F32_BLOCK_BEGIN              \
-    write_block(buf ^ 1);               \
-    flush_store();                      \
-    load_block();                       \
-    const uint4* cur = ring + buf * BLK;
+    // Resident stream: a block is just an offset -- no staging, no barrier, and the stores need no deferral because nothing in the
+    // loop waits on the vector-memory queue any more (they drain behind the next round's input loads).
+#define TG_F32_BLOCK_BEGIN                                  \
+    const uint4* cur;                                       \
+    if (resident) {                                         \
+        cur = ring + pos * BLK;                             \
+        pos = pos + 1 == n_stream ? 0 : pos + 1;            \
+    } else {                                                \
+        write_block(buf ^ 1);                               \
+        flush_store();                                      \
+        load_block();                                       \
+        cur = ring + buf * BLK;                             \
+    }
     // (not __syncthreads(): its fence would also wait for the activation / dZ stores issued a moment ago -- a memory round trip
     // per block; the barrier only orders LDS traffic: this wave's ring writes have landed, everyone's reads of `cur` are done)
 #define TG_F32_BLOCK_END                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-    __builtin_amdgcn_s_barrier();                               \
-    asm volatile("" ::: "memory");                              \
-    buf ^= 1;
+    if (!resident) {                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+        buf ^= 1;                                               \
+    }
 
     // one 32-feature output tile against a whole H-wide operand: H / 2 MFMA steps; step (mt, t) multiplies the block's k pair
     // F(t, 0 / 1) of input tile mt = register t of the two lane halves
@@ -198,7 +215,11 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
         const int64_t row = round * 256 + wave * 32 + j;
         const bool valid = row < rows;
         auto defer_store = [&](float* g, int mt, const f32x16& v) {
-            pend_g = g; pend_mt = mt; pend_v = v; pend_row = row; pend_valid = valid;
+            if (resident) {
+                if (valid) store_tile<H>(g, row, mt, h, v);
+            } else {
+                pend_g = g; pend_mt = mt; pend_v = v; pend_row = row; pend_valid = valid;
+            }
         };
         const int64_t rowc = valid ? row : rows - 1;
         f32x16 xin[MT], xout[MT];
@@ -377,10 +398,10 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
 }
 
 template <int H>
-static size_t f32_chain_lds() {
+static size_t f32_chain_lds(int n_hh, int k2, int ring_blocks) {
     constexpr int MT = H / 32, BLK = (H / 8) * 64;
-    return (size_t)2 * BLK * 16 + (size_t)MT * 4 * 64 * 16 + (size_t)(kF32MaxHidden * H + 4 * H + 16) * 4 +
-           (size_t)kF32MaxHidden * 8 * (MT / 2) * 64 * 4 + 8 * 4 * 8;
+    return (size_t)ring_blocks * BLK * 16 + (size_t)MT * (k2 / 4) * 64 * 16 + (size_t)(kF32MaxHidden * H + 4 * H + 16) * 4 +
+           (size_t)(n_hh + 1) * 8 * (MT / 2) * 64 * 4 + 8 * 4 * 8;
 }
 
 static int f32_chain_grid(int64_t rows) {
@@ -390,9 +411,13 @@ static int f32_chain_grid(int64_t rows) {
 }
 
 template <int H, bool kTrain>
-static int launch_f32_chain(const F32ChainArgs& args, hipStream_t st) {
+static int launch_f32_chain(const F32ChainArgs& args_in, hipStream_t st) {
     auto kern = mlp_f32_chain_kernel<H, kTrain>;
-    const size_t shmem = f32_chain_lds<H>();
+    F32ChainArgs args = args_in;
+    const int n_stream = args.net.n_hh * (H / 32) * (kTrain ? 2 : 1);
+    static const bool no_resident = getenv("TG_F32_NO_RESIDENT") != nullptr;             // A/B runs
+    args.resident = !no_resident && n_stream > 0 && f32_chain_lds<H>(args.net.n_hh, args.net.k2, n_stream) <= 160 * 1024;
+    const size_t shmem = f32_chain_lds<H>(args.net.n_hh, args.net.k2, args.resident ? n_stream : 2);
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_forward")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)f32_chain_grid(args.rows)), dim3(512), shmem, st, args);
@@ -651,21 +676,18 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
             const int64_t r0 = sg * SR;
             const int nr = rows - r0 < SR ? (int)(rows - r0) : SR;
             if (head) {
-                // thread (column cb, row group rg): fully unrolled, rows past the end carry g = 0 (masked), loads issued together
-                constexpr int RG = 256 / H, RPG = SR / RG;
-                const int cb = tid % H, rg = tid / H;
-#pragma unroll 8
-                for (int r = 0; r < RPG; ++r) {
-                    const int rr = rg * RPG + r;
-                    float4 g4 = lds_f4(T + 32 * rr);
-                    if (rr >= nr) g4 = float4{0.f, 0.f, 0.f, 0.f};
-                    const float qv = lds_f(W + rr * H + cb);
-                    hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
-                    hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
-                    if (cb < 4) {                       // head bias: column sums of g, by the threads whose column index is an output
-                        const float gk = cb == 0 ? g4.x : (cb == 1 ? g4.y : (cb == 2 ? g4.z : g4.w));
-                        bsum += gk;
+                // (one column per thread, a plain loop over the stage's rows: spreading the rows over all 256 threads with the loads
+                // issued together measured SLOWER here -- 167 vs 104 us for 1 M rows: the job is byte-bound, and the extra threads'
+                // LDS traffic competes with the co-resident workgroup)
+                if (tid < H) {
+                    for (int r = 0; r < nr; ++r) {
+                        const float4 g4 = lds_f4(T + 32 * r);
+                        const float qv = lds_f(W + r * H + tid);
+                        hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
+                        hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
                     }
+                } else if (tid < H + 4) {
+                    for (int r = 0; r < nr; ++r) bsum += lds_f(T + 32 * r + (tid - H));
                 }
             } else {
                 if (wave < MT) {
@@ -677,41 +699,26 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
                         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
                     }
                 }
-                {
-                    constexpr int RG = 256 / H, RPG = SR / RG;
-                    const int cb = tid % H, rg = tid / H;
-                    float v[RPG];
-#pragma unroll
-                    for (int r = 0; r < RPG; ++r) v[r] = lds_f(W + (rg * RPG + r) * H + cb);
-#pragma unroll
-                    for (int r = 0; r < RPG; ++r) bsum += rg * RPG + r < nr ? v[r] : 0.f;
+                if (tid >= 256 - H) {                   // (the waves without a tile when H = 64)
+                    for (int r = 0; r < nr; ++r) bsum += lds_f(W + r * H + (tid - (256 - H)));
                 }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 
-    // ---- the row groups' partial sums (bias, head) meet in LDS and are added in group order ----
-    {
+    // ---- the wide job's row groups' partial bias sums meet in LDS and are added in group order ----
+    if (!head && !narrow) {
         constexpr int RG = 256 / H;
-        float* red = reinterpret_cast<float*>(lds_c);                       // [5][256]
+        float* red = reinterpret_cast<float*>(lds_c);                       // [256]
         __syncthreads();
         red[tid] = bsum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) red[(k + 1) * 256 + tid] = hacc[k];
         __syncthreads();
         if (tid < H) {
             float t = red[tid];
-            float hk[4] = {red[256 + tid], red[512 + tid], red[768 + tid], red[1024 + tid]};
 #pragma unroll
-            for (int g = 1; g < RG; ++g) {
-                t += red[g * H + tid];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) hk[k] += red[(k + 1) * 256 + g * H + tid];
-            }
+            for (int g = 1; g < RG; ++g) t += red[g * H + tid];
             bsum = t;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) hacc[k] = hk[k];
         }
     }
 
@@ -722,14 +729,15 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         if (tid < H) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) slab[k * H + tid] = hacc[k];
-            if (tid < 4) slab[4 * H + tid] = bsum;
+        } else if (tid < H + 4) {
+            slab[4 * H + (tid - H)] = bsum;
         }
     } else if (narrow) {
         if (wave < MT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[0][0][r];
         }
-        if (tid < H) slab[H * 32 + tid] = bsum;
+        if (tid >= 256 - H) slab[H * 32 + (tid - (256 - H))] = bsum;
     } else {
 #pragma unroll
         for (int x = 0; x < TW; ++x)
