@@ -1870,6 +1870,59 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
         assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (i, rows)
 
 
+def test_c2_size_grpo_learn_matches_the_oracle(tg, dev):
+    """BASELINE configs[1] at full size on the product path: CartPole GRPO, 4,096 envs (64 groups x 64), fp32 5-128-128-1 -- fused
+    fp32 rollout, fp32 chain learner, fused optimizer step -- against the CPU oracle's GRPO step (algorithms/grpo.py:50-148 restated,
+    pinned by the reference's goldens) on the SAME sampled buffer: objective values of both updates, post-step weights."""
+    torch.manual_seed(21)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+    sd = {n: v.detach().cpu().clone() for n, v in pol.state_dict().items()}
+    ora, old = L.OraclePolicy(5, 1, (128, 128), cov=0.5), L.OraclePolicy(5, 1, (128, 128), cov=0.5)
+    ora.load_state_dict({n: v.clone() for n, v in sd.items()})
+    old.load_state_dict({n: v.clone() for n, v in sd.items()})
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=128), pol, num_workers=64, num_episodes_per_worker=64, seed=9)
+    assert mgr.engine.fused and mgr.engine._fused_f32
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), updates_per_iter=2)
+    algo.learn(buf)
+    m = algo._mlp(pol.actor)
+    assert m._f32 is not None and bool(algo._fused_adam)
+    n_valid = int(buf.device_traj.mask.sum())
+    assert n_valid > 100000 and algo.last_stats["n_valid"] == n_valid
+    torch.set_num_threads(8)
+    Js = L.grpo_learn(ora, old, torch.optim.Adam(ora.parameters(), lr=3e-4), buf.group_observations, buf.group_actions, buf.group_rewards,
+                      buf.group_masks, epsilon=0.15, gamma=0.5, updates_per_iter=2)
+    for a, b in zip(algo.last_stats["J"], Js):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (a, b)
+    for (n, p), q in zip(pol.actor.named_parameters(), ora.parameters()):
+        d = p.detach().cpu() - q.detach()
+        # Adam's normalised step: an entry whose gradient sits at rounding level may move by up to lr per step in either direction
+        assert float(d.abs().max()) <= 2 * 2 * 3e-4 + 1e-6 and float(d.norm() / q.detach().norm()) < 3e-4, n
+
+
+def test_f32_learn_is_independent_of_the_chunk_size(tg, dev):
+    """The learner walks the valid rows in chunks (`chunk_rows`): on the fp32 chain learner several small chunks must give the
+    one-chunk result up to fp32 summation order (loss sums, gradients accumulate across chunks)."""
+    def run(chunk):
+        torch.manual_seed(4)
+        pol = tg.GaussianActorCritic_NeuralNetwork(5, 1, (128, 128, 128), cov=0.4, device=dev)
+        mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=40), pol, num_workers=8, num_episodes_per_worker=32, seed=2)
+        buf = tg.Rollout_Buffer(mgr)
+        buf.sample()
+        algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), ref_model=None, updates_per_iter=2,
+                      gamma=0.99, batch_size=None, chunk_rows=chunk)
+        algo.learn(buf)
+        assert algo._mlp(pol.actor)._f32 is not None
+        return [p.detach().clone() for p in pol.parameters()], algo.last_stats
+
+    (wa, sa), (wb, sb) = run(None), run(1777)
+    for k in ("total_loss", "actor_loss", "critic_loss"):
+        np.testing.assert_allclose(sa[k], sb[k], rtol=1e-5, atol=1e-7)
+    for a, b in zip(wa, wb):
+        assert float((a - b).norm() / a.norm()) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------
 # learn() at the shapes the hot learner kernels run, minibatch PPO, the configs' shard sizes
 # --------------------------------------------------------------------------------------------
