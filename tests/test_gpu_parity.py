@@ -1901,6 +1901,28 @@ def test_c2_size_grpo_learn_matches_the_oracle(tg, dev):
         assert float(d.abs().max()) <= 2 * 2 * 3e-4 + 1e-6 and float(d.norm() / q.detach().norm()) < 3e-4, n
 
 
+def test_ppo_with_more_than_four_actions_keeps_one_prepared_input(tg, dev):
+    """An fp32 actor with > 4 outputs is outside the fp32 chain learner while its 1-output critic is inside: PPO must put both on
+    the per-layer path (they share one padded input) instead of feeding one of them a wrongly padded buffer."""
+    torch.manual_seed(0)
+    pol = tg.GaussianActorCritic_NeuralNetwork(12, 6, (64, 64), cov=0.3, device=dev)
+    algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), ref_model=None, updates_per_iter=1,
+                  batch_size=None)
+    G, E, T = 2, 8, 6
+    g = torch.Generator().manual_seed(1)
+    buf = _Buf()
+    buf.group_observations = torch.randn(G, E, T, 12, generator=g)
+    buf.group_actions = torch.randn(G, E, T, 6, generator=g)
+    buf.group_rewards = torch.randn(G, E, T, generator=g)
+    buf.group_masks = torch.ones(G, E, T)
+    buf.group_lengths = torch.full((G, E), float(T))
+    before = [p.detach().clone() for p in pol.parameters()]
+    algo.learn(buf)
+    m_a, m_c = algo._mlp(pol.actor), algo._mlp(pol.critic)
+    assert m_a._f32 is None and m_c._f32 is None and m_a.in_pad == m_c.in_pad == 32
+    assert all(torch.isfinite(p).all() for p in pol.parameters()) and any(not torch.equal(p, b) for p, b in zip(pol.parameters(), before))
+
+
 def test_f32_learn_is_independent_of_the_chunk_size(tg, dev):
     """The learner walks the valid rows in chunks (`chunk_rows`): on the fp32 chain learner several small chunks must give the
     one-chunk result up to fp32 summation order (loss sums, gradients accumulate across chunks)."""

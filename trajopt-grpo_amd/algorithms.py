@@ -329,6 +329,10 @@ class PPO(_GpuLearner):
         T, n = traj.T, traj.n
         idx, X, act = self._gather_valid(traj)
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
+        m_a, m_c = self._mlp(self.policy.actor), self._mlp(self.policy.critic)
+        if m_a is not None and m_c is not None and m_a.in_pad != m_c.in_pad:
+            m_a.disable_f32_chain()                       # (only one of the two fits the fp32 chain learner: both take the
+            m_c.disable_f32_chain()                       #  per-layer path, so that they keep sharing ONE prepared input)
         self._refresh(self.policy.actor, self.policy.critic)
         xin = self._prep(self.policy.actor, X, traj.T * traj.n)   # actor and critic share input width / compute dtype
         # V on valid rows only; padded rows never reach a result (they are masked in both scans)

@@ -172,6 +172,17 @@ class GemmMLP:
         self._log_path(net)
         self.refresh()
 
+    def disable_f32_chain(self):
+        """Back to the per-layer path with the 32-wide padded input (a learner whose actor and critic would otherwise expect
+        differently padded inputs: e.g. > 4 actions beside a 1-output critic)."""
+        if self._f32 is None:
+            return
+        self._f32 = None
+        self.in_pad = _round_up(self.in_dim, 32)
+        w0 = self.w[0]
+        self.w[0] = torch.zeros(w0.shape[0], self.in_pad, dtype=w0.dtype, device=w0.device)
+        self.refresh()
+
     def _log_path(self, net):
         """One INFO line per net shape (logger `trajopt_grpo_amd`) saying which kernels run it, and a WARNING when a net falls off the
         hand-written chain kernels onto library GEMMs + per-layer glue (that used to be silent)."""
