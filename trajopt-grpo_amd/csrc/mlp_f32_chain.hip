@@ -454,6 +454,7 @@ struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 __device__ uint4 g_f32_zero16;
 #if TG_F32DW_STAMPS
 __device__ unsigned long long g_f32_stamps[4096 * 4];      // per wave: cycles in [wait + bias][arrive][products + reads], stages
+__device__ unsigned long long g_f32_stamps2[4096 * 6];     // per wave: s_memtime at entry / loop start / loop end / exit, s_memrealtime at entry / exit
 #endif                             // 16 zero bytes: the source of an image's padding lanes
 
 typedef __attribute__((address_space(3))) void f32_lds_void;
@@ -493,6 +494,10 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
     constexpr int TW = MT >= 4 ? 2 : 1;                 // a wave's block of output tiles is TW x TW (H = 128: 2 x 2; H = 64: 1 x 1)
     extern __shared__ uint4 lds[];
     char* lds_c = reinterpret_cast<char*>(lds);
+#if TG_F32DW_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_loop0 = 0, st_loop1 = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     int jb = 0;
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         }
 #if TG_F32DW_STAMPS
         unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0;
+        st_loop0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
         for (; sg < n_st; sg += nb) {
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 #endif
         }
 #if TG_F32DW_STAMPS
+        st_loop1 = __builtin_amdgcn_s_memtime();
         if (lane == 0 && blockIdx.x < 1024) {
             unsigned long long* o = g_f32_stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
             o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = st_n;
@@ -749,6 +756,12 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
             }
         if (tid < H) slab[H * H + tid] = bsum;
     }
+#if TG_F32DW_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_f32_stamps2 + ((size_t)blockIdx.x * 4 + wave) * 6;
+        o[0] = st_entry; o[1] = st_loop0; o[2] = st_loop1; o[3] = __builtin_amdgcn_s_memtime(); o[4] = st_rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // grad[m][n] += sum over the job's slabs, in a fixed order.
@@ -888,6 +901,9 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
 #if TG_F32DW_STAMPS
 int tg_debug_f32_stamps(unsigned long long* host_out) {    /* diagnostic builds only: not part of the ABI */
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+int tg_debug_f32_stamps2(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps2), sizeof(unsigned long long) * 4096 * 6) == hipSuccess ? 0 : -1;
 }
 #endif
 
