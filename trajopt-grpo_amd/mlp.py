@@ -200,7 +200,8 @@ class GemmMLP:
                    if self.cd == torch.float32 else
                    "bf16 chain kernels: hidden width 128 / 256, 3-6 equal hidden layers, <= 32 inputs, <= 8 outputs"
                    + ("; the forward chain alone covers this net" if self._chain is not None else ""))
-            _LOG.warning("%s is outside the hand-written learner kernels' shapes (%s): its update runs on hipBLASLt GEMMs + per-layer "
+            log = _LOG.warning if sum(l.weight.numel() for l in lin) >= 4096 else _LOG.info       # (scaffolding-sized nets: not worth a warning)
+            log("%s is outside the hand-written learner kernels' shapes (%s): its update runs on hipBLASLt GEMMs + per-layer "
                          "HIP kernels, several times slower per row", shape, why)
 
     def refresh(self):
