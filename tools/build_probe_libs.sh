@@ -1,0 +1,11 @@
+#!/bin/bash
+# Probe builds of the library (timing-only / diagnostic variants; never the product) into scratch/, selected at run time with
+# TG_NATIVE_LIB=<path>.  tools/mall_window_probe.sh and tools/mall_clocks.sh expect the first four.
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $R/scratch
+build() { make -C $R/trajopt-grpo_amd/csrc -j8 OUT=../../scratch/libtg_$1.so OBJDIR=../../build/obj_$1 EXTRA="$2" 2>&1 | grep -E "error|warning:" ; ls -la $R/scratch/libtg_$1.so; }
+build w64k_plain  "-DTG_PROBE_ROW_WINDOW=65536 -DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_AUX=0"     # update kernels' streams folded into a 64 K-row window
+build w16k_plain  "-DTG_PROBE_ROW_WINDOW=16384 -DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_AUX=0"
+build w64k_nt     "-DTG_PROBE_ROW_WINDOW=65536"                                            # ... with the product's non-temporal policies
+build nowin_plain "-DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_AUX=0"                                 # default cache policies, no window
+build dwstamps    "-DTG_F32DW_STAMPS=1"                                                    # fp32 weight-gradient kernel with s_memtime stamps
