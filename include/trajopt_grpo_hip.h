@@ -411,7 +411,10 @@ int  tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, i
  *   d head output as F32 [rows][4], d_head_slabs / d_bias_partial are not used (the head's gradient is a job of
  *   tg_mlp_f32_weight_grad) and d_work is f64 [tg_mlp_f32_blocks()][4]; the caller adds the first min(blocks, ceil(rows / 256)).
  *   d_acts / d_dz: HOST arrays of n_hidden_layers device pointers, f32 [rows][H] each: the post-ReLU outputs of the hidden layers
- *   and d loss / d their pre-activations (index = layer, 0 = first hidden layer), written for tg_mlp_f32_weight_grad.
+ *   and d loss / d their pre-activations (index = layer, 0 = first hidden layer), written for tg_mlp_f32_weight_grad.  With >= 2
+ *   hidden layers d_acts[0] and (given d_top_maskbits: u32 [rows][4], the top layer's ReLU mask, 1 bit per feature) d_dz[n - 1]
+ *   may be NULL: the weight-gradient job that would read them rebuilds them on chip (tg_f32_dw_job.recompute).  Mask layout:
+ *   feature 32 mt + 8 q + 4 hh + low (q < 4, hh < 2, low < 4) is bit low + 4 q + 16 (mt % 2) of word hh * (H / 64) + mt / 2.
  * tg_mlp_f32_weight_grad: every job's wgrad += P^T Q (and bgrad += column sums of P) in one launch + one fixed-order reduction
  *   (deterministic, no float atomics).  kind MM: P f32 [rows][H] (a layer's dZ), Q f32 [rows][n_cols] (its input: n_cols = H, or
  *   the padded net input, n_cols = in_pad), window m_out = H x n_out <= n_cols; kind HEAD: P = d loss / d head output f32
@@ -421,7 +424,8 @@ int  tg_mlp_f32_blocks(void);
 int  tg_mlp_f32_forward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
                         int64_t rows, float* d_out, void* stream);
 int  tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
-                                 int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream);
+                                 int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits,
+                                 const tg_chain_loss* loss, void* stream);
 enum { TG_F32DW_MM = 0, TG_F32DW_HEAD = 1 };
 typedef struct tg_f32_dw_job {
     const float* d_p;
@@ -430,6 +434,14 @@ typedef struct tg_f32_dw_job {
     float*       d_bgrad;     /* f32 [m_out] or NULL */
     int64_t      wgrad_ld;
     int32_t      kind, n_cols, m_out, n_out;
+    /* wide MM job with operands REBUILT on chip instead of read (with >= 2 hidden layers): bit 0: Q = relu(W0 x + b0), d_q = the
+     * net input f32 [rows][in_pad]; bit 1: P = (g . W_head) * mask, d_p = d loss / d output f32 [rows][4], d_maskbits = the top
+     * layer's mask bits u32 [rows][4] written by tg_mlp_f32_forward_backward (which then need not store those two matrices) */
+    int32_t      recompute, in_pad, in_dim, act_dim;
+    const float* d_w0;        /* Linear 0 weight f32 [H][in_dim], bias f32 [H] (the master tensors) */
+    const float* d_b0;
+    const float* d_wh;        /* head weight f32 [act_dim][H] */
+    const uint32_t* d_maskbits;
 } tg_f32_dw_job;
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
 int  tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,

@@ -1783,11 +1783,13 @@ def test_f32_chain_forward_matches_fp64(tg, dev, dims, rows):
 @pytest.mark.parametrize("dims", F32_SHAPES)
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("rows", [1, 255, 4000, 70001])
-def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
+def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monkeypatch):
     """forward_loss() + backward_fused() of an fp32 net -- tg_mlp_f32_forward_backward (forward, clipped-surrogate / squared-error
     head as loss_kernels.hip, backward data) and tg_mlp_f32_weight_grad -- against torch autograd of the same loss in fp64
     (algorithms/ppo.py:159-183, grpo.py:122-145): loss sums to 1e-6, every stored activation / dZ to 1e-5 of its scale, every
-    parameter gradient to 2e-5 (x sqrt(rows / 1000)) of its scale; gradients ACCUMULATE into .grad; bit-identical run to run."""
+    parameter gradient to 2e-5 (x sqrt(rows / 1000)) of its scale; gradients ACCUMULATE into .grad; bit-identical run to run.
+    Both forms of the weight-gradient job are held to the same bar: operands read back from HBM, and (nets with >= 2 hidden
+    layers, the default) the first activation / top dZ rebuilt on chip from the input row / d loss / d output + mask bits."""
     from trajopt_grpo_amd import mlp as M
     S, A, hidden = dims
     if kind == 1:
@@ -1802,7 +1804,8 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
     var = torch.full((A,), 0.3)
     eps, sc, cc, kc = 0.2, -1.0 / rows, 0.5 / rows, 0.5 / rows
 
-    def run():
+    def run(recompute):
+        monkeypatch.setattr(M, "_F32_RECOMPUTE", recompute)
         m = M.GemmMLP(net, torch.float32)
         for i, p in enumerate(net.parameters()):
             p.grad = torch.full_like(p, 0.25 * (i + 1))                 # the kernels must ADD to what is there
@@ -1812,14 +1815,35 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
             s = m.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=norm[0:2], var=var, epsilon=eps, surr_coef=sc, kl_coef=kc)
         else:
             s = m.forward_loss(xp, 1, ret=ret, norm=norm[2:4], critic_coef=cc)
-        stored = [t.clone() for t in m._acts[1:]], [t.clone() for t in m._bits], m._dz_head.clone()
+        cl = lambda t: None if t is None else t.clone()
+        stored = [cl(t) for t in m._acts[1:]], [cl(t) for t in m._bits], m._dz_head.clone(), cl(m._tmask)
         m.backward_fused()
         torch.cuda.synchronize()
         return s.clone(), [p.grad.clone() for p in net.parameters()], stored
 
-    s, got, (acts, dzs, dout) = run()
-    s2, got2, _ = run()
+    s, got, (acts, dzs, dout, _) = run(False)
+    s2, got2, _ = run(False)
     assert torch.equal(s, s2) and all(torch.equal(a, b) for a, b in zip(got, got2))
+    assert all(t is not None for t in acts) and all(t is not None for t in dzs)
+    sr, got_r, (acts_r, dzs_r, dout_r, tmask) = run(True)
+    sr2, got_r2, _ = run(True)
+    assert torch.equal(sr, s) and torch.equal(dout_r, dout)
+    assert all(torch.equal(a, b) for a, b in zip(got_r, got_r2))
+    n_hidden = len(hidden)
+    if n_hidden >= 2:
+        # neither the first activation nor the top dZ was written; everything in between is the same bits as in the storing run.
+        # The top layer's mask travels as 4 words per row: feature 32 mt + 8 q + 4 hh + low <-> word hh * (H / 64) + mt // 2,
+        # bit low + 4 q + 16 (mt % 2)  (include/trajopt_grpo_hip.h, tg_mlp_f32_forward_backward)
+        assert acts_r[0] is None and dzs_r[n_hidden - 1] is None and tmask is not None
+        assert all(torch.equal(a, b) for a, b in zip(acts_r[1:], acts[1:])) and all(torch.equal(a, b) for a, b in zip(dzs_r[:-1], dzs[:-1]))
+        Hh = hidden[-1]
+        f = torch.arange(Hh, device=dev)
+        mt, q, hh, low = f >> 5, (f & 31) >> 3, (f >> 2) & 1, f & 3
+        word, bit = hh * (Hh // 64) + (mt >> 1), low + 4 * q + 16 * (mt & 1)
+        got_bits = (tmask.to(torch.int64)[:, word] >> bit) & 1
+        assert torch.equal(got_bits.bool(), acts[-1] > 0)
+    else:
+        assert tmask is None and all(torch.equal(a, b) for a, b in zip(got_r, got))
     # ---- the same update in fp64.  The ReLU masks are the KERNEL's (a pre-activation within fp32 rounding of zero may fall on
     # the other side of the ReLU in fp64; one such flip moves a weight gradient by a whole row's contribution): they are checked
     # against the fp64 pre-activations separately, everything else is then compared tightly ----
@@ -1864,10 +1888,11 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows):
         ref_w[l], ref_b[l] = dz.t() @ (hs[l - 1] if l > 0 else X.double()), dz.sum(0)
         dh = dz @ W[l]
     ref = [t for pair in zip(ref_w, ref_b) for t in pair]                # parameters(): weight, bias per layer
-    for i, (gg, r) in enumerate(zip(got, ref)):
-        base = 0.25 * (i + 1)
-        scale = float(r.abs().max()) + 1e-12
-        assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (i, rows)
+    for form, grads in (("stored", got), ("rebuilt", got_r)):
+        for i, (gg, r) in enumerate(zip(grads, ref)):
+            base = 0.25 * (i + 1)
+            scale = float(r.abs().max()) + 1e-12
+            assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (form, i, rows)
 
 
 def test_c2_size_grpo_learn_matches_the_oracle(tg, dev):

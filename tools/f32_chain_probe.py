@@ -56,10 +56,10 @@ for spec in a.shapes.split(","):
         t_fwd = timeit(lambda: m.forward(xp, keep=False, padded=True), a.iters)
         t_fb = timeit(fl, a.iters)
         fl()
-        saved = (m._acts, m._bits, m._dz_head)
+        saved = (m._acts, m._bits, m._dz_head, m._tmask)
 
         def dw():
-            m._acts, m._bits, m._dz_head = saved
+            m._acts, m._bits, m._dz_head, m._tmask = saved
             m._backward_fused_f32()
         t_dw = timeit(dw, a.iters)
         flop_fwd = 2.0 * (H * m.in_pad + (nh - 1) * H * H)

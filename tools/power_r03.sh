@@ -29,13 +29,13 @@ for p in net.parameters(): p.grad = torch.zeros_like(p)
 m = M.GemmMLP(net, torch.float32); rows = 1 << 20
 xp = m.prepare_input(torch.randn(rows, 5, device=dev)); act = torch.randn(rows, 1, device=dev); lpo = -torch.rand(rows, device=dev) - 1; adv = torch.randn(rows, device=dev)
 fl = lambda: m.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, var=torch.full((1,), 0.3), epsilon=0.2, surr_coef=-1.0 / rows)
-fl(); saved = (m._acts, m._bits, m._dz_head)
+fl(); saved = (m._acts, m._bits, m._dz_head, m._tmask)
 t0 = time.time()
 while time.time() - t0 < 24:
     for _ in range(50):
         if which == "fb": fl()
         else:
-            m._acts, m._bits, m._dz_head = saved; m._backward_fused_f32()
+            m._acts, m._bits, m._dz_head, m._tmask = saved; m._backward_fused_f32()
     torch.cuda.synchronize()
 PY
 for w in fb dw; do (timeout -k 10 60 python3 /tmp/f32_loop.py $w > /dev/null 2>&1 &); sleep 12; sample "f32_$w(128x4, 1M rows)"; wait; sleep 6; done

@@ -60,7 +60,9 @@ TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR, TG_DW_RH = 0, 1, 2, 3, 4
 class F32DwJob(C.Structure):
     """tg_f32_dw_job (include/trajopt_grpo_hip.h)."""
     _fields_ = [("d_p", C.c_void_p), ("d_q", C.c_void_p), ("d_wgrad", C.c_void_p), ("d_bgrad", C.c_void_p),
-                ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("n_cols", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32)]
+                ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("n_cols", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32),
+                ("recompute", C.c_int32), ("in_pad", C.c_int32), ("in_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("d_w0", C.c_void_p), ("d_b0", C.c_void_p), ("d_wh", C.c_void_p), ("d_maskbits", C.c_void_p)]
 
 
 TG_F32DW_MM, TG_F32DW_HEAD = 0, 1
@@ -124,7 +126,7 @@ SIGNATURES = {
     "tg_mlp_f32_stream_floats": (C.c_int64, [_I32, _I32, _I32]),
     "tg_mlp_f32_blocks": (C.c_int, []),
     "tg_mlp_f32_forward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, _VP, _VP]),
-    "tg_mlp_f32_forward_backward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+    "tg_mlp_f32_forward_backward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP,
                                               C.POINTER(ChainLoss), _VP]),
     "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP]),

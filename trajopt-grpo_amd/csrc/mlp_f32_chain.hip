@@ -64,6 +64,8 @@ struct F32ChainArgs {
     float* acts[kF32MaxHidden];   // kTrain: post-ReLU outputs of the hidden layers, f32 [rows][H]
     float* dz[kF32MaxHidden];     // kTrain: d loss / d pre-activation of the hidden layers, f32 [rows][H]
     float* out;             // !kTrain: head output f32 [rows][4]
+    uint32_t* top_mask;     // kTrain, optional: the top hidden layer's ReLU mask bits, u32 [rows][4] (per row: [lane half h][MT / 2 words];
+                            // feature 32 mt + 8 q + 4 h + low is bit low + 4 q + 16 (mt & 1) of word mt >> 1 of half h)
     int32_t resident;       // the whole H x H block stream fits the LDS beside the tables: loaded once, no ring, no block barriers
     F32Loss loss;
 };
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
                 xin[mo] = acc;
                 if constexpr (kTrain) {
                     if (mo & 1) *bits_slot(0, mo >> 1) |= m << 16; else *bits_slot(0, mo >> 1) = m;
-                    if (valid) store_tile<H>(a.acts[0], row, mo, h, acc);
+                    if (valid && a.acts[0] != nullptr) store_tile<H>(a.acts[0], row, mo, h, acc);      // (null: the weight-gradient job recomputes it)
                 }
             }
         }
@@ -353,7 +355,11 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
                     d[4 * q + 3] = (mw >> (4 * q + 3)) & 1u ? s.w : 0.f;
                 }
                 xin[mt] = d;
-                if (valid) store_tile<H>(a.dz[n_hh], row, mt, h, d);
+                if (valid && a.dz[n_hh] != nullptr) store_tile<H>(a.dz[n_hh], row, mt, h, d);         // (null: recomputed from g and the mask bits)
+            }
+            if (valid && a.top_mask != nullptr) {
+#pragma unroll
+                for (int w = 0; w < MT / 2; ++w) a.top_mask[row * 4 + h * (MT / 2) + w] = *bits_slot(n_hh, w);
             }
             for (int l = n_hh; l >= 1; --l) {
 #pragma unroll
@@ -441,6 +447,13 @@ struct F32DwJob {
     int32_t kind, n;        // n: columns of q
     int32_t first_block, n_blocks, slab_len;
     int64_t slab_off;
+    // wide job with recomputed operands (see f32_dw_wide_recompute): bit 0: Q = relu(W0 x + b0) from the net input rows (`q` = x
+    // f32 [rows][in_pad]); bit 1: P = (g . W_head) * mask from d loss / d output (`p` = g f32 [rows][4]) and the top layer's ReLU mask bits
+    int32_t recompute, in_pad, in_dim, act_dim;
+    const float* w0;        // Linear 0 weight, f32 [H][in_dim] (the master tensor)
+    const float* b0;        // Linear 0 bias f32 [H]
+    const float* wh;        // head weight f32 [act_dim][H] (the master tensor)
+    const uint32_t* mask;   // u32 [rows][4]: the top hidden layer's ReLU mask bits as tg_mlp_f32_forward_backward writes them
 };
 struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 
@@ -460,6 +473,8 @@ __device__ unsigned long long g_f32_stamps2[4096 * 6];     // per wave: s_memtim
 typedef __attribute__((address_space(3))) void f32_lds_void;
 __device__ static inline float lds_f(const float* __restrict__ p) { return *p; }
 __device__ static inline float4 lds_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+__device__ static inline uint4 lds_u4(const uint32_t* __restrict__ p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ static inline void lds_st(float* __restrict__ p, float v) { *p = v; }
 
 template <int H>
 struct F32DwGeom {
@@ -470,7 +485,13 @@ struct F32DwGeom {
     static constexpr int WIDE_SLOT = 16384, LIGHT_SLOT = 16384 + SRL * 128;
     static constexpr int WIDE_SLOTS = 4, LIGHT_SLOTS = 3;
     static constexpr int NG_WIDE = 4, NG_LIGHT = 4 + SRL / 32;      // DMA instructions per wave and stage
-    static constexpr int LDS_BYTES = WIDE_SLOT * WIDE_SLOTS > LIGHT_SLOT * LIGHT_SLOTS ? WIDE_SLOT * WIDE_SLOTS : LIGHT_SLOT * LIGHT_SLOTS;
+    // wide job with recomputed operands: slot = [P panel 8 KiB][Q panel 8 KiB][x image SRW x 32 floats][g | mask rows: 1 KiB], 3 slots,
+    // behind them the tables: W0 [H][32] (zero padded), b0 [H], W_head [4][H]
+    static constexpr int REC_SLOT = 16384 + SRW * 128 + 1024, REC_SLOTS = 3;
+    static constexpr int REC_TABLES = (H * 36 + H + 4 * H) * 4;
+    static constexpr int LDS_PLAIN = WIDE_SLOT * WIDE_SLOTS > LIGHT_SLOT * LIGHT_SLOTS ? WIDE_SLOT * WIDE_SLOTS : LIGHT_SLOT * LIGHT_SLOTS;
+    static constexpr int LDS_REC = REC_SLOT * REC_SLOTS + REC_TABLES;
+    static constexpr int LDS_BYTES = LDS_PLAIN > LDS_REC ? LDS_PLAIN : LDS_REC;
 };
 
 // `rows_in` rows x H floats from `g` (row-major) starting at row r0 into a linear LDS panel: this wave's 4 pieces of the 16
@@ -484,6 +505,162 @@ __device__ static inline void f32_dma_wide(const float* __restrict__ g, int64_t 
         int64_t r = r0 + (int64_t)(piece - first_piece) * G::RPP + lane / G::LPR;
         r = r < rows ? r : rows - 1;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g + r * H) + lane % G::LPR, (f32_lds_void*)(panel + piece * 1024), 16, 0, 0);
+    }
+}
+
+// Wide job whose operands are REBUILT on chip instead of streamed (the fp32 sibling of tg_mlp_weight_grad's kinds HR / RH): the
+// first hidden activation is a function of the 32..128-B input row, the top layer's dZ of the 16-B d loss / d output row and 16 B of
+// mask bits -- so tg_mlp_f32_forward_backward need not write them (512 B per row each at H = 128) and this job need not read them.
+// Per stage: DMA the stored operand (if any) and the small rows, barrier, all 256 threads fill the recomputed panel(s) in the slot
+// (thread = one row x 8 consecutive features: fp32 FMA chains over the table rows), barrier, products as in the streamed job.
+template <int H, bool kRecP, bool kRecQ>
+__device__ static void f32_dw_wide_recompute(const F32DwJob& job, int64_t rows, char* lds_c, f32x16 (&acc)[(H / 32 >= 4) ? 2 : 1][(H / 32 >= 4) ? 2 : 1],
+                                              float& bsum) {
+    using G = F32DwGeom<H>;
+    constexpr int MT = H / 32, TW = MT >= 4 ? 2 : 1;
+    constexpr int SR = G::SRW, D = G::REC_SLOTS, P_ = D - 1;
+    constexpr int XP = SR / 8 / 4 > 0 ? SR / 8 / 4 : 1;                 // x-image pieces per wave (SR = 32: 1 of 4; SR = 16: 1 of 2, duplicated)
+    constexpr int NG = (kRecP ? 0 : 2) + (kRecQ ? 0 : 2) + (kRecQ ? XP : 0) + (kRecP ? 1 : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int my = (int)blockIdx.x - job.first_block, nb = job.n_blocks;
+    const int64_t n_st = (rows + SR - 1) / SR;
+    constexpr int kW0Stride = 36;                                       // floats per table row (32 + 4: conflict-free float4 reads across rows)
+    float* w0_s = reinterpret_cast<float*>(lds_c + D * G::REC_SLOT);     // [H][36]
+    float* b0_s = w0_s + H * kW0Stride;
+    float* wh_s = b0_s + H;                                             // [4][H]
+    if constexpr (kRecQ) {
+        for (int q = tid; q < H * 32; q += 256) {
+            const int f = q >> 5, k = q & 31;
+            w0_s[f * kW0Stride + k] = k < job.in_dim ? job.w0[f * job.in_dim + k] : 0.f;
+        }
+        for (int q = tid; q < H; q += 256) b0_s[q] = job.b0[q];
+    }
+    if constexpr (kRecP) {
+        for (int q = tid; q < 4 * H; q += 256) wh_s[q] = (q / H) < job.act_dim ? job.wh[q] : 0.f;
+    }
+    const int thin_f4 = job.in_pad / 4;
+    auto issue = [&](int64_t sg, int slot) {
+        char* sb = lds_c + slot * G::REC_SLOT;
+        const int64_t r0 = sg * SR;
+        if constexpr (!kRecP) f32_dma_wide<H>(job.p, r0, rows, sb, 0, wave, lane);
+        if constexpr (!kRecQ) f32_dma_wide<H>(job.q, r0, rows, sb, 8, wave, lane);
+        if constexpr (kRecQ) {
+            // the input rows as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece
+            const int piece = (SR / 8 >= 4) ? wave : (wave & 1);
+            int64_t r = r0 + piece * 8 + (lane >> 3);
+            r = r < rows ? r : rows - 1;
+            const int c4 = lane & 7;
+            const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(job.q + r * job.in_pad) + c4 : &g_f32_zero16;
+            __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + piece * 1024), 16, 0, 0);
+        }
+        if constexpr (kRecP) {
+            // one piece: lanes [0, SR): the stage's g rows (16 B each); lanes [32, 32 + SR): its mask rows (SR <= 32)
+            const int rr = lane & 31;
+            int64_t r = r0 + (rr < SR ? rr : SR - 1);
+            r = r < rows ? r : rows - 1;
+            const uint4* src = lane < 32 ? reinterpret_cast<const uint4*>(job.p) + r : reinterpret_cast<const uint4*>(job.mask) + r;
+            __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + SR * 128), 16, 0, 0);
+        }
+    };
+    int64_t sg_issue = my;
+    int slot_issue = 0, slot = 0;
+    __syncthreads();                                                    // the tables are in place (ordinary stores: before any DMA)
+#pragma unroll 1
+    for (int t = 0; t < P_; ++t) {
+        issue(sg_issue, slot_issue);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+    }
+    constexpr int RG = 256 / H, RPG = SR / RG;
+    const int cb = tid % H, rg = tid / H;
+    // recompute: thread -> (row rr, features 8 fg .. 8 fg + 7): 256 threads cover SR rows x H features in SR * H / 2048 passes
+    constexpr int FG = H / 8, PASSES = SR * FG / 256;
+#pragma unroll 1
+    for (int64_t sg = my; sg < n_st; sg += nb) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P_ - 1) * NG) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(sg_issue, slot_issue);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        char* sb = lds_c + slot * G::REC_SLOT;
+        float* P = reinterpret_cast<float*>(sb);
+        float* Q = P + SR * H;
+        const float* X = reinterpret_cast<const float*>(sb + 16384);                       // [SR][32]
+        const float* Gm = reinterpret_cast<const float*>(sb + 16384 + SR * 128);           // g rows [32][4] floats, then mask rows [32][4] words
+        slot = slot + 1 == D ? 0 : slot + 1;
+        const int64_t r0 = sg * SR;
+        const int nr = rows - r0 < SR ? (int)(rows - r0) : SR;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            // thread -> row rr, features fg + FG c (c = 0..7): consecutive lanes touch consecutive features / table rows, so the table
+            // reads (row stride 36 floats) and the panel writes are conflict-free
+            const int e = ps * 256 + tid, rr = e / FG, fg = e % FG;
+            if constexpr (kRecQ) {
+                // a0[rr][f] = relu(b0[f] + sum_k W0[f][k] x[rr][k]), k ascending
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = lds_f(b0_s + fg + FG * c);
+                for (int k4 = 0; k4 < thin_f4; ++k4) {
+                    const float4 xv = lds_f4(X + rr * 32 + 4 * k4);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float4 w = lds_f4(w0_s + (fg + FG * c) * kW0Stride + 4 * k4);
+                        o[c] = fmaf(w.x, xv.x, o[c]); o[c] = fmaf(w.y, xv.y, o[c]); o[c] = fmaf(w.z, xv.z, o[c]); o[c] = fmaf(w.w, xv.w, o[c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) lds_st(Q + rr * H + fg + FG * c, fmaxf(o[c], 0.f));
+            }
+            if constexpr (kRecP) {
+                // dZ_top[rr][f] = (sum_a g[rr][a] W_head[a][f]) * bit(rr, f).  Feature f = 32 mt + 8 q + 4 hh + low is bit low + 4 q of the
+                // 16-bit group (tile mt, lane half hh): word hh * (MT / 2) + (mt >> 1) of the row, shifted by 16 (mt & 1)
+                const float4 g4 = lds_f4(Gm + 4 * rr);
+                const uint4 mw = lds_u4(reinterpret_cast<const uint32_t*>(Gm + 32 * 4) + 4 * rr);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int f = fg + FG * c;
+                    float v = lds_f(wh_s + f) * g4.x;
+                    v = fmaf(lds_f(wh_s + H + f), g4.y, v);
+                    v = fmaf(lds_f(wh_s + 2 * H + f), g4.z, v);
+                    v = fmaf(lds_f(wh_s + 3 * H + f), g4.w, v);
+                    const int mt = f >> 5, fl = f & 31, q = fl >> 3, hh = (fl >> 2) & 1, low = fl & 3;
+                    const int wi = hh * (MT / 2) + (mt >> 1);
+                    const uint32_t word = wi == 0 ? mw.x : (wi == 1 ? mw.y : (wi == 2 ? mw.z : mw.w));
+                    const bool keep = ((word >> (low + 4 * q + 16 * (mt & 1))) & 1u) != 0u && rr < nr;
+                    lds_st(P + rr * H + f, keep ? v : 0.f);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this thread's panel writes have landed ...
+        __builtin_amdgcn_s_barrier();                               // ... and everyone's
+        asm volatile("" ::: "memory");
+        float av[SR / 2][TW], bv[SR / 2][TW];
+#pragma unroll
+        for (int s = 0; s < SR / 2; ++s)
+#pragma unroll
+            for (int x = 0; x < TW; ++x) {
+                av[s][x] = lds_f(P + (2 * s + kk) * H + 32 * (TW * wm + x) + i);
+                bv[s][x] = lds_f(Q + (2 * s + kk) * H + 32 * (TW * wn + x) + i);
+            }
+        float bt[RPG];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) bt[r] = lds_f(P + (rg * RPG + r) * H + cb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) bsum += rg * RPG + r < nr ? bt[r] : 0.f;
+#pragma unroll
+        for (int s = 0; s < SR / 2; ++s) {
+            const bool ok = 2 * s + kk < nr;                        // rows past the end are clamped re-reads: their products are zeroed
+#pragma unroll
+            for (int x = 0; x < TW; ++x) av[s][x] = ok ? av[s][x] : 0.f;
+#pragma unroll
+            for (int x = 0; x < TW; ++x)
+#pragma unroll
+                for (int y = 0; y < TW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][x], bv[s][y], acc[x][y], 0, 0, 0);
+        }
     }
 }
 
@@ -518,7 +695,11 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
     float bsum = 0.f;                                   // bias gradient of one column (see the roles below)
     float hacc[4] = {0.f, 0.f, 0.f, 0.f};               // head: dW_h[a][tid]
 
-    if (!head && !narrow) {
+    if (!head && !narrow && job.recompute != 0) {
+        if (job.recompute == 3) f32_dw_wide_recompute<H, true, true>(job, rows, lds_c, acc, bsum);
+        else if (job.recompute == 2) f32_dw_wide_recompute<H, true, false>(job, rows, lds_c, acc, bsum);
+        else f32_dw_wide_recompute<H, false, true>(job, rows, lds_c, acc, bsum);
+    } else if (!head && !narrow) {
         // ================= wide job: dW = P^T Q over H x H, SRW rows per stage =================
         constexpr int SR = G::SRW, D = G::WIDE_SLOTS, P_ = D - 1, NG = G::NG_WIDE;
         const int64_t n_st = (rows + SR - 1) / SR;
@@ -863,7 +1044,8 @@ int tg_mlp_f32_forward(const float* d_x, int32_t in_pad, const float* d_stream, 
 }
 
 int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
-                                int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream) {
+                                int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits, const tg_chain_loss* loss,
+                                void* stream) {
     TG_REQUIRE(d_x && d_stream && d_acts && d_dz && loss, "tg_mlp_f32_forward_backward: null pointer");
     TG_REQUIRE(rows > 0, "tg_mlp_f32_forward_backward: no rows");
     TG_REQUIRE(loss->kind == 0 || loss->kind == 1, "tg_mlp_f32_forward_backward: kind %d", loss->kind);
@@ -876,10 +1058,14 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
     F32ChainArgs a{};
     if (int rc = fill_f32_net(a.net, d_stream, hidden, n_hidden_layers, in_pad, "tg_mlp_f32_forward_backward")) return rc;
     for (int l = 0; l < n_hidden_layers; ++l) {
-        TG_REQUIRE(d_acts[l] && d_dz[l], "tg_mlp_f32_forward_backward: buffer %d is null", l);
+        // with >= 2 hidden layers the first activation and the top layer's dZ may be left out: the weight-gradient job of the layer
+        // that would read them rebuilds them (tg_f32_dw_job.recompute) -- the latter needs the top layer's mask bits
+        const bool a_opt = l == 0 && n_hidden_layers >= 2, z_opt = l == n_hidden_layers - 1 && n_hidden_layers >= 2 && d_top_maskbits;
+        TG_REQUIRE((d_acts[l] || a_opt) && (d_dz[l] || z_opt), "tg_mlp_f32_forward_backward: buffer %d is null", l);
         a.acts[l] = (float*)d_acts[l];
         a.dz[l] = (float*)d_dz[l];
     }
+    a.top_mask = (uint32_t*)d_top_maskbits;
     a.x = d_x; a.rows = rows;
     F32Loss& L = a.loss;
     L.kind = loss->kind; L.A = loss->act_dim;
@@ -938,6 +1124,11 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         } else {
             TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
             TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
+            TG_REQUIRE(jb.recompute >= 0 && jb.recompute <= 3 && (jb.recompute == 0 || jb.n_cols == H), "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
+            TG_REQUIRE(!(jb.recompute & 1) || (jb.d_w0 && jb.d_b0 && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad),
+                       "tg_mlp_f32_weight_grad: job %d recomputes the first activation: first-layer weights / input width missing", j);
+            TG_REQUIRE(!(jb.recompute & 2) || (jb.d_wh && jb.d_maskbits && jb.act_dim >= 1 && jb.act_dim <= 4),
+                       "tg_mlp_f32_weight_grad: job %d recomputes the top dZ: head weights / mask bits missing", j);
             bytes[j] = jb.n_cols == H ? 0 : 4 * H + 4 * jb.n_cols;
             n_wide += jb.n_cols == H;
         }
@@ -979,6 +1170,8 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         const tg_f32_dw_job& jb = jobs[j];
         F32DwJob& dj = args.job[j];
         dj.p = jb.d_p; dj.q = jb.d_q; dj.kind = jb.kind; dj.n = jb.n_cols;
+        dj.recompute = jb.recompute; dj.in_pad = jb.in_pad; dj.in_dim = jb.in_dim; dj.act_dim = jb.act_dim;
+        dj.w0 = jb.d_w0; dj.b0 = jb.d_b0; dj.wh = jb.d_wh; dj.mask = jb.d_maskbits;
         dj.first_block = grid;
         // at least 4 stages per workgroup
         const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H == 128 ? 16 : 32) : (H == 128 ? 32 : 64)));

@@ -35,6 +35,7 @@ _STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
 _FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
 _FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
 _F32_CHAIN = os.environ.get("TG_F32_CHAIN", "1") == "1"       # 0: fp32 nets on the per-layer GEMM path (A/B runs)
+_F32_RECOMPUTE = os.environ.get("TG_F32_RECOMPUTE", "1") == "1"   # 0: store the first activation / top dZ instead of rebuilding them (A/B runs)
 
 
 _LOG = logging.getLogger("trajopt_grpo_amd")
@@ -152,6 +153,7 @@ class GemmMLP:
         self._w0_slabs = None
         self._head_ws = None
         self._dz_head = None
+        self._tmask = None
         # like dx_events, for every tg_mlp_weight_grad launch / every training (keep=True) tg_mlp_forward_chain launch
         self.dw_events = None
         self.fwd_events = None
@@ -425,44 +427,60 @@ class GemmMLP:
         f = self._f32
         rows, H, dev, nh = xp.shape[0], f.H, xp.device, f.n_hidden
         assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
-        acts = [self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
-        dzs = [self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
+        # with >= 2 hidden layers the first activation and the top layer's dZ are neither written nor read: the weight-gradient job
+        # that needs them rebuilds them from the input row / from d loss / d output + the top layer's mask bits (16 B per row)
+        rec = _F32_RECOMPUTE and nh >= 2
+        acts = [None if (rec and i == 0) else self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
+        dzs = [None if (rec and i == nh - 1) else self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
+        tmask = self._ws.get("fmask", rows, 4, torch.int32, dev) if rec else None
         dout = self._ws.get("fz_head", rows, 4, torch.float32, dev)
         nblk = lib.tg_mlp_f32_blocks()
         if self._head_ws is None:
             self._head_ws = torch.empty(nblk * 4, dtype=torch.float64, device=dev)
         a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef)
         a.d_dout8, a.d_work = dout.data_ptr(), self._head_ws.data_ptr()
-        ptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in acts])
-        zptrs = (N.C.c_void_p * nh)(*[t.data_ptr() for t in dzs])
+        ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in acts])
+        zptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
         ev = None
         if self.fwd_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.C.byref(a),
-                                                N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
+        N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.ptr(tmask),
+                                                N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
         if ev is not None:
             ev[1].record()
             # matrix-core flops per row: first layer + forward and backward products of the H x H layers (head: vector unit)
             self.fwd_events.append((ev[0], ev[1], rows, 2 * H * f.in_pad + 4 * (nh - 1) * H * H, f"tg::mlp_f32_chain_kernel<{H},true>"))
         grid = min(nblk, -(-rows // 256))
-        self._acts, self._bits, self._dz_head = [xp] + acts, dzs, dout
+        self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
         return self._head_ws[:grid * 4].view(grid, 4).sum(0)
 
     def _backward_fused_f32(self):
         f = self._f32
         xp, acts, dzs, dout = self._acts[0], self._acts[1:], self._bits, self._dz_head
         rows, H, nh, lin = xp.shape[0], f.H, f.n_hidden, self.linears
+        if nh == 1:
+            assert acts[0] is not None and dzs[0] is not None
         if self._dw_ws is None:
             self._dw_ws = torch.empty(N.load().tg_mlp_f32_weight_grad_workspace(H) // 4, dtype=torch.float32, device=xp.device)
-        specs = [(N.TG_F32DW_MM, dzs[i], acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H) for i in range(nh - 1, 0, -1)]
-        specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim))
-        specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H))
+        # (kind, P, Q, columns of Q, weight window, bias window, rows x columns of the window, recompute bits)
+        specs = []
+        for i in range(nh - 1, 0, -1):
+            rp, rq = dzs[i] is None, acts[i - 1] is None           # top layer's dZ / first activation rebuilt on chip
+            specs.append((N.TG_F32DW_MM, dout if rp else dzs[i], xp if rq else acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H,
+                          (2 if rp else 0) | (1 if rq else 0)))
+        specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim, 0))
+        specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H, 0))
         arr = (N.F32DwJob * len(specs))()
-        for slot, (kind, p, q, ncols, wg, bg, m_out, n_out) in zip(arr, specs):
+        for slot, (kind, p, q, ncols, wg, bg, m_out, n_out, recompute) in zip(arr, specs):
             assert wg.dtype == torch.float32 and wg.stride(1) == 1 and bg.dtype == torch.float32 and bg.is_contiguous()
             slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wg.data_ptr(), bg.data_ptr()
             slot.wgrad_ld, slot.kind, slot.n_cols, slot.m_out, slot.n_out = wg.stride(0), kind, ncols, m_out, n_out
+            slot.recompute, slot.in_pad, slot.in_dim, slot.act_dim = recompute, f.in_pad, self.in_dim, self.out_dim
+            if recompute:
+                w0, b0, wh = lin[0].weight, lin[0].bias, lin[nh].weight
+                assert w0.is_contiguous() and wh.is_contiguous() and w0.dtype == torch.float32
+                slot.d_w0, slot.d_b0, slot.d_wh, slot.d_maskbits = w0.data_ptr(), b0.data_ptr(), wh.data_ptr(), N.ptr(self._tmask)
         ev = None
         if self.dw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -472,7 +490,7 @@ class GemmMLP:
         if ev is not None:
             ev[1].record()
             self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * 32, f"tg::mlp_f32_dw_kernel<{H}>"))
-        self._acts = self._bits = self._dz_head = None
+        self._acts = self._bits = self._dz_head = self._tmask = None
 
     @torch.no_grad()
     def backward_fused(self):
