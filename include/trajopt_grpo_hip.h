@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 7
+#define TG_ABI_VERSION 8
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -434,14 +434,27 @@ typedef struct tg_f32_dw_job {
     float*       d_bgrad;     /* f32 [m_out] or NULL */
     int64_t      wgrad_ld;
     int32_t      kind, n_cols, m_out, n_out;
-    /* wide MM job with operands REBUILT on chip instead of read (with >= 2 hidden layers): bit 0: Q = relu(W0 x + b0), d_q = the
-     * net input f32 [rows][in_pad]; bit 1: P = (g . W_head) * mask, d_p = d loss / d output f32 [rows][4], d_maskbits = the top
-     * layer's mask bits u32 [rows][4] written by tg_mlp_f32_forward_backward (which then need not store those two matrices) */
+    /* wide MM job with operands REBUILT on chip instead of read, and the net's two light gradients riding on it (nets with >= 2
+     * hidden layers; tg_mlp_f32_forward_backward then need not store the rebuilt matrices, and no MM job for the first layer /
+     * HEAD job is given):
+     *   bit 0 (the second layer's job): Q = relu(W0 x + b0), d_q = the net input f32 [rows][in_pad]; rider: the FIRST layer's
+     *     gradient -- d_dz0 = the bottom dZ f32 [rows][H], d_w0grad f32 H x in_dim (row stride w0grad_ld) += dZ_0^T x, d_b0grad [H];
+     *   bit 1 (the top layer's job): P = (g . W_head) * mask, d_p = d loss / d output f32 [rows][4], d_maskbits = the top layer's
+     *     mask bits u32 [rows][4] written by tg_mlp_f32_forward_backward; rider: the HEAD's gradient -- d_a_top = the top
+     *     activation f32 [rows][H], d_whgrad f32 act_dim x H (row stride whgrad_ld) += g^T A_top, d_bhgrad [act_dim]. */
     int32_t      recompute, in_pad, in_dim, act_dim;
     const float* d_w0;        /* Linear 0 weight f32 [H][in_dim], bias f32 [H] (the master tensors) */
     const float* d_b0;
     const float* d_wh;        /* head weight f32 [act_dim][H] */
     const uint32_t* d_maskbits;
+    const float* d_a_top;
+    float*       d_whgrad;
+    float*       d_bhgrad;
+    int64_t      whgrad_ld;
+    const float* d_dz0;
+    float*       d_w0grad;
+    float*       d_b0grad;
+    int64_t      w0grad_ld;
 } tg_f32_dw_job;
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
 int  tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,

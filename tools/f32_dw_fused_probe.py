@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Times tg_mlp_f32_weight_grad's fused job (rebuilt operands + riders) of a 5-128-128-1 net at a fixed row count; with STAMPS=1 and
+TG_NATIVE_LIB=scratch/libtg_dwstamps.so (tools/build_probe_libs.sh) prints the per-phase cycle counts of the stage loop."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import trajopt_grpo_amd as tg
+from trajopt_grpo_amd import mlp as M
+dev = torch.device("cuda", 0)
+rows = int(os.environ.get("ROWS", 176584))
+shape = os.environ.get("SHAPE", "5:1:128x2")
+S, A, hw = shape.split(":"); S, A = int(S), int(A); H, nh = (int(v) for v in hw.split("x"))
+torch.manual_seed(0)
+net = tg.NeuralNetwork(S, A, (H,) * nh, "ReLU").to(dev)
+for p in net.parameters():
+    p.grad = torch.zeros_like(p)
+m = M.GemmMLP(net, torch.float32)
+X = torch.randn(rows, S, device=dev); xp = m.prepare_input(X)
+act = torch.randn(rows, A, device=dev); lpo = -0.5 * torch.rand(rows, device=dev) - 1.0; adv = torch.randn(rows, device=dev)
+m.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, var=torch.full((A,), 0.3), epsilon=0.2, surr_coef=-1.0 / rows, kl_coef=0.5 / rows)
+saved = (m._acts, m._bits, m._dz_head, m._tmask)
+def dw():
+    m._acts, m._bits, m._dz_head, m._tmask = saved
+    m._backward_fused_f32()
+for _ in range(3): dw()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): dw()
+e1.record(); torch.cuda.synchronize()
+print(shape, rows, "weight_grad %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
+if os.environ.get("STAMPS"):
+    import ctypes, numpy as np
+    raw = ctypes.CDLL(os.environ["TG_NATIVE_LIB"])
+    buf = (ctypes.c_ulonglong * (4096 * 8))()
+    assert raw.tg_debug_f32_stamps3(buf) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+    a = a[a[:, 6] > 0]
+    per = a[:, :6] / a[:, 6:7]
+    print("waves", len(a), "stages/wave %.1f" % a[:, 6].mean())
+    print("cycles per stage: wait+barrier %.0f  issue %.0f  phase1 %.0f  barrier %.0f  operand reads %.0f  products %.0f  | sum %.0f" % (*per.mean(0), per.mean(0).sum()))
+    for w in range(4):
+        print(" wave", w, np.round(per[w::4].mean(0)))

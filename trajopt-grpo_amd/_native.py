@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TG_NATIVE_LIB: another build of the same library (probe builds with different compile-time flags, tools/mall_probe.py)
 LIB_PATH = os.environ.get("TG_NATIVE_LIB") or os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 7                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 8                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -62,7 +62,9 @@ class F32DwJob(C.Structure):
     _fields_ = [("d_p", C.c_void_p), ("d_q", C.c_void_p), ("d_wgrad", C.c_void_p), ("d_bgrad", C.c_void_p),
                 ("wgrad_ld", C.c_int64), ("kind", C.c_int32), ("n_cols", C.c_int32), ("m_out", C.c_int32), ("n_out", C.c_int32),
                 ("recompute", C.c_int32), ("in_pad", C.c_int32), ("in_dim", C.c_int32), ("act_dim", C.c_int32),
-                ("d_w0", C.c_void_p), ("d_b0", C.c_void_p), ("d_wh", C.c_void_p), ("d_maskbits", C.c_void_p)]
+                ("d_w0", C.c_void_p), ("d_b0", C.c_void_p), ("d_wh", C.c_void_p), ("d_maskbits", C.c_void_p),
+                ("d_a_top", C.c_void_p), ("d_whgrad", C.c_void_p), ("d_bhgrad", C.c_void_p), ("whgrad_ld", C.c_int64),
+                ("d_dz0", C.c_void_p), ("d_w0grad", C.c_void_p), ("d_b0grad", C.c_void_p), ("w0grad_ld", C.c_int64)]
 
 
 TG_F32DW_MM, TG_F32DW_HEAD = 0, 1

@@ -447,13 +447,17 @@ struct F32DwJob {
     int32_t kind, n;        // n: columns of q
     int32_t first_block, n_blocks, slab_len;
     int64_t slab_off;
-    // wide job with recomputed operands (see f32_dw_wide_recompute): bit 0: Q = relu(W0 x + b0) from the net input rows (`q` = x
-    // f32 [rows][in_pad]); bit 1: P = (g . W_head) * mask from d loss / d output (`p` = g f32 [rows][4]) and the top layer's ReLU mask bits
+    // wide job with rebuilt operands and riders (see f32_dw_fused): bit 0: Q = relu(W0 x + b0) from the net input rows (`q` = x
+    // f32 [rows][in_pad]), the first layer's gradient rides; bit 1: P = (g . W_head) * mask from d loss / d output (`p` = g f32
+    // [rows][4]) and the top layer's ReLU mask bits, the head's gradient rides
     int32_t recompute, in_pad, in_dim, act_dim;
     const float* w0;        // Linear 0 weight, f32 [H][in_dim] (the master tensor)
     const float* b0;        // Linear 0 bias f32 [H]
     const float* wh;        // head weight f32 [act_dim][H] (the master tensor)
     const uint32_t* mask;   // u32 [rows][4]: the top hidden layer's ReLU mask bits as tg_mlp_f32_forward_backward writes them
+    const float* a_top;     // head rider: the top activation f32 [rows][H]
+    const float* dz0;       // first-layer rider: the bottom dZ f32 [rows][H]
+    int32_t ring_slots;     // 2 or 3
 };
 struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 
@@ -467,6 +471,7 @@ struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 __device__ uint4 g_f32_zero16;
 #if TG_F32DW_STAMPS
 __device__ unsigned long long g_f32_stamps[4096 * 4];      // per wave: cycles in [wait + bias][arrive][products + reads], stages
+__device__ unsigned long long g_f32_stamps3[4096 * 8];     // fused job, per wave: cycles in [wait + barrier][issue][phase 1][barrier][operand reads][products], stages
 __device__ unsigned long long g_f32_stamps2[4096 * 6];     // per wave: s_memtime at entry / loop start / loop end / exit, s_memrealtime at entry / exit
 #endif                             // 16 zero bytes: the source of an image's padding lanes
 
@@ -475,6 +480,7 @@ __device__ static inline float lds_f(const float* __restrict__ p) { return *p; }
 __device__ static inline float4 lds_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
 __device__ static inline uint4 lds_u4(const uint32_t* __restrict__ p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ static inline void lds_st(float* __restrict__ p, float v) { *p = v; }
+__device__ static inline uint32_t lds_u(const uint32_t* __restrict__ p) { return *p; }
 
 template <int H>
 struct F32DwGeom {
@@ -485,17 +491,13 @@ struct F32DwGeom {
     static constexpr int WIDE_SLOT = 16384, LIGHT_SLOT = 16384 + SRL * 128;
     static constexpr int WIDE_SLOTS = 4, LIGHT_SLOTS = 3;
     static constexpr int NG_WIDE = 4, NG_LIGHT = 4 + SRL / 32;      // DMA instructions per wave and stage
-    // wide job with recomputed operands: slot = [P panel 8 KiB][Q panel 8 KiB][x image SRW x 32 floats][g | mask rows: 1 KiB], 3 slots,
-    // behind them the tables: W0 [H][32] (zero padded), b0 [H], W_head [4][H]
-    static constexpr int REC_SLOT = 16384 + SRW * 128 + 1024, REC_SLOTS = 3;
-    static constexpr int REC_TABLES = (H * 36 + H + 4 * H) * 4;
     static constexpr int LDS_PLAIN = WIDE_SLOT * WIDE_SLOTS > LIGHT_SLOT * LIGHT_SLOTS ? WIDE_SLOT * WIDE_SLOTS : LIGHT_SLOT * LIGHT_SLOTS;
-    static constexpr int LDS_REC = REC_SLOT * REC_SLOTS + REC_TABLES;
-    static constexpr int LDS_BYTES = LDS_PLAIN > LDS_REC ? LDS_PLAIN : LDS_REC;
+    static constexpr int LDS_MAX = 79 * 1024;               // two workgroups per CU (160 KiB)
 };
 
 // `rows_in` rows x H floats from `g` (row-major) starting at row r0 into a linear LDS panel: this wave's 4 pieces of the 16
-template <int H>
+// (kZeroTail: rows past the end arrive as zeros instead of as re-reads of the last row)
+template <int H, bool kZeroTail = false>
 __device__ static inline void f32_dma_wide(const float* __restrict__ g, int64_t r0, int64_t rows, char* panel, int first_piece,
                                            int wave, int lane) {
     using G = F32DwGeom<H>;
@@ -503,163 +505,317 @@ __device__ static inline void f32_dma_wide(const float* __restrict__ g, int64_t 
     for (int t = 0; t < 2; ++t) {
         const int piece = first_piece + 2 * wave + t;       // 8 pieces per 8-KiB half: waves take 2 each
         int64_t r = r0 + (int64_t)(piece - first_piece) * G::RPP + lane / G::LPR;
-        r = r < rows ? r : rows - 1;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(g + r * H) + lane % G::LPR, (f32_lds_void*)(panel + piece * 1024), 16, 0, 0);
+        const uint4* src = reinterpret_cast<const uint4*>(g + (r < rows ? r : rows - 1) * H) + lane % G::LPR;
+        if constexpr (kZeroTail) src = r < rows ? src : &g_f32_zero16;
+        __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(panel + piece * 1024), 16, 0, 0);
     }
 }
 
-// Wide job whose operands are REBUILT on chip instead of streamed (the fp32 sibling of tg_mlp_weight_grad's kinds HR / RH): the
-// first hidden activation is a function of the 32..128-B input row, the top layer's dZ of the 16-B d loss / d output row and 16 B of
-// mask bits -- so tg_mlp_f32_forward_backward need not write them (512 B per row each at H = 128) and this job need not read them.
-// Per stage: DMA the stored operand (if any) and the small rows, barrier, all 256 threads fill the recomputed panel(s) in the slot
-// (thread = one row x 8 consecutive features: fp32 FMA chains over the table rows), barrier, products as in the streamed job.
+// Wide job whose operands are REBUILT on chip instead of streamed, with the net's two light gradients riding on it (the fp32
+// sibling of tg_mlp_weight_grad's kinds HR / RH).  The first hidden activation is a function of the 32..128-B input row, the top
+// layer's dZ of the 16-B d loss / d output row and 16 B of mask bits -- so tg_mlp_f32_forward_backward need not write them (512 B
+// per row each at H = 128) and this job need not read them.  What the job streams instead are the wide operands of the two light
+// gradients, which then need no workgroups (and no matrix pipe idling beside their byte streams) of their own:
+//   kRecP (top layer's job):    P = (g . W_head) * mask rebuilt;  rider: the head's gradient  dW_h = g^T . A_top, db_h = sum g
+//   kRecQ (second layer's job): Q = relu(W0 x + b0) rebuilt;      rider: the first layer's    dW_0 = dZ_0^T . x,  db_0 = sum dZ_0
+// (a net with two hidden layers has ONE such job carrying both).  Per stage of SRW rows: the ring slot holds the two streamed
+// panels + the input rows as a zero-padded [SRW][32] image + the g | mask rows; phase 1: thread = (feature f, 8 rows) fills the
+// rebuilt panel(s) -- fp32 FMA chains, k ascending -- and does the riders' vector work (bias sums, head products) on the values
+// passing through its registers; barrier; phase 2: the matrix products, the first layer's on one extra tile per wave.
 template <int H, bool kRecP, bool kRecQ>
-__device__ static void f32_dw_wide_recompute(const F32DwJob& job, int64_t rows, char* lds_c, f32x16 (&acc)[(H / 32 >= 4) ? 2 : 1][(H / 32 >= 4) ? 2 : 1],
-                                              float& bsum) {
-    using G = F32DwGeom<H>;
+struct F32FusedGeom {
+    static constexpr int SR = F32DwGeom<H>::SRW;
+    static constexpr int PANEL = SR * H * 4;                                 // 8 KiB
+    static constexpr int OFF_P = 0;                                         // streamed P (if not rebuilt)
+    static constexpr int OFF_Q = OFF_P + (kRecP ? 0 : PANEL);               // streamed Q (if not rebuilt)
+    static constexpr int OFF_AT = OFF_Q + (kRecQ ? 0 : PANEL);              // head rider: the top activation
+    static constexpr int OFF_Z0 = OFF_AT + (kRecP ? PANEL : 0);             // first-layer rider: the bottom dZ
+    static constexpr int OFF_X = OFF_Z0 + (kRecQ ? PANEL : 0);              // input rows, [SR][32] floats
+    static constexpr int OFF_G = OFF_X + (kRecQ ? SR * 128 : 0);            // g rows [32][4] floats, then mask rows [32][4] words
+    static constexpr int SLOT = OFF_G + (kRecP ? 1024 : 0);
+    static constexpr int N_SMALL = (kRecQ ? SR / 8 : 0) + (kRecP ? 1 : 0);  // 1-KiB pieces of the small operands
+    static constexpr int SPW = (N_SMALL + 3) / 4;                           // ... per wave and stage (a wave may repeat a piece)
+    static constexpr int NG = 4 + SPW;                                      // DMA instructions per wave and stage (always two panels)
+    static constexpr int REC_PANELS = ((kRecP ? 1 : 0) + (kRecQ ? 1 : 0)) * PANEL;
+    static constexpr int lds_bytes(int slots, int in_pad) { return slots * SLOT + REC_PANELS + (kRecQ ? H * (in_pad + 4) * 4 : 0); }
+    static constexpr int SLAB = H * H + H + (kRecQ ? H * 32 + H : 0) + (kRecP ? 4 * H + 4 : 0);
+};
+
+template <int H, bool kRecP, bool kRecQ>
+__device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds_c, float* __restrict__ ws) {
+    using F = F32FusedGeom<H, kRecP, kRecQ>;
     constexpr int MT = H / 32, TW = MT >= 4 ? 2 : 1;
-    constexpr int SR = G::SRW, D = G::REC_SLOTS, P_ = D - 1;
-    constexpr int XP = SR / 8 / 4 > 0 ? SR / 8 / 4 : 1;                 // x-image pieces per wave (SR = 32: 1 of 4; SR = 16: 1 of 2, duplicated)
-    constexpr int NG = (kRecP ? 0 : 2) + (kRecQ ? 0 : 2) + (kRecQ ? XP : 0) + (kRecP ? 1 : 0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int SR = F::SR, NG = F::NG;
+    constexpr int KS = 4 / MT;                                          // the first layer's tile: k-steps split over KS waves (H = 64: 2)
+    static_assert(SR / (256 / H) == 8, "a thread rebuilds 8 rows of one feature per stage");
+    const int D = job.ring_slots;                                       // 2 or 3 (host: what fits 79 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int my = (int)blockIdx.x - job.first_block, nb = job.n_blocks;
     const int64_t n_st = (rows + SR - 1) / SR;
-    constexpr int kW0Stride = 36;                                       // floats per table row (32 + 4: conflict-free float4 reads across rows)
-    float* w0_s = reinterpret_cast<float*>(lds_c + D * G::REC_SLOT);     // [H][36]
-    float* b0_s = w0_s + H * kW0Stride;
-    float* wh_s = b0_s + H;                                             // [4][H]
+    const int f = tid % H;                                              // this thread's feature ...
+    const int rb = (wave * 64 / H) * 8;                                 // ... and first row of the stage (wave-uniform)
+    float* Pp = reinterpret_cast<float*>(lds_c + D * F::SLOT);          // rebuilt panels [SR][H], behind the ring
+    float* Qp = Pp + (kRecP ? SR * H : 0);
+    float* w0_s = Qp + (kRecQ ? SR * H : 0);                            // [H][in_pad + 4]
+    const int wstride = job.in_pad + 4;
+    const int thin_f4 = job.in_pad / 4;
+    float b0v = 0.f, whv[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (kRecQ) {
-        for (int q = tid; q < H * 32; q += 256) {
-            const int f = q >> 5, k = q & 31;
-            w0_s[f * kW0Stride + k] = k < job.in_dim ? job.w0[f * job.in_dim + k] : 0.f;
+        for (int q = tid; q < H * job.in_pad; q += 256) {
+            const int ff = q / job.in_pad, k = q - ff * job.in_pad;
+            w0_s[ff * wstride + k] = k < job.in_dim ? job.w0[ff * job.in_dim + k] : 0.f;
         }
-        for (int q = tid; q < H; q += 256) b0_s[q] = job.b0[q];
+        b0v = job.b0[f];
     }
     if constexpr (kRecP) {
-        for (int q = tid; q < 4 * H; q += 256) wh_s[q] = (q / H) < job.act_dim ? job.wh[q] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) whv[a] = a < job.act_dim ? job.wh[a * H + f] : 0.f;
     }
-    const int thin_f4 = job.in_pad / 4;
+    // feature f = 32 mt + 8 q + 4 hh + low is bit low + 4 q + 16 (mt & 1) of word hh * (MT / 2) + (mt >> 1) of its row's mask
+    const int m_word = ((f >> 2) & 1) * (MT / 2) + (f >> 6), m_shift = (f & 3) + 4 * ((f & 31) >> 3) + 16 * ((f >> 5) & 1);
+
     auto issue = [&](int64_t sg, int slot) {
-        char* sb = lds_c + slot * G::REC_SLOT;
+        char* sb = lds_c + slot * F::SLOT;
         const int64_t r0 = sg * SR;
-        if constexpr (!kRecP) f32_dma_wide<H>(job.p, r0, rows, sb, 0, wave, lane);
-        if constexpr (!kRecQ) f32_dma_wide<H>(job.q, r0, rows, sb, 8, wave, lane);
-        if constexpr (kRecQ) {
-            // the input rows as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece
-            const int piece = (SR / 8 >= 4) ? wave : (wave & 1);
-            int64_t r = r0 + piece * 8 + (lane >> 3);
-            r = r < rows ? r : rows - 1;
-            const int c4 = lane & 7;
-            const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(job.q + r * job.in_pad) + c4 : &g_f32_zero16;
-            __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + piece * 1024), 16, 0, 0);
-        }
-        if constexpr (kRecP) {
-            // one piece: lanes [0, SR): the stage's g rows (16 B each); lanes [32, 32 + SR): its mask rows (SR <= 32)
-            const int rr = lane & 31;
-            int64_t r = r0 + (rr < SR ? rr : SR - 1);
-            r = r < rows ? r : rows - 1;
-            const uint4* src = lane < 32 ? reinterpret_cast<const uint4*>(job.p) + r : reinterpret_cast<const uint4*>(job.mask) + r;
-            __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + SR * 128), 16, 0, 0);
+        // (P-side operands arrive as zeros past the last row: no product or sum needs masking)
+        if constexpr (!kRecP) f32_dma_wide<H, true>(job.p, r0, rows, sb + F::OFF_P, 0, wave, lane);
+        if constexpr (!kRecQ) f32_dma_wide<H>(job.q, r0, rows, sb + F::OFF_Q, 0, wave, lane);
+        if constexpr (kRecP) f32_dma_wide<H>(job.a_top, r0, rows, sb + F::OFF_AT, 0, wave, lane);
+        if constexpr (kRecQ) f32_dma_wide<H, true>(job.dz0, r0, rows, sb + F::OFF_Z0, 0, wave, lane);
+#pragma unroll
+        for (int t = 0; t < F::SPW; ++t) {
+            const int pc = (wave + 4 * t) % F::N_SMALL;
+            if (kRecQ && pc < SR / 8) {
+                // the input rows as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece
+                int64_t r = r0 + pc * 8 + (lane >> 3);
+                r = r < rows ? r : rows - 1;
+                const int c4 = lane & 7;
+                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(job.q + r * job.in_pad) + c4 : &g_f32_zero16;
+                __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_X + pc * 1024), 16, 0, 0);
+            } else {
+                // lanes [0, 32): the stage's g rows (16 B each; zeros past the last row); lanes [32, 64): its mask rows
+                const int rr = lane & 31;
+                const int64_t r = r0 + (rr < SR ? rr : SR - 1);
+                const int64_t rc = r < rows ? r : rows - 1;
+                const uint4* src = lane < 32 ? (r < rows ? reinterpret_cast<const uint4*>(job.p) + rc : &g_f32_zero16)
+                                             : reinterpret_cast<const uint4*>(job.mask) + rc;
+                __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_G), 16, 0, 0);
+            }
         }
     };
+    f32x16 acc[TW][TW], acc0 = f32x16{};
+#pragma unroll
+    for (int x = 0; x < TW; ++x)
+#pragma unroll
+        for (int y = 0; y < TW; ++y) acc[x][y] = f32x16{};
+    float bsum = 0.f, b0sum = 0.f, hacc[4] = {0.f, 0.f, 0.f, 0.f}, gsum[4] = {0.f, 0.f, 0.f, 0.f};
     int64_t sg_issue = my;
     int slot_issue = 0, slot = 0;
-    __syncthreads();                                                    // the tables are in place (ordinary stores: before any DMA)
+    __syncthreads();                                                    // the table is in place (ordinary stores: before any DMA)
 #pragma unroll 1
-    for (int t = 0; t < P_; ++t) {
+    for (int t = 0; t < D - 1; ++t) {
         issue(sg_issue, slot_issue);
         sg_issue += nb;
         slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
     }
-    constexpr int RG = 256 / H, RPG = SR / RG;
-    const int cb = tid % H, rg = tid / H;
-    // recompute: thread -> (row rr, features 8 fg .. 8 fg + 7): 256 threads cover SR rows x H features in SR * H / 2048 passes
-    constexpr int FG = H / 8, PASSES = SR * FG / 256;
+    const int tile0 = wave % MT, ks0 = wave / MT;                       // first-layer rider: this wave's tile and k-step phase
+#if TG_F32DW_STAMPS
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+#define TG_FSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - st_t; st_t = now_; }
+#else
+#define TG_FSTAMP(k)
+#endif
 #pragma unroll 1
     for (int64_t sg = my; sg < n_st; sg += nb) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P_ - 1) * NG) : "memory");
-        __builtin_amdgcn_s_barrier();
+#if TG_F32DW_STAMPS
+        unsigned long long st_t = __builtin_amdgcn_s_memtime();
+        st[6] += 1;
+#endif
+        if (D == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // the stage has landed for every wave; every wave is done with the previous stage's slot and panels
         asm volatile("" ::: "memory");
+        TG_FSTAMP(0)
         issue(sg_issue, slot_issue);
         sg_issue += nb;
         slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
-        char* sb = lds_c + slot * G::REC_SLOT;
-        float* P = reinterpret_cast<float*>(sb);
-        float* Q = P + SR * H;
-        const float* X = reinterpret_cast<const float*>(sb + 16384);                       // [SR][32]
-        const float* Gm = reinterpret_cast<const float*>(sb + 16384 + SR * 128);           // g rows [32][4] floats, then mask rows [32][4] words
+        char* sb = lds_c + slot * F::SLOT;
         slot = slot + 1 == D ? 0 : slot + 1;
-        const int64_t r0 = sg * SR;
-        const int nr = rows - r0 < SR ? (int)(rows - r0) : SR;
+        const float* X = reinterpret_cast<const float*>(sb + F::OFF_X);
+        const float* Gm = reinterpret_cast<const float*>(sb + F::OFF_G);
+        const uint32_t* Mm = reinterpret_cast<const uint32_t*>(sb + F::OFF_G + 512);
+        const float* AT = reinterpret_cast<const float*>(sb + F::OFF_AT);
+        const float* Z0 = reinterpret_cast<const float*>(sb + F::OFF_Z0);
+        TG_FSTAMP(1)
+        // ---- phase 1: rebuild, and the riders' vector work ----
+        if constexpr (kRecQ) {
+            // a0[row][f] = relu(b0[f] + sum_k W0[f][k] x[row][k]), k ascending
+            float z[8], o[8];
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            // thread -> row rr, features fg + FG c (c = 0..7): consecutive lanes touch consecutive features / table rows, so the table
-            // reads (row stride 36 floats) and the panel writes are conflict-free
-            const int e = ps * 256 + tid, rr = e / FG, fg = e % FG;
-            if constexpr (kRecQ) {
-                // a0[rr][f] = relu(b0[f] + sum_k W0[f][k] x[rr][k]), k ascending
-                float o[8];
+            for (int r = 0; r < 8; ++r) z[r] = lds_f(Z0 + (rb + r) * H + f);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = lds_f(b0_s + fg + FG * c);
-                for (int k4 = 0; k4 < thin_f4; ++k4) {
-                    const float4 xv = lds_f4(X + rr * 32 + 4 * k4);
+            for (int r = 0; r < 8; ++r) o[r] = b0v;
+            for (int k4 = 0; k4 < thin_f4; ++k4) {
+                const float4 w = lds_f4(w0_s + f * wstride + 4 * k4);
+                float4 xv[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float4 w = lds_f4(w0_s + (fg + FG * c) * kW0Stride + 4 * k4);
-                        o[c] = fmaf(w.x, xv.x, o[c]); o[c] = fmaf(w.y, xv.y, o[c]); o[c] = fmaf(w.z, xv.z, o[c]); o[c] = fmaf(w.w, xv.w, o[c]);
-                    }
-                }
+                for (int r = 0; r < 8; ++r) xv[r] = lds_f4(X + (rb + r) * 32 + 4 * k4);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) lds_st(Q + rr * H + fg + FG * c, fmaxf(o[c], 0.f));
-            }
-            if constexpr (kRecP) {
-                // dZ_top[rr][f] = (sum_a g[rr][a] W_head[a][f]) * bit(rr, f).  Feature f = 32 mt + 8 q + 4 hh + low is bit low + 4 q of the
-                // 16-bit group (tile mt, lane half hh): word hh * (MT / 2) + (mt >> 1) of the row, shifted by 16 (mt & 1)
-                const float4 g4 = lds_f4(Gm + 4 * rr);
-                const uint4 mw = lds_u4(reinterpret_cast<const uint32_t*>(Gm + 32 * 4) + 4 * rr);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int f = fg + FG * c;
-                    float v = lds_f(wh_s + f) * g4.x;
-                    v = fmaf(lds_f(wh_s + H + f), g4.y, v);
-                    v = fmaf(lds_f(wh_s + 2 * H + f), g4.z, v);
-                    v = fmaf(lds_f(wh_s + 3 * H + f), g4.w, v);
-                    const int mt = f >> 5, fl = f & 31, q = fl >> 3, hh = (fl >> 2) & 1, low = fl & 3;
-                    const int wi = hh * (MT / 2) + (mt >> 1);
-                    const uint32_t word = wi == 0 ? mw.x : (wi == 1 ? mw.y : (wi == 2 ? mw.z : mw.w));
-                    const bool keep = ((word >> (low + 4 * q + 16 * (mt & 1))) & 1u) != 0u && rr < nr;
-                    lds_st(P + rr * H + f, keep ? v : 0.f);
+                for (int r = 0; r < 8; ++r) {
+                    o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_st(Qp + (rb + r) * H + f, fmaxf(o[r], 0.f));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) b0sum += z[r];
+        }
+        if constexpr (kRecP) {
+            // dZ_top[row][f] = (sum_a g[row][a] W_head[a][f]) * bit(row, f), as the chain kernel forms it
+            float at[8];
+            float4 g4[8];
+            uint32_t mw[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                at[r] = lds_f(AT + (rb + r) * H + f);
+                g4[r] = lds_f4(Gm + 4 * (rb + r));
+                mw[r] = lds_u(Mm + 4 * (rb + r) + m_word);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t word = mw[r];
+                float v = whv[0] * g4[r].x;
+                v = fmaf(whv[1], g4[r].y, v); v = fmaf(whv[2], g4[r].z, v); v = fmaf(whv[3], g4[r].w, v);
+                const float pv = ((word >> m_shift) & 1u) != 0u ? v : 0.f;
+                lds_st(Pp + (rb + r) * H + f, pv);
+                bsum += pv;
+                hacc[0] = fmaf(g4[r].x, at[r], hacc[0]); hacc[1] = fmaf(g4[r].y, at[r], hacc[1]);
+                hacc[2] = fmaf(g4[r].z, at[r], hacc[2]); hacc[3] = fmaf(g4[r].w, at[r], hacc[3]);
+                gsum[0] += g4[r].x; gsum[1] += g4[r].y; gsum[2] += g4[r].z; gsum[3] += g4[r].w;
+            }
+        } else {
+            const float* Ps = reinterpret_cast<const float*>(sb + F::OFF_P);
+            float pz[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pz[r] = lds_f(Ps + (rb + r) * H + f);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bsum += pz[r];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this thread's panel writes have landed ...
+        TG_FSTAMP(2)
         __builtin_amdgcn_s_barrier();                               // ... and everyone's
         asm volatile("" ::: "memory");
+        TG_FSTAMP(3)
+        // ---- phase 2: products (every operand in registers first: one exposed LDS latency per stage) ----
+        const float* Pa = kRecP ? Pp : reinterpret_cast<const float*>(sb + F::OFF_P);
+        const float* Qa = kRecQ ? Qp : reinterpret_cast<const float*>(sb + F::OFF_Q);
         float av[SR / 2][TW], bv[SR / 2][TW];
 #pragma unroll
         for (int s = 0; s < SR / 2; ++s)
 #pragma unroll
             for (int x = 0; x < TW; ++x) {
-                av[s][x] = lds_f(P + (2 * s + kk) * H + 32 * (TW * wm + x) + i);
-                bv[s][x] = lds_f(Q + (2 * s + kk) * H + 32 * (TW * wn + x) + i);
+                av[s][x] = lds_f(Pa + (2 * s + kk) * H + 32 * (TW * wm + x) + i);
+                bv[s][x] = lds_f(Qa + (2 * s + kk) * H + 32 * (TW * wn + x) + i);
             }
-        float bt[RPG];
+        float za[SR / 2 / KS], xb[SR / 2 / KS];
+        if constexpr (kRecQ) {
 #pragma unroll
-        for (int r = 0; r < RPG; ++r) bt[r] = lds_f(P + (rg * RPG + r) * H + cb);
+            for (int s = 0; s < SR / 2 / KS; ++s) {
+                const int row = 2 * (KS * s + ks0) + kk;
+                za[s] = lds_f(Z0 + row * H + 32 * tile0 + i);
+                xb[s] = lds_f(X + row * 32 + i);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < RPG; ++r) bsum += rg * RPG + r < nr ? bt[r] : 0.f;
+        for (int s = 0; s < SR / 2; ++s)
+#pragma unroll
+            for (int x = 0; x < TW; ++x) asm volatile("" : "+v"(av[s][x]), "+v"(bv[s][x]));     // (the products stay behind the wait)
+        TG_FSTAMP(4)
 #pragma unroll
         for (int s = 0; s < SR / 2; ++s) {
-            const bool ok = 2 * s + kk < nr;                        // rows past the end are clamped re-reads: their products are zeroed
-#pragma unroll
-            for (int x = 0; x < TW; ++x) av[s][x] = ok ? av[s][x] : 0.f;
 #pragma unroll
             for (int x = 0; x < TW; ++x)
 #pragma unroll
                 for (int y = 0; y < TW; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][x], bv[s][y], acc[x][y], 0, 0, 0);
+            if constexpr (kRecQ) {                                  // the rider's step between the wide steps: its chain is one accumulator
+                if (s % KS == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s / KS], xb[s / KS], acc0, 0, 0, 0);
+            }
+        }
+        TG_FSTAMP(5)
+    }
+#if TG_F32DW_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_f32_stamps3 + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = st[k];
+    }
+#endif
+#undef TG_FSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no LDS-DMA may outlive the workgroup's LDS allocation
+    __syncthreads();
+    // ---- the row groups' partial sums (and, H = 64, the k-step phases' partial tiles) meet in LDS, added in a fixed order ----
+    constexpr int RG = 256 / H;
+    float* red = reinterpret_cast<float*>(lds_c);                       // [6][256] floats, [4][4] (g sums per wave), then [KS - 1][MT][16][64]
+    red[tid] = bsum;
+    red[256 + tid] = b0sum;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) red[(2 + a) * 256 + tid] = hacc[a];
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) red[6 * 256 + wave * 4 + a] = gsum[a];    // (every thread of a row group holds the same row sums)
+    }
+    float* tiles = red + 7 * 256;
+    if (kRecQ && KS > 1 && ks0 > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tiles[(((ks0 - 1) * MT + tile0) * 16 + r) * 64 + lane] = acc0[r];
+    }
+    __syncthreads();
+    float* slab = ws + job.slab_off + (int64_t)my * job.slab_len;
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int x = 0; x < TW; ++x)
+#pragma unroll
+        for (int y = 0; y < TW; ++y) {
+            const int m0 = 32 * (TW * wm + x), n0 = 32 * (TW * wn + y);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[x][y][r];
+        }
+    float* s1 = slab + H * H + H;                                       // first-layer rider: [H][32] + [H]
+    float* s2 = s1 + (kRecQ ? H * 32 + H : 0);                          // head rider: [4][H] + [4]
+    if (tid < H) {
+        float t[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            t[q] = red[q * 256 + tid];
+#pragma unroll
+            for (int g = 1; g < RG; ++g) t[q] += red[q * 256 + g * H + tid];
+        }
+        slab[H * H + tid] = t[0];
+        if constexpr (kRecQ) s1[H * 32 + tid] = t[1];
+        if constexpr (kRecP) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s2[a * H + tid] = t[2 + a];
+            if (tid < 4) {
+                // one wave per row group (the first of each group's waves): groups added in order
+                float gs = 0.f;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) gs += red[6 * 256 + (g * (H / 64)) * 4 + tid];
+                s2[4 * H + tid] = gs;
+            }
+        }
+    }
+    if constexpr (kRecQ) {
+        if (ks0 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc0[r];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) v += tiles[(((k - 1) * MT + tile0) * 16 + r) * 64 + lane];
+                s1[(32 * tile0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = v;
+            }
         }
     }
 }
@@ -696,10 +852,12 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
     float hacc[4] = {0.f, 0.f, 0.f, 0.f};               // head: dW_h[a][tid]
 
     if (!head && !narrow && job.recompute != 0) {
-        if (job.recompute == 3) f32_dw_wide_recompute<H, true, true>(job, rows, lds_c, acc, bsum);
-        else if (job.recompute == 2) f32_dw_wide_recompute<H, true, false>(job, rows, lds_c, acc, bsum);
-        else f32_dw_wide_recompute<H, false, true>(job, rows, lds_c, acc, bsum);
-    } else if (!head && !narrow) {
+        if (job.recompute == 3) f32_dw_fused<H, true, true>(job, rows, lds_c, ws);
+        else if (job.recompute == 2) f32_dw_fused<H, true, false>(job, rows, lds_c, ws);
+        else f32_dw_fused<H, false, true>(job, rows, lds_c, ws);
+        return;
+    }
+    if (!head && !narrow) {
         // ================= wide job: dW = P^T Q over H x H, SRW rows per stage =================
         constexpr int SR = G::SRW, D = G::WIDE_SLOTS, P_ = D - 1, NG = G::NG_WIDE;
         const int64_t n_st = (rows + SR - 1) / SR;
@@ -1088,6 +1246,9 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
 int tg_debug_f32_stamps(unsigned long long* host_out) {    /* diagnostic builds only: not part of the ABI */
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
 }
+int tg_debug_f32_stamps3(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps3), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
 int tg_debug_f32_stamps2(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps2), sizeof(unsigned long long) * 4096 * 6) == hipSuccess ? 0 : -1;
 }
@@ -1095,7 +1256,8 @@ int tg_debug_f32_stamps2(unsigned long long* host_out) {
 
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
     if (hidden != 64 && hidden != 128) return 0;
-    return (int64_t)f32_dw_max_blocks() * (hidden * hidden + hidden) * (int64_t)sizeof(float);
+    // (a fused job's slab: the layer's gradient + both riders')
+    return (int64_t)f32_dw_max_blocks() * (hidden * hidden + hidden + hidden * 32 + hidden + 4 * hidden + 4) * (int64_t)sizeof(float);
 }
 
 int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
@@ -1112,12 +1274,18 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
     // layer: 16 products per 64 rows; head: vector arithmetic) by the bytes they stream: the wide jobs share HALF the slots -- one
     // wide workgroup per CU keeps every SIMD's matrix pipe busy -- and the light jobs share the rest in proportion to their bytes
     // per row, so that a CU streams a light job beside a wide job's products.
+    // (time per row in units of one plain wide job; 0 = a light job, which shares what the wide jobs leave in proportion to its bytes)
     int64_t bytes[kF32DwMaxJobs], light_sum = 0;
+    double weight[kF32DwMaxJobs], wide_sum = 0.0;
     int n_wide = 0;
+    size_t shmem = H == 128 ? (size_t)F32DwGeom<128>::LDS_PLAIN : (size_t)F32DwGeom<64>::LDS_PLAIN;
+    int ring_slots[kF32DwMaxJobs], fused_slab[kF32DwMaxJobs];
     for (int j = 0; j < n_jobs; ++j) {
         const tg_f32_dw_job& jb = jobs[j];
         TG_REQUIRE(jb.kind == F32DW_MM || jb.kind == F32DW_HEAD, "tg_mlp_f32_weight_grad: job %d has kind %d", j, jb.kind);
         TG_REQUIRE(jb.d_p && jb.d_q && jb.d_wgrad, "tg_mlp_f32_weight_grad: job %d has a null pointer", j);
+        weight[j] = 0.0;
+        ring_slots[j] = fused_slab[j] = 0;
         if (jb.kind == F32DW_HEAD) {
             TG_REQUIRE(jb.n_cols == H && jb.m_out >= 1 && jb.m_out <= 4 && jb.n_out == H && jb.wgrad_ld >= H, "tg_mlp_f32_weight_grad: job %d: bad head window", j);
             bytes[j] = 4 * H + 16;
@@ -1125,12 +1293,31 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
             TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
             TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
             TG_REQUIRE(jb.recompute >= 0 && jb.recompute <= 3 && (jb.recompute == 0 || jb.n_cols == H), "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
-            TG_REQUIRE(!(jb.recompute & 1) || (jb.d_w0 && jb.d_b0 && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad),
-                       "tg_mlp_f32_weight_grad: job %d recomputes the first activation: first-layer weights / input width missing", j);
-            TG_REQUIRE(!(jb.recompute & 2) || (jb.d_wh && jb.d_maskbits && jb.act_dim >= 1 && jb.act_dim <= 4),
-                       "tg_mlp_f32_weight_grad: job %d recomputes the top dZ: head weights / mask bits missing", j);
+            TG_REQUIRE(!(jb.recompute & 1) || (jb.d_w0 && jb.d_b0 && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad &&
+                                               jb.d_dz0 && jb.d_w0grad && jb.d_b0grad && jb.w0grad_ld >= jb.in_dim),
+                       "tg_mlp_f32_weight_grad: job %d rebuilds the first activation: first-layer weights / input width / rider missing", j);
+            TG_REQUIRE(!(jb.recompute & 2) || (jb.d_wh && jb.d_maskbits && jb.act_dim >= 1 && jb.act_dim <= 4 && jb.d_a_top && jb.d_whgrad && jb.d_bhgrad && jb.whgrad_ld >= H),
+                       "tg_mlp_f32_weight_grad: job %d rebuilds the top dZ: head weights / mask bits / rider missing", j);
             bytes[j] = jb.n_cols == H ? 0 : 4 * H + 4 * jb.n_cols;
-            n_wide += jb.n_cols == H;
+            if (jb.n_cols == H) {
+                ++n_wide;
+                // products per stage and wave: 32 (H = 128), + 8 for the first layer's tile; the head rider is vector work
+                weight[j] = 1.0 + ((jb.recompute & 1) ? 0.25 : 0.0) + ((jb.recompute & 2) ? 0.05 : 0.0);
+                wide_sum += weight[j];
+            }
+            if (jb.recompute) {
+                auto fit = [&](auto geom) {
+                    using F = decltype(geom);
+                    ring_slots[j] = F::lds_bytes(3, jb.in_pad) <= F32DwGeom<128>::LDS_MAX ? 3 : 2;
+                    fused_slab[j] = F::SLAB;
+                    return (size_t)F::lds_bytes(ring_slots[j], jb.in_pad);
+                };
+                size_t need = 0;
+                if (H == 128) need = jb.recompute == 3 ? fit(F32FusedGeom<128, true, true>{}) : (jb.recompute == 2 ? fit(F32FusedGeom<128, true, false>{}) : fit(F32FusedGeom<128, false, true>{}));
+                else need = jb.recompute == 3 ? fit(F32FusedGeom<64, true, true>{}) : (jb.recompute == 2 ? fit(F32FusedGeom<64, true, false>{}) : fit(F32FusedGeom<64, false, true>{}));
+                TG_REQUIRE(need <= (size_t)F32DwGeom<128>::LDS_MAX, "tg_mlp_f32_weight_grad: job %d needs %zu B of LDS", j, need);
+                shmem = need > shmem ? need : shmem;
+            }
         }
         light_sum += bytes[j];
     }
@@ -1139,7 +1326,7 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
     // the fp32 matrix rate of one workgroup per CU against a light job's bytes at the ~12 GB/s one workgroup streams
     // (TG_F32DW_WIDE_PCT overrides: a tuning knob, read once)
     static const int forced_pct = [] { const char* e = getenv("TG_F32DW_WIDE_PCT"); return e ? atoi(e) : 0; }();
-    const double t_wide = n_wide * (H == 128 ? 0.085 : 0.085 / 4), t_light = (double)light_sum / 12000.0;
+    const double t_wide = wide_sum * (H == 128 ? 0.085 : 0.085 / 4), t_light = (double)light_sum / 12000.0;
     int wide_slots = 0;
     if (n_wide) {
         const double share = forced_pct > 0 ? forced_pct / 100.0 : t_wide / (t_wide + t_light);
@@ -1150,7 +1337,7 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
     const int light_slots = max_blocks - wide_slots;
     int alloc[kF32DwMaxJobs], used = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        alloc[j] = bytes[j] == 0 ? wide_slots / n_wide : (int)(bytes[j] * light_slots / light_sum);
+        alloc[j] = bytes[j] == 0 ? (int)(wide_slots * weight[j] / wide_sum) : (int)(bytes[j] * light_slots / light_sum);
         if (alloc[j] < 1) alloc[j] = 1;
         used += alloc[j];
     }
@@ -1160,6 +1347,11 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
             if (alloc[j] > alloc[big]) big = j;
         --alloc[big];
         --used;
+    }
+    {
+        int n_desc = 0;
+        for (int j = 0; j < n_jobs; ++j) n_desc += 2 + ((jobs[j].recompute & 1) ? 2 : 0) + ((jobs[j].recompute & 2) ? 2 : 0);
+        TG_REQUIRE(n_desc <= 2 * kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d gradient windows exceed %d", n_desc, 2 * kF32DwMaxJobs);
     }
     F32DwArgs args{};
     args.n_jobs = n_jobs;
@@ -1172,12 +1364,13 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         dj.p = jb.d_p; dj.q = jb.d_q; dj.kind = jb.kind; dj.n = jb.n_cols;
         dj.recompute = jb.recompute; dj.in_pad = jb.in_pad; dj.in_dim = jb.in_dim; dj.act_dim = jb.act_dim;
         dj.w0 = jb.d_w0; dj.b0 = jb.d_b0; dj.wh = jb.d_wh; dj.mask = jb.d_maskbits;
+        dj.a_top = jb.d_a_top; dj.dz0 = jb.d_dz0; dj.ring_slots = ring_slots[j];
         dj.first_block = grid;
         // at least 4 stages per workgroup
         const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H == 128 ? 16 : 32) : (H == 128 ? 32 : 64)));
         const int cap = (int)(n_st < 4 ? 1 : (n_st / 4 > 1 << 20 ? 1 << 20 : n_st / 4));
         dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;
-        dj.slab_len = f32_dw_slab_len(H, jb.kind, jb.n_cols);
+        dj.slab_len = jb.recompute ? fused_slab[j] : f32_dw_slab_len(H, jb.kind, jb.n_cols);
         dj.slab_off = off;
         grid += dj.n_blocks;
         const int Nslab = jb.kind == F32DW_HEAD ? H : (jb.n_cols <= 32 ? 32 : H);
@@ -1190,11 +1383,25 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
             fb = F32FinishDesc{(const float*)d_workspace + off + boff, jb.d_bgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.m_out, elems};
             elems += jb.m_out;
         }
+        // the riders' parts of a fused job's slab: [H x H][H] | first layer [H x 32][H] | head [4 x H][4]
+        int64_t roff = off + H * H + H;
+        if (jb.recompute & 1) {
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_w0grad, jb.w0grad_ld, dj.slab_len, dj.n_blocks, 32, H, jb.in_dim, elems};
+            elems += H * jb.in_dim;
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + H * 32, jb.d_b0grad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, H, elems};
+            elems += H;
+            roff += H * 32 + H;
+        }
+        if (jb.recompute & 2) {
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_whgrad, jb.whgrad_ld, dj.slab_len, dj.n_blocks, H, jb.act_dim, H, elems};
+            elems += jb.act_dim * H;
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + 4 * H, jb.d_bhgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.act_dim, elems};
+            elems += jb.act_dim;
+        }
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
     fa.total = elems;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shmem = H == 128 ? (size_t)F32DwGeom<128>::LDS_BYTES : (size_t)F32DwGeom<64>::LDS_BYTES;
     if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
         static LdsOptIn opt_in;

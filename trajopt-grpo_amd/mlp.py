@@ -463,24 +463,33 @@ class GemmMLP:
             assert acts[0] is not None and dzs[0] is not None
         if self._dw_ws is None:
             self._dw_ws = torch.empty(N.load().tg_mlp_f32_weight_grad_workspace(H) // 4, dtype=torch.float32, device=xp.device)
-        # (kind, P, Q, columns of Q, weight window, bias window, rows x columns of the window, recompute bits)
+        # (kind, P, Q, columns of Q, weight window, bias window, rows x columns of the window, rebuild bits)
         specs = []
+        fused = False
         for i in range(nh - 1, 0, -1):
             rp, rq = dzs[i] is None, acts[i - 1] is None           # top layer's dZ / first activation rebuilt on chip
+            fused = fused or rp or rq
             specs.append((N.TG_F32DW_MM, dout if rp else dzs[i], xp if rq else acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H,
                           (2 if rp else 0) | (1 if rq else 0)))
-        specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim, 0))
-        specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H, 0))
+        if not fused:                                               # (the rebuilding jobs carry these two as riders)
+            specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim, 0))
+            specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H, 0))
         arr = (N.F32DwJob * len(specs))()
-        for slot, (kind, p, q, ncols, wg, bg, m_out, n_out, recompute) in zip(arr, specs):
+        for slot, (kind, p, q, ncols, wg, bg, m_out, n_out, rebuild) in zip(arr, specs):
             assert wg.dtype == torch.float32 and wg.stride(1) == 1 and bg.dtype == torch.float32 and bg.is_contiguous()
             slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wg.data_ptr(), bg.data_ptr()
             slot.wgrad_ld, slot.kind, slot.n_cols, slot.m_out, slot.n_out = wg.stride(0), kind, ncols, m_out, n_out
-            slot.recompute, slot.in_pad, slot.in_dim, slot.act_dim = recompute, f.in_pad, self.in_dim, self.out_dim
-            if recompute:
-                w0, b0, wh = lin[0].weight, lin[0].bias, lin[nh].weight
-                assert w0.is_contiguous() and wh.is_contiguous() and w0.dtype == torch.float32
-                slot.d_w0, slot.d_b0, slot.d_wh, slot.d_maskbits = w0.data_ptr(), b0.data_ptr(), wh.data_ptr(), N.ptr(self._tmask)
+            slot.recompute, slot.in_pad, slot.in_dim, slot.act_dim = rebuild, f.in_pad, self.in_dim, self.out_dim
+            if rebuild & 1:                                         # rider: the first layer's gradient
+                w0, b0 = lin[0].weight, lin[0].bias
+                assert w0.is_contiguous() and w0.dtype == torch.float32 and w0.grad.stride(1) == 1 and b0.grad.is_contiguous()
+                slot.d_w0, slot.d_b0, slot.d_dz0 = w0.data_ptr(), b0.data_ptr(), dzs[0].data_ptr()
+                slot.d_w0grad, slot.d_b0grad, slot.w0grad_ld = w0.grad.data_ptr(), b0.grad.data_ptr(), w0.grad.stride(0)
+            if rebuild & 2:                                         # rider: the head's gradient
+                wh, bh = lin[nh].weight, lin[nh].bias
+                assert wh.is_contiguous() and wh.dtype == torch.float32 and wh.grad.stride(1) == 1 and bh.grad.is_contiguous()
+                slot.d_wh, slot.d_maskbits, slot.d_a_top = wh.data_ptr(), self._tmask.data_ptr(), acts[nh - 1].data_ptr()
+                slot.d_whgrad, slot.d_bhgrad, slot.whgrad_ld = wh.grad.data_ptr(), bh.grad.data_ptr(), wh.grad.stride(0)
         ev = None
         if self.dw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
