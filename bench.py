@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the T-step rollout loop as one hipGraph")
     ap.add_argument("--no-fused", action="store_true",
                     help="per-step launches (actor GEMMs + tg_rollout_step) instead of the fused persistent rollout kernel")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="time the hot kernels' launches on every N-th step of the timed region (0: every step when a step takes >= 20 ms, else every 4th)")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="do not bracket the rollout / learner launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -390,9 +392,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm_ms = 1e9                        # duration of the last warm-up step (decides how densely launches are timed below)
     for i in range(args.warmup):
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
         buf.sample()
         algo.learn(buf)
+        torch.cuda.synchronize()
+        warm_ms = 1e3 * (time.perf_counter() - w0)
         progress(f"warm-up step {i + 1}/{args.warmup}")
     # event-pair overhead (no kernel in between), for the per-launch timing below
     pairs = []
@@ -407,15 +414,26 @@ def main():
     t_roll = t_learn = 0.0
     launches = []            # (duration ms, env-steps in that launch)
     launch_units = []
-    if not args.graph and not args.no_launch_events:
-        mgr.engine.step_events = []
     nets = [policy.actor] + ([policy.critic] if algo_name == "ppo" else [])
     learner_mlps = [m for m in (algo._mlp(n_) for n_ in nets) if m is not None]
-    for m in (learner_mlps if not args.no_launch_events else []):
-        m.dx_events, m.dw_events, m.fwd_events = [], [], []     # HIP-event pairs around every learner-kernel launch
+    # HIP-event pairs around every hot-kernel launch.  An event is a packet on the queue (~6 us between two kernels): on a step
+    # of a few milliseconds (C2: ~45 timed launches in 3.5 ms) timing EVERY launch of EVERY step slows the step by 8 %, so such
+    # steps are timed on every `event_every`-th step of the timed region; steps >= 20 ms (C3) time all of them.
+    event_every = args.event_every if args.event_every > 0 else (1 if warm_ms >= 20.0 else 4)
+    event_lists = {id(m): ([], [], []) for m in learner_mlps}
+    timed_steps = 0
+
+    def set_events(on):
+        mgr.engine.step_events = [] if (on and not args.graph) else None
+        for m in learner_mlps:
+            m.dx_events, m.dw_events, m.fwd_events = event_lists[id(m)] if on else (None, None, None)
+
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        timed = not args.no_launch_events and _ % event_every == 0
+        set_events(timed)
+        timed_steps += timed
         r0 = time.perf_counter()
         buf.sample()                        # ends with a host read of avg_reward -> rollout is complete here
         r1 = time.perf_counter()
@@ -432,10 +450,13 @@ def main():
         algo.learn(buf)
         torch.cuda.synchronize()            # (learn's last kernels; the next rollout would wait for them anyway)
         t_learn += time.perf_counter() - r1
+        if os.environ.get("TG_BENCH_STEP_TIMES"):
+            print(f"step {_} timed={timed} sample {1e3 * (r1 - r0):.3f} ms learn {1e3 * (time.perf_counter() - r1):.3f} ms", file=sys.stderr, flush=True)
         if (_ + 1) % 5 == 0:
             progress(f"step {_ + 1}/{args.steps}")
     barrier()
     dt = time.perf_counter() - t0
+    set_events(not args.no_launch_events)       # (the lists the code below reads)
 
     fam_launches = {"bwd": [], "dw": [], "fwd": []}     # (ms, algorithmic bytes, rows, kernel name) per launch
     for m in learner_mlps:
@@ -524,6 +545,7 @@ def main():
                        "parallelism": f"env-shard x{world} (whole groups per rank), 1 grad all-reduce per optimizer step"},
             "rollout_only_env_steps_per_s": total_steps / t_roll if t_roll > 0 else None,
             "rollout_ms": 1e3 * t_roll / args.steps,
+            "launch_events": None if args.no_launch_events else {"every_nth_step": event_every, "timed_steps": timed_steps},
             "env_steps_per_step": total_steps / args.steps,
             # fixed work: independent of how long the policy survives (the number of valid rows grows as it learns)
             "update_ns_per_valid_row": 1e9 * t_learn * world / total_steps if total_steps else None,
@@ -589,7 +611,7 @@ def main():
                 kernels[fam] = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                                 "kernel": ls[0][3], "flops_per_row": nflop / nrows, "launches": len(ls),
                                 "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
-                                "total_ms_per_step": 1e3 * dur / args.steps,
+                                "total_ms_per_step": 1e3 * dur / max(timed_steps, 1),
                                 "note": {"fwd": "tg_mlp_f32_forward_backward: forward + loss head + backward-data pass of every row in one launch; "
                                                 "flops = matrix-core products only (first layer + 2 x the H x H layers; the <= 4-output head runs on the vector unit)",
                                          "dw": "tg_mlp_f32_weight_grad: every weight / bias gradient of the net in one launch; flops = the H x H layers' "
@@ -613,7 +635,7 @@ def main():
                                               "this run's average rows per launch" if pmc else None,
                             "kernel": ls[0][3], "bytes_per_row": nbytes / nrows, "launches": len(ls),
                             "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
-                            "total_ms_per_step": 1e3 * dur / args.steps, "note": notes[fam]}
+                            "total_ms_per_step": 1e3 * dur / max(timed_steps, 1), "note": notes[fam]}
         if kernels:
             top = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
             out["roofline"] = dict(kernels[top], family=top,

@@ -31,12 +31,17 @@ print(shape, rows, "weight_grad %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
 if os.environ.get("STAMPS"):
     import ctypes, numpy as np
     raw = ctypes.CDLL(os.environ["TG_NATIVE_LIB"])
-    buf = (ctypes.c_ulonglong * (4096 * 8))()
+    buf = (ctypes.c_ulonglong * (4096 * 12))()
     assert raw.tg_debug_f32_stamps3(buf) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 12).astype(np.float64)
     a = a[a[:, 6] > 0]
     per = a[:, :6] / a[:, 6:7]
     print("waves", len(a), "stages/wave %.1f" % a[:, 6].mean())
     print("cycles per stage: wait+barrier %.0f  issue %.0f  phase1 %.0f  barrier %.0f  operand reads %.0f  products %.0f  | sum %.0f" % (*per.mean(0), per.mean(0).sum()))
     for w in range(4):
         print(" wave", w, np.round(per[w::4].mean(0)))
+    t0 = a[:, 7].min()
+    print("memtime: entry spread %.0f, entry->loop %.0f, loop %.0f, loop end->exit %.0f, last exit - first entry %.0f cycles" % (
+        a[:, 7].max() - t0, (a[:, 8] - a[:, 7]).mean(), (a[:, 9] - a[:, 8]).mean(), (a[:, 10] - a[:, 9]).mean(), a[:, 10].max() - t0))
+    clk = ((a[:, 10] - a[:, 7]) / (a[:, 11] * 10.0))
+    print("per-wave kernel time (100 MHz realtime) mean %.1f us max %.1f us; in-kernel clock %.3f GHz" % (a[:, 11].mean() / 100.0, a[:, 11].max() / 100.0, clk.mean()))

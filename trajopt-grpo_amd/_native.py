@@ -181,6 +181,11 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def event_pair():
+    """Two timing events for one launch (profiling runs: bench.py)."""
+    return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+
 def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 

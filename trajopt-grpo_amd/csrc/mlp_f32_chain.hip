@@ -471,7 +471,7 @@ struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 __device__ uint4 g_f32_zero16;
 #if TG_F32DW_STAMPS
 __device__ unsigned long long g_f32_stamps[4096 * 4];      // per wave: cycles in [wait + bias][arrive][products + reads], stages
-__device__ unsigned long long g_f32_stamps3[4096 * 8];     // fused job, per wave: cycles in [wait + barrier][issue][phase 1][barrier][operand reads][products], stages
+__device__ unsigned long long g_f32_stamps3[4096 * 12];     // fused job, per wave: cycles in [wait + barrier][issue][phase 1][barrier][operand reads][products], stages
 __device__ unsigned long long g_f32_stamps2[4096 * 6];     // per wave: s_memtime at entry / loop start / loop end / exit, s_memrealtime at entry / exit
 #endif                             // 16 zero bytes: the source of an image's padding lanes
 
@@ -546,6 +546,10 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
     using F = F32FusedGeom<H, kRecP, kRecQ>;
     constexpr int MT = H / 32, TW = MT >= 4 ? 2 : 1;
     constexpr int SR = F::SR, NG = F::NG;
+#if TG_F32DW_STAMPS
+    const unsigned long long fs_entry = __builtin_amdgcn_s_memtime(), fs_rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long fs_loop0 = 0, fs_loop1 = 0;
+#endif
     constexpr int KS = 4 / MT;                                          // the first layer's tile: k-steps split over KS waves (H = 64: 2)
     static_assert(SR / (256 / H) == 8, "a thread rebuilds 8 rows of one feature per stage");
     const int D = job.ring_slots;                                       // 2 or 3 (host: what fits 79 KiB)
@@ -623,6 +627,7 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
     const int tile0 = wave % MT, ks0 = wave / MT;                       // first-layer rider: this wave's tile and k-step phase
 #if TG_F32DW_STAMPS
     unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+    fs_loop0 = __builtin_amdgcn_s_memtime();
 #define TG_FSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - st_t; st_t = now_; }
 #else
 #define TG_FSTAMP(k)
@@ -747,11 +752,7 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
         TG_FSTAMP(5)
     }
 #if TG_F32DW_STAMPS
-    if (lane == 0 && blockIdx.x < 1024) {
-        unsigned long long* o = g_f32_stamps3 + ((size_t)blockIdx.x * 4 + wave) * 8;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) o[k] = st[k];
-    }
+    fs_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 #undef TG_FSTAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -818,6 +819,14 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
             }
         }
     }
+#if TG_F32DW_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_f32_stamps3 + ((size_t)blockIdx.x * 4 + wave) * 12;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = st[k];
+        o[7] = fs_entry; o[8] = fs_loop0; o[9] = fs_loop1; o[10] = __builtin_amdgcn_s_memtime(); o[11] = __builtin_amdgcn_s_memrealtime() - fs_rt0;
+    }
+#endif
 }
 
 template <int H>
@@ -1247,7 +1256,7 @@ int tg_debug_f32_stamps(unsigned long long* host_out) {    /* diagnostic builds 
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
 }
 int tg_debug_f32_stamps3(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps3), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps3), sizeof(unsigned long long) * 4096 * 12) == hipSuccess ? 0 : -1;
 }
 int tg_debug_f32_stamps2(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_f32_stamps2), sizeof(unsigned long long) * 4096 * 6) == hipSuccess ? 0 : -1;

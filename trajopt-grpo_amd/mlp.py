@@ -296,7 +296,7 @@ class GemmMLP:
             mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits]) if keep else None
             ev = None
             if keep and self.fwd_events is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev = N.event_pair()
                 ev[0].record()
             N.check(N.load().tg_mlp_forward_chain(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H,
                                                   L - 1, rows, ptrs, mptrs, out.data_ptr(), oc,
@@ -378,7 +378,7 @@ class GemmMLP:
         mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits])
         ev = None
         if self.fwd_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         N.check(lib.tg_mlp_forward_chain_loss(xp.data_ptr(), self._chain.stream.data_ptr(), self._chain.bias.data_ptr(), H, L - 1,
                                               rows, ptrs, mptrs, N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_forward_chain_loss")
@@ -443,7 +443,7 @@ class GemmMLP:
         zptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
         ev = None
         if self.fwd_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.ptr(tmask),
                                                 N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
@@ -492,7 +492,7 @@ class GemmMLP:
                 slot.d_whgrad, slot.d_bhgrad, slot.whgrad_ld = wh.grad.data_ptr(), bh.grad.data_ptr(), wh.grad.stride(0)
         ev = None
         if self.dw_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         N.check(N.load().tg_mlp_f32_weight_grad(H, arr, len(specs), rows, self._dw_ws.data_ptr(),
                                                 self._dw_ws.numel() * 4, N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
@@ -591,7 +591,7 @@ class GemmMLP:
                 self._w0_slabs = torch.empty(2 * lib.tg_mlp_backward_chain_blocks() * H * 32, dtype=torch.float32, device=device)
         ev = None
         if self.dx_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         if fuse0:
             n_slabs = N.C.c_int32(0)
@@ -628,7 +628,7 @@ class GemmMLP:
             jobs.append((N.TG_DW_HX, dzs[nh - 1], acts[0], lin[0].weight.grad, lin[0].bias.grad))
         ev = None
         if self.dw_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0], self._bchain.stream)
         if ev is not None:
@@ -684,7 +684,7 @@ class GemmMLP:
                 dz_below = torch.empty_like(a)
                 ev = None
                 if self.dx_events is not None:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev = N.event_pair()
                     ev[0].record()
                 mb = bits[i + 1]
                 N.check(lib.tg_dx_relu_bias(dz.data_ptr(), frag.data_ptr(), a.data_ptr(), None if mb is None else mb.data_ptr(),

@@ -232,7 +232,7 @@ class DeviceRollout:
         n_hidden = len(self._linears) - 1
         ev = None
         if self.step_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = N.event_pair()
             ev[0].record()
         if self._fused_f32:
             N.check(lib.tg_fused_rollout_f32(C.byref(self.params), C.byref(tr), self._frag.stream.data_ptr(),
@@ -260,13 +260,13 @@ class DeviceRollout:
             if sample:
                 mean = self._actor_mean(t)
                 if self.step_events is not None:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev = N.event_pair()
                     ev[0].record()
                 N.check(lib.tg_rollout_step(p, C.byref(tr), t, mean.data_ptr(), mean.stride(0), self._sigma,
                                             self.rng.data_ptr(), env_offset, st), "tg_rollout_step")
             else:
                 if self.step_events is not None:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev = N.event_pair()
                     ev[0].record()
                 N.check(lib.tg_rollout_step(p, C.byref(tr), t, None, 0, None, None, env_offset, st), "tg_rollout_step")
             if ev is not None:
