@@ -1115,48 +1115,80 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 // grad[m][n] += sum over the job's slabs, in a fixed order.
 struct F32FinishDesc {
     const float* slab; float* grad; int64_t grad_ld;
-    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
+    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;     // first_elem: in UNITS (below) once the launcher has laid them out
+    int32_t vec;                                                // a unit = 4 consecutive floats of a row (else 1 float)
 };
 struct F32FinishArgs { F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total; };
 
-// A workgroup = 32 consecutive output elements x 8 slab chunks: thread (el, c) adds slabs c, c + 8, ... of its element (8 loads in
-// flight), the 8 chunk sums meet in LDS and are added in chunk order: a fixed order whatever the launch, and ~400 slabs of 64 KB
-// are read at memory speed (one thread per element walking all of them was a 100-us chain of dependent loads).
+// A workgroup = 32 consecutive output units x 8 slab chunks: thread (el, c) adds slabs c, c + 8, ... of its unit (8 loads in
+// flight), the 8 chunk sums meet in LDS and are added in chunk order: a fixed order whatever the launch, and ~500 slabs of 64-85 KB
+// are read at memory speed (one thread per element walking all of them was a 100-us chain of dependent loads).  A unit is a float4
+// where the window allows it (the H x H gradients: 512 contiguous bytes per workgroup and slab instead of 128).
 __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa) {
-    __shared__ float part[8][32];
+    __shared__ float4 part[8][32];
     const int el = threadIdx.x & 31, c = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
-    float sum = 0.f;
+    float4 sum = float4{0.f, 0.f, 0.f, 0.f};
     float* dst = nullptr;
+    bool vec = false;
     if (e < fa.total) {
         int k = 0;
 #pragma unroll
         for (int t = 1; t < 2 * kF32DwMaxJobs; ++t)
             if (t < fa.n && e >= fa.d[t].first_elem) k = t;
         const F32FinishDesc d = fa.d[k];
-        const int le = e - d.first_elem;
+        vec = d.vec != 0;
+        const int le = (e - d.first_elem) * (vec ? 4 : 1);
         const int m = le / d.n_out, n = le - m * d.n_out;
         const float* src = d.slab + (int64_t)m * d.N + n;
         dst = d.grad + (int64_t)m * d.grad_ld + n;
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int b = c;
-        for (; b + 56 < d.n_slabs; b += 64) {               // slabs b, b + 8, ..., b + 56
-            float v[8];
+        if (vec) {
+            float4 s[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 8 * u) * d.slab_len];
+            for (int u = 0; u < 8; ++u) s[u] = float4{0.f, 0.f, 0.f, 0.f};
+            for (; b + 56 < d.n_slabs; b += 64) {           // slabs b, b + 8, ..., b + 56
+                float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += v[u];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(b + 8 * u) * d.slab_len);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+            }
+            for (; b < d.n_slabs; b += 8) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)b * d.slab_len);
+                s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+            }
+            sum.x = ((s[0].x + s[1].x) + (s[2].x + s[3].x)) + ((s[4].x + s[5].x) + (s[6].x + s[7].x));
+            sum.y = ((s[0].y + s[1].y) + (s[2].y + s[3].y)) + ((s[4].y + s[5].y) + (s[6].y + s[7].y));
+            sum.z = ((s[0].z + s[1].z) + (s[2].z + s[3].z)) + ((s[4].z + s[5].z) + (s[6].z + s[7].z));
+            sum.w = ((s[0].w + s[1].w) + (s[2].w + s[3].w)) + ((s[4].w + s[5].w) + (s[6].w + s[7].w));
+        } else {
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (; b + 56 < d.n_slabs; b += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 8 * u) * d.slab_len];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += v[u];
+            }
+            for (; b < d.n_slabs; b += 8) s[0] += src[(int64_t)b * d.slab_len];
+            sum.x = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
         }
-        for (; b < d.n_slabs; b += 8) s[0] += src[(int64_t)b * d.slab_len];
-        sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     part[c][el] = sum;
     __syncthreads();
     if (c == 0 && dst) {
-        float t = part[0][el];
+        float4 t = part[0][el];
 #pragma unroll
-        for (int u = 1; u < 8; ++u) t += part[u][el];
-        *dst += t;
+        for (int u = 1; u < 8; ++u) { t.x += part[u][el].x; t.y += part[u][el].y; t.z += part[u][el].z; t.w += part[u][el].w; }
+        if (vec) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            float4 g = *d4;
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            *d4 = g;
+        } else {
+            *dst += t.x;
+        }
     }
 }
 
@@ -1409,7 +1441,17 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         }
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
-    fa.total = elems;
+    // lay the windows out in units: float4 where a window's rows are contiguous and 16-B aligned in the slab and in the gradient
+    int units = 0;
+    for (int k = 0; k < fa.n; ++k) {
+        F32FinishDesc& d = fa.d[k];
+        const int cnt = d.m_out * d.n_out;
+        d.vec = (d.n_out % 4 == 0 && (d.m_out == 1 || (d.N == d.n_out && d.grad_ld % 4 == 0)) && d.slab_len % 4 == 0 &&
+                 ((uintptr_t)d.slab & 15) == 0 && ((uintptr_t)d.grad & 15) == 0) ? 1 : 0;
+        d.first_elem = units;
+        units += d.vec ? cnt / 4 : cnt;
+    }
+    fa.total = units;
     hipStream_t st = (hipStream_t)stream;
     if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
@@ -1423,7 +1465,7 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, st, args, rows, (float*)d_workspace);
     }
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad");
-    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(units, 32)), dim3(256), 0, st, fa);
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad (finish)");
     return TG_OK;
 }
