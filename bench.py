@@ -428,6 +428,12 @@ def main():
         for m in learner_mlps:
             m.dx_events, m.dw_events, m.fwd_events = event_lists[id(m)] if on else (None, None, None)
 
+    # Phase split of a step on the GPU's own timeline: one event at the start of the step, one after sample() has enqueued the
+    # rollout, one after learn() has enqueued the update.  The host is NOT synchronised between steps: the learner reads its loss
+    # statistics lazily, so the next rollout is enqueued while the last updates still run (the timed region is bracketed by a
+    # barrier + synchronize on both sides, as the contract says).
+    phase_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    step_units = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -435,28 +441,32 @@ def main():
         set_events(timed)
         timed_steps += timed
         r0 = time.perf_counter()
-        buf.sample()                        # ends with a host read of avg_reward -> rollout is complete here
+        phase_ev[_][0].record()
+        buf.sample()
+        phase_ev[_][1].record()
         r1 = time.perf_counter()
-        t_roll += r1 - r0
-        env_steps += buf.device_traj.env_steps()
+        n_steps_now = buf.device_traj.env_steps()
+        env_steps += n_steps_now
+        step_units.append(n_steps_now)
         if mgr.engine.step_events:
             if mgr.engine.fused:
-                launches += [(a.elapsed_time(b), buf.device_traj.env_steps()) for _, a, b in mgr.engine.step_events]
-                launch_units.append(buf.device_traj.env_steps())
+                launches += [(a.elapsed_time(b), n_steps_now) for _k, a, b in mgr.engine.step_events]
+                launch_units.append(n_steps_now)
             else:
                 alive = buf.device_traj.mask.sum(1, dtype=torch.int64).tolist()
                 launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
             mgr.engine.step_events = []
         algo.learn(buf)
-        torch.cuda.synchronize()            # (learn's last kernels; the next rollout would wait for them anyway)
-        t_learn += time.perf_counter() - r1
+        phase_ev[_][2].record()
         if os.environ.get("TG_BENCH_STEP_TIMES"):
-            print(f"step {_} timed={timed} sample {1e3 * (r1 - r0):.3f} ms learn {1e3 * (time.perf_counter() - r1):.3f} ms", file=sys.stderr, flush=True)
+            print(f"step {_} timed={timed} sample {1e3 * (r1 - r0):.3f} ms (host) learn enqueue {1e3 * (time.perf_counter() - r1):.3f} ms (host)", file=sys.stderr, flush=True)
         if (_ + 1) % 5 == 0:
             progress(f"step {_ + 1}/{args.steps}")
     barrier()
     dt = time.perf_counter() - t0
     set_events(not args.no_launch_events)       # (the lists the code below reads)
+    t_roll = sum(e[0].elapsed_time(e[1]) for e in phase_ev) * 1e-3
+    t_learn = sum(e[1].elapsed_time(e[2]) for e in phase_ev) * 1e-3
 
     fam_launches = {"bwd": [], "dw": [], "fwd": []}     # (ms, algorithmic bytes, rows, kernel name) per launch
     for m in learner_mlps:

@@ -1895,6 +1895,37 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monke
             assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (form, i, rows)
 
 
+def test_rollout_register_stream_is_rebuilt_by_the_step_launch(tg, dev):
+    """The fused fp32 rollout's weight stream (mlp.RegisterStreamF32) rides on the launch that rebuilds the learner's layouts after
+    every optimizer step (optim.StreamRefresher): after learn() it holds exactly the bytes its own refresh() builds, the next
+    rollout skips that refresh, and any write to the policy through torch makes it stale again."""
+    torch.manual_seed(5)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=64), pol, num_workers=8, num_episodes_per_worker=32, seed=3)
+    assert mgr.engine.fused and mgr.engine._fused_f32
+    buf = tg.Rollout_Buffer(mgr)
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), updates_per_iter=3)
+    buf.sample()
+    frag = mgr.engine._frag
+    w_before = frag.stream.clone()
+    algo.learn(buf)
+    assert bool(algo._fused_adam) and algo._rollout_stream is frag and frag.is_fresh()
+    s, t = frag.stream.clone(), frag.table.clone()
+    assert not torch.equal(s, w_before)
+    calls = []
+    plain = frag.refresh
+    frag.refresh = lambda: (calls.append(1), plain())[1]
+    buf.sample()                                            # no refresh of its own
+    assert not calls
+    frag._refresh()
+    assert torch.equal(frag.stream, s) and torch.equal(frag.table, t)
+    with torch.no_grad():
+        next(pol.actor.parameters()).mul_(1.0)              # a write through torch (version counter)
+    assert not frag.is_fresh()
+    buf.sample()
+    assert calls == [1] and frag.is_fresh()
+
+
 def test_c2_size_grpo_learn_matches_the_oracle(tg, dev):
     """BASELINE configs[1] at full size on the product path: CartPole GRPO, 4,096 envs (64 groups x 64), fp32 5-128-128-1 -- fused
     fp32 rollout, fp32 chain learner, fused optimizer step -- against the CPU oracle's GRPO step (algorithms/grpo.py:50-148 restated,

@@ -181,6 +181,11 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# Bumped by every launch that writes parameters through raw pointers (optim.FusedAdam.step): torch's own version counters do not
+# see those writes, so anything that caches a function of the weights keys its freshness on (versions, this counter).
+RAW_PARAM_WRITES = [0]
+
+
 def event_pair():
     """Two timing events for one launch (profiling runs: bench.py)."""
     return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

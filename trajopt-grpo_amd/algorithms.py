@@ -96,13 +96,47 @@ class _GpuLearner(Algorithm):
         self._refresher = None
         self._mlps = {}
         self._ws = M._Workspace()       # per-iteration tensors whose size follows the number of valid rows
-        self.last_stats = {}
+        self._stats, self._stats_pending = {}, None
 
     def learn(self, buffer) -> None:
         """One training iteration on `buffer` (algorithms/grpo.py:50-148, ppo.py:64-186).  The native kernels are
         launched through ctypes on the policy's device: make it the current one for the duration."""
         with torch.cuda.device(self.policy.device):
+            # the fused fp32 rollout's weight stream of THIS policy's actor, if the buffer's manager has one: rebuilt by the launch
+            # that follows every optimizer step, so the next rollout starts without a refresh of its own
+            frag = getattr(getattr(getattr(buffer, "rollout_manager", None), "engine", None), "_frag", None)
+            ok = hasattr(frag, "segments") and getattr(frag, "lin", None) == [m for m in self.policy.actor.network if isinstance(m, torch.nn.Linear)]
+            self._rollout_stream = frag if ok else None
             self._learn(buffer)
+
+    @property
+    def last_stats(self) -> dict:
+        """Loss statistics of the last learn() as Python numbers.  They are read from the device when first asked for, not at the
+        end of learn(): the host goes on to enqueue the next rollout while the last updates still run."""
+        if self._stats_pending is not None:
+            self._stats, self._stats_pending = self._stats_pending(), None
+        return self._stats
+
+    @last_stats.setter
+    def last_stats(self, value) -> None:
+        self._stats, self._stats_pending = value, None
+
+    @torch.no_grad()
+    def _copy_policy_to_old(self) -> None:
+        """old_policy <- policy (grpo.py:148, ppo.py:186) as ONE multi-tensor copy when the two state dicts line up (they are
+        deep copies of each other), else through load_state_dict."""
+        def leaves(d):                                                      # (the actor-critic's state dict nests one per net)
+            out = []
+            for v in d.values():
+                out += leaves(v) if isinstance(v, dict) else [v]
+            return out
+
+        src, dst = leaves(self.policy.state_dict()), leaves(self.old_policy.state_dict())
+        if len(src) == len(dst) and all(torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype
+                                        and a.device == b.device for a, b in zip(src, dst)):
+            torch._foreach_copy_(dst, src)
+        else:
+            self.old_policy.load_state_dict(self.policy.state_dict())
 
     def sync_old_policy(self) -> None:
         """old_policy <- policy.  The constructors deep-copy the policy BEFORE a checkpoint is loaded into it
@@ -141,9 +175,10 @@ class _GpuLearner(Algorithm):
             self.optimizer.step()
         self._refresh(*nets)
         if stepped:
-            key = tuple(id(n) for n in nets)
+            extra = [x for x in (getattr(self, "_rollout_stream", None),) if x is not None]
+            key = tuple(id(n) for n in nets) + tuple(id(x) for x in extra)
             if self._refresher is None or self._refresher[0] != key:
-                self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets]))
+                self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets], extra))
             self._refresher[1].run()
 
     def _prep(self, net, X, cap_rows=0):
@@ -248,11 +283,11 @@ class GRPO(_GpuLearner):
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
             self._optimizer_step(actor)
             Js.append(sums)
-        self.old_policy.load_state_dict(self.policy.state_dict())           # grpo.py:148
+        self._copy_policy_to_old()                                          # grpo.py:148
         if Js:
             allJ = torch.stack(Js)
             D.allreduce_sum_(allJ, self.process_group)
-            self.last_stats = {"J": (allJ[:, 0] / G_global).tolist(), "n_valid": allJ[0, 3].item()}
+            self._stats_pending = lambda: {"J": (allJ[:, 0] / G_global).tolist(), "n_valid": allJ[0, 3].item()}
 
     def save(self, path: str) -> None:
         torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pth"))   # grpo.py:154
@@ -379,7 +414,7 @@ class PPO(_GpuLearner):
                     b = perm[k * local_bs:(k + 1) * local_bs]
                     self._step(xin.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
                                ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums)
-        self.old_policy.load_state_dict(self.policy.state_dict())           # ppo.py:186
+        self._copy_policy_to_old()                                          # ppo.py:186
         if all_sums:
             S = torch.stack(all_sums)
             D.allreduce_sum_(S, self.process_group)
@@ -389,8 +424,8 @@ class PPO(_GpuLearner):
             critic = (S[:, 1] / nn)
             kl = (S[:, 2] / nn)
             total = actor + self.c1 * critic - self.entropy * ent + self.kl_coeff * kl
-            self.last_stats = {"actor_loss": actor.tolist(), "critic_loss": critic.tolist(), "kl_div": kl.tolist(),
-                               "total_loss": total.tolist(), "entropy": ent, "n_valid": n_global}
+            self._stats_pending = lambda: {"actor_loss": actor.tolist(), "critic_loss": critic.tolist(), "kl_div": kl.tolist(),
+                                           "total_loss": total.tolist(), "entropy": ent, "n_valid": n_global}
 
     def metadata(self) -> dict:
         return {"algorithm": "PPO", "epsilon": self.epsilon, "c1": self.c1, "kl_coeff": self.kl_coeff,

@@ -872,10 +872,55 @@ class RegisterStreamF32:
         self._wflat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.stream = torch.empty(self._idx.numel(), dtype=torch.float32, device=dev)
         self.table = torch.zeros(n_hidden * H + 4 * H + 4, dtype=torch.float32, device=dev)
+        self._fresh_key = None
         self.refresh()
 
-    @torch.no_grad()
+    def _key(self):
+        """What the stream is a function of: the parameters' storage and torch version counters, and the count of raw-pointer
+        parameter writes (the fused Adam launch bypasses the version counters)."""
+        return (tuple((p.data_ptr(), p._version) for l in self.lin for p in (l.weight, l.bias)), N.RAW_PARAM_WRITES[0])
+
+    def mark_fresh(self) -> None:
+        self._fresh_key = self._key()
+
+    def is_fresh(self) -> bool:
+        return self._fresh_key == self._key()
+
+    def segments(self, tensor_ids):
+        """The stream and the table as tg_gather_streams segments: [(dst, int32 code per element, is_bf16)], code = master tensor
+        << 24 | offset, -1 = zero (optim.StreamRefresher: rebuilt in the launch that follows an optimizer step)."""
+        H, lin = self.H, self.lin
+        n_hidden = len(lin) - 1
+        flat = torch.full((self._wflat.numel(),), -1, dtype=torch.int64)
+        off = 0
+        for l, k in zip(lin[:-1], self._k):
+            gi, ti = tensor_ids[id(l.weight)]
+            assert gi == 0
+            r, c = torch.arange(H).view(H, 1), torch.arange(k).view(1, k)
+            flat[off:off + H * k] = torch.where(c < l.in_features, (ti << 24) + r * l.in_features + c, -1).reshape(-1)
+            off += H * k
+        dev = self.stream.device
+        s_codes = flat[self._idx.cpu()].to(torch.int32).to(dev)
+        t = torch.full((self.table.numel(),), -1, dtype=torch.int64)
+        for li, l in enumerate(lin[:-1]):
+            gi, ti = tensor_ids[id(l.bias)]
+            assert gi == 0
+            t[li * H:(li + 1) * H] = (ti << 24) + torch.arange(H)
+        head = lin[-1]
+        gi, tw = tensor_ids[id(head.weight)]
+        gi2, tb = tensor_ids[id(head.bias)]
+        assert gi == 0 and gi2 == 0
+        for a in range(head.out_features):
+            t[n_hidden * H + a * H:n_hidden * H + (a + 1) * H] = (tw << 24) + a * H + torch.arange(H)
+            t[n_hidden * H + 4 * H + a] = (tb << 24) + a
+        return [(self.stream, s_codes, 0), (self.table, t.to(torch.int32).to(dev), 0)]
+
     def refresh(self):
+        self._refresh()
+        self.mark_fresh()
+
+    @torch.no_grad()
+    def _refresh(self):
         H, off = self.H, 0
         n_hidden = len(self.lin) - 1
         for l, k in zip(self.lin[:-1], self._k):

@@ -106,6 +106,7 @@ class FusedAdam:
             with torch.cuda.device(dev):
                 N.check(lib.tg_adam_step(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
                                          N.stream_ptr(dev)), "tg_adam_step")
+        N.RAW_PARAM_WRITES[0] += 1
         return True
 
 
@@ -113,8 +114,11 @@ class StreamRefresher:
     """All derived weight layouts of a set of GemmMLPs rebuilt from the fp32 masters in ONE launch (tg_gather_streams).  Built
     against a FusedAdam's tensor table (the masters' pointers); rebuilt when that table changes."""
 
-    def __init__(self, adam: FusedAdam, mlps):
+    def __init__(self, adam: FusedAdam, mlps, extra_streams=()):
+        """extra_streams: objects with segments(tensor_ids) -> [(dst, int32 codes, is_bf16)] and mark_fresh() (the fused fp32
+        rollout's register stream: the next rollout then starts without a refresh of its own)."""
         self.adam, self.mlps = adam, [m for m in mlps if m is not None]
+        self.extra = [x for x in extra_streams if x is not None]
         self._sig = None
         self._seg = None
 
@@ -159,6 +163,13 @@ class StreamRefresher:
                 keep.append(code)
                 first += dst.numel()
                 dev = dst.device
+        for x in self.extra:
+            for dst, code, is_bf16 in x.segments({k: v for k, v in self.adam.tensor_ids.items()}):
+                assert code.numel() == dst.numel() and dst.is_contiguous() and code.dtype == torch.int32
+                segs.append([dst.data_ptr(), code.data_ptr(), first, is_bf16])
+                keep.append(code)
+                first += dst.numel()
+                dev = dst.device
         if not segs or len(segs) > 32:
             return False
         self._seg = (torch.tensor(segs, dtype=torch.int64).to(dev), len(segs), first, keep, dev)
@@ -177,4 +188,6 @@ class StreamRefresher:
             N.check(N.load().tg_gather_streams(seg.data_ptr(), n, total, tab.data_ptr(), N.stream_ptr(dev)), "tg_gather_streams")
         for m, what in self._marks:
             m._stale.discard(what)
+        for x in self.extra:
+            x.mark_fresh()
         return True

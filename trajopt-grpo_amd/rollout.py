@@ -227,8 +227,8 @@ class DeviceRollout:
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
         if self._frag is None:
             self._frag = (M.RegisterStreamF32 if self._fused_f32 else M.FragmentStream)(self.policy.actor, self._fused_H)
-        else:
-            self._frag.refresh()                                  # weights change every learn()
+        elif not getattr(self._frag, "is_fresh", lambda: False)():
+            self._frag.refresh()                                  # weights change every learn() (unless its last launch rebuilt this stream)
         n_hidden = len(self._linears) - 1
         ev = None
         if self.step_events is not None:
