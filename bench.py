@@ -445,7 +445,9 @@ def main():
         buf.sample()
         phase_ev[_][1].record()
         r1 = time.perf_counter()
-        n_steps_now = buf.device_traj.env_steps()
+        algo.learn(buf)
+        phase_ev[_][2].record()
+        n_steps_now = buf.device_traj.env_steps()           # (on the host since learn() asked for it: no wait here)
         env_steps += n_steps_now
         step_units.append(n_steps_now)
         if mgr.engine.step_events:
@@ -456,8 +458,6 @@ def main():
                 alive = buf.device_traj.mask.sum(1, dtype=torch.int64).tolist()
                 launches += [(a.elapsed_time(b), alive[t]) for t, a, b in mgr.engine.step_events]
             mgr.engine.step_events = []
-        algo.learn(buf)
-        phase_ev[_][2].record()
         if os.environ.get("TG_BENCH_STEP_TIMES"):
             print(f"step {_} timed={timed} sample {1e3 * (r1 - r0):.3f} ms (host) learn enqueue {1e3 * (time.perf_counter() - r1):.3f} ms (host)", file=sys.stderr, flush=True)
         if (_ + 1) % 5 == 0:

@@ -211,7 +211,12 @@ class _GpuLearner(Algorithm):
 
     def _gather_valid(self, traj):
         """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
-        idx = traj.mask.reshape(-1).nonzero().squeeze(1)
+        flat = traj.mask.reshape(-1)
+        if traj.host_valid_rows is not None and hasattr(torch, "nonzero_static"):
+            # the count is on the host already (it rode on the rollout's statistics): no host-device round trip for the shape
+            idx = torch.nonzero_static(flat, size=int(traj.host_valid_rows())).squeeze(1)
+        else:
+            idx = flat.nonzero().squeeze(1)
         rows_all, cap = traj.obs_rows(), traj.T * traj.n
         if rows_all.dtype == torch.float32:
             X = torch.index_select(rows_all, 0, idx, out=self._ws.get("X", idx.numel(), traj.S, torch.float32, idx.device, cap))

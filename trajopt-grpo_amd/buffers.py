@@ -36,7 +36,9 @@ class Rollout_Buffer(Buffer):
         self._ref = None                     # cached reference-layout CPU tensors
         self._ref_limits = (None, None)      # (max_groups, max_episodes) of the lazy reference view; None = everything
         self._ref_is_full = False
-        self.avg_reward = []
+        self._avg_reward = []
+        self._pending = None                 # (pinned f64 [3] = reward sum, env count, local valid rows; event) of the last sample()
+        self._stats_host = None
         self.fig = None
         self.axs = None
 
@@ -85,16 +87,53 @@ class Rollout_Buffer(Buffer):
         self.avg_reward = np.atleast_1d(np.loadtxt(os.path.join(path, "reward.csv"), delimiter=",")).tolist()
         return len(self.avg_reward)
 
+    # ---- avg_reward: the reference's list of per-iteration averages (rollout_buffer.py:70), resolved lazily ----------------
+    @property
+    def avg_reward(self):
+        self._resolve()
+        return self._avg_reward
+
+    @avg_reward.setter
+    def avg_reward(self, value):
+        self._pending = None
+        self._avg_reward = value
+
+    def _resolve(self):
+        """Wait for the last sample()'s statistics (an asynchronous device -> pinned-host copy) and append its average reward.
+        sample() itself does not wait: the learner enqueues its return-to-go / advantage kernels first and asks for the number of
+        valid rows (`valid_rows()`) only when it needs a shape -- by then the copy has landed behind the rollout."""
+        if self._pending is not None:
+            host, ev = self._pending
+            self._pending = None
+            ev.synchronize()
+            s, c, v = host.tolist()
+            self._stats_host = (s, c, int(v))
+            self._avg_reward.append(np.asarray(s / c, dtype=np.float32))
+        return self._stats_host
+
+    def valid_rows(self) -> int:
+        """Valid (mask = 1) env-steps of the last sample() on this rank."""
+        return self._resolve()[2]
+
     def sample(self):
         mgr = self.rollout_manager
         if hasattr(mgr, "rollout_device"):
+            self._resolve()                                   # (the previous iteration's, long since complete)
             traj = mgr.rollout_device()
             self.device_traj, self._ref, self._ref_is_full = traj, None, False
-            total = traj.rew.sum(dtype=torch.float64).reshape(1)
-            stats = torch.cat([total, torch.tensor([float(traj.n)], dtype=torch.float64, device=total.device)])
-            D.allreduce_sum_(stats, getattr(mgr, "process_group", None))
-            s, c = stats.tolist()
-            self.avg_reward.append(np.asarray(s / c, dtype=np.float32))
+            dev = traj.rew.device
+            stats = torch.empty(3, dtype=torch.float64, device=dev)
+            stats[0:1] = traj.rew.sum(dtype=torch.float64)
+            stats[1].fill_(float(traj.n))
+            D.allreduce_sum_(stats[0:2], getattr(mgr, "process_group", None))
+            stats[2:3].copy_(traj.counters[0:1])              # this rank's valid rows (tg_rollout_finish)
+            if getattr(self, "_pinned", None) is None:
+                self._pinned = torch.empty(3, dtype=torch.float64).pin_memory()
+            self._pinned.copy_(stats, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._pending = (self._pinned, ev)
+            traj.host_valid_rows = self.valid_rows            # (DeviceTrajectory.env_steps() / the learner ask through this)
         else:
             self.store(*mgr.rollout())
 
@@ -104,7 +143,8 @@ class Rollout_Buffer(Buffer):
         self._ref = dict(zip(self._REF_FIELDS, (group_observations, group_actions, group_rewards, group_lengths,
                                                 group_masks)))
         self._ref_is_full = True
-        self.avg_reward.append(group_rewards.sum(2).mean().detach().numpy())
+        self._resolve()
+        self._avg_reward.append(group_rewards.sum(2).mean().detach().numpy())
 
     def retrieve(self):
         """The reference reads attributes that are never set (:107-108); return the five stored tensors."""

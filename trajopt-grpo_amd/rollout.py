@@ -38,6 +38,7 @@ class DeviceTrajectory:
         self.mask = torch.zeros(T, n, dtype=torch.uint8, device=device)
         self.len = torch.zeros(n, dtype=torch.int32, device=device)
         self.counters = torch.zeros(4, dtype=torch.int64, device=device)
+        self.host_valid_rows = None          # callable -> this rollout's valid rows, already on the host (Rollout_Buffer.sample)
 
     def native(self) -> N.Traj:
         t = N.Traj()
@@ -55,6 +56,8 @@ class DeviceTrajectory:
         return self.act.reshape(self.A, self.T * self.n).t()
 
     def env_steps(self) -> int:
+        if self.host_valid_rows is not None:
+            return int(self.host_valid_rows())
         return int(self.counters[0].item())
 
     # ---- reference layout (CPU float32), rollout_manager.py:86-90 -------------------
@@ -188,6 +191,7 @@ class DeviceRollout:
         """One rollout.  `initial_states` (N,S) and `forced_actions` (N,T,A) or (G,E,T,A)
         replace the RNG draws (teacher-forced parity runs)."""
         self.params = self.env.native_params()
+        self.traj.host_valid_rows = None                 # (set again by Rollout_Buffer.sample for THIS rollout)
         # the policy's covariance is read fresh every rollout (the reference reads self.cov in every forward,
         # actor_critic.py:131-136; the learner reads policy.var in every learn())
         self._sigma = (C.c_float * self.A)(*[float(v) for v in torch.sqrt(self.policy.var)])
