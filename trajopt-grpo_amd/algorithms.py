@@ -134,7 +134,27 @@ class _GpuLearner(Algorithm):
         src, dst = leaves(self.policy.state_dict()), leaves(self.old_policy.state_dict())
         if len(src) == len(dst) and all(torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype
                                         and a.device == b.device for a, b in zip(src, dst)):
+            # ... and with them the weight streams already built from these weights (the launch after the last optimizer step):
+            # the old policy's forward pass of the next learn() then needs no rebuild of its own
+            marks = []
+            for name in ("actor", "critic"):
+                new, old = getattr(self.policy, name, None), getattr(self.old_policy, name, None)
+                mn, mo = (self._mlps.get(id(new)), self._mlps.get(id(old))) if new is not None and old is not None else (None, None)
+                if mn is None or mo is None:
+                    continue
+                k = mn._key()
+                for what, attr, fields in (("f32", "_f32", ("stream",)), ("chain", "_chain", ("stream", "bias"))):
+                    sn, so = getattr(mn, attr, None), getattr(mo, attr, None)
+                    if sn is None or so is None or what in mn._stale or mn.__dict__.get("_built", {}).get(what) != k:
+                        continue
+                    ts = [(getattr(sn, f_), getattr(so, f_)) for f_ in fields]
+                    if all(a.shape == b.shape and a.dtype == b.dtype for a, b in ts):
+                        src += [a for a, _ in ts]
+                        dst += [b for _, b in ts]
+                        marks.append((mo, what))
             torch._foreach_copy_(dst, src)
+            for mo, what in marks:
+                mo.mark_built(what)                                         # (keyed on the old net's weights AFTER the copy)
         else:
             self.old_policy.load_state_dict(self.policy.state_dict())
 

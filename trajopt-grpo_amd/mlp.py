@@ -183,6 +183,7 @@ class GemmMLP:
         self.in_pad = _round_up(self.in_dim, 32)
         w0 = self.w[0]
         self.w[0] = torch.zeros(w0.shape[0], self.in_pad, dtype=w0.dtype, device=w0.device)
+        self.__dict__.setdefault("_built", {}).clear()              # (a re-allocated operand: nothing built counts any more)
         self.refresh()
 
     def _log_path(self, net):
@@ -210,12 +211,26 @@ class GemmMLP:
         """The fp32 master weights changed: every derived operand (padded compute-dtype copies, chain streams, packed
         backward-data fragments) is rebuilt the next time the path that reads it runs -- with the chain kernels active
         the per-layer copies are never touched (17 of 36 tiny launches per update and net)."""
-        self._stale = {"w", "chain", "bchain", "dx", "f32"}
+        k = self._key()
+        built = self.__dict__.setdefault("_built", {})
+        self._stale = {w for w in ("w", "chain", "bchain", "dx", "f32") if built.get(w) != k}
+
+    def _key(self):
+        """What every derived operand is a function of: the master tensors' storage and torch version counters, and the count of
+        raw-pointer parameter writes (the fused Adam launch bypasses the version counters).  refresh() marks stale only what was
+        built from a different key, so a learn() that starts with the weights its last optimizer step left rebuilds nothing."""
+        return (tuple((p.data_ptr(), p._version) for l in self.linears for p in (l.weight, l.bias)), N.RAW_PARAM_WRITES[0])
+
+    def mark_built(self, what: str) -> None:
+        """`what` has just been rebuilt from the current weights by someone else (optim.StreamRefresher, a copy of an identical
+        net's stream)."""
+        self._stale.discard(what)
+        self.__dict__.setdefault("_built", {})[what] = self._key()
 
     def _fresh(self, what: str):
         if what not in self._stale:
             return
-        self._stale.discard(what)
+        self.mark_built(what)
         with torch.no_grad():
             if what == "w":
                 for w, b, l in zip(self.w, self.b, self.linears):

@@ -187,7 +187,7 @@ class StreamRefresher:
         with torch.cuda.device(dev):
             N.check(N.load().tg_gather_streams(seg.data_ptr(), n, total, tab.data_ptr(), N.stream_ptr(dev)), "tg_gather_streams")
         for m, what in self._marks:
-            m._stale.discard(what)
+            m.mark_built(what)
         for x in self.extra:
             x.mark_fresh()
         return True
