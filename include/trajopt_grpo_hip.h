@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 8
+#define TG_ABI_VERSION 9
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -457,22 +457,26 @@ typedef struct tg_f32_dw_job {
     int64_t      w0grad_ld;
 } tg_f32_dw_job;
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
+/* d_loss_work / n_loss_rows / d_loss_sums (optional, both pointers or neither): the reduction launch also adds rows [0, n_loss_rows)
+ * of d_loss_work (f64 [.][4]: tg_mlp_f32_forward_backward's d_work, n_loss_rows = min(blocks, ceil(rows / 256))) into d_loss_sums
+ * (f64 [4]) in a fixed order -- the loss statistics of an update without reduction / accumulation launches of their own. */
 int  tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
-                            int64_t workspace_bytes, void* stream);
+                            int64_t workspace_bytes, const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums, void* stream);
 
 /* ---- Optimizer step and derived weight layouts (pipelines: torch.optim.Adam; algorithms/grpo.py:145, ppo.py:183) ----
  * tg_adam_step: torch.optim.Adam's DEFAULT update (foreach path: no amsgrad, weight decay, maximize, capturable) of n_tensors
  *   fp32 tensors in one launch, the same fp32 operation sequence per element as torch's kernels (bit-identical results).
  *   d_table: DEVICE array of n_tensors descriptors (param, grad, exp_avg, exp_avg_sq device pointers; `first` = the running
  *   element offset of the tensor in the launch's index space, ascending; total = the sum of the sizes).  step = the 1-based
- *   step number AFTER the increment (torch's state['step']).
+ *   step number AFTER the increment (torch's state['step']).  zero_grads != 0: every gradient element is set to 0 once it has
+ *   been read -- the NEXT update's optimizer.zero_grad(set_to_none=False) (algorithms/grpo.py:143, ppo.py:181) without a launch.
  * tg_gather_streams: dst[j] = master tensor (code[j] >> 24) element (code[j] & 0xFFFFFF), or 0 where code[j] < 0, converted
  *   to bf16 (is_bf16) or kept f32, for every segment in one launch (d_segments: DEVICE array, `first` as above; the master
  *   tensors are the `p` pointers of d_table).  Rebuilds every derived weight layout after a step. */
-typedef struct tg_adam_tensor { float* p; const float* g; float* m; float* v; int64_t first; } tg_adam_tensor;
+typedef struct tg_adam_tensor { float* p; float* g; float* m; float* v; int64_t first; } tg_adam_tensor;
 typedef struct tg_gather_segment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; } tg_gather_segment;
 int  tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
-                  int64_t step, void* stream);
+                  int64_t step, int32_t zero_grads, void* stream);
 int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table,
                        void* stream);
 

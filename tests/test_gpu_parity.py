@@ -1677,10 +1677,12 @@ def test_fused_adam_is_bit_identical_to_torch(tg, dev, lr, betas, eps):
             if it == 3:
                 g[g.abs() < 0.5 * g.abs().mean()] = 0.0                      # exact zeros: sqrt(0) + eps paths
             pa.grad, pb.grad = g.clone(), g.clone()
-        assert fused.step()
+        assert fused.step(zero_grads=it % 2 == 1)       # odd steps: the launch also zeroes the gradients it consumed
+        assert fused.grads_zeroed == (it % 2 == 1)
         opt_b.step()
         for pa, pb in zip(pol_a.parameters(), pol_b.parameters()):
             assert torch.equal(pa, pb), it
+            assert torch.equal(pa.grad, torch.zeros_like(pa) if it % 2 == 1 else pb.grad), it
             sa, sb = opt_a.state[pa], opt_b.state[pb]
             assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), it
             assert float(sa["step"]) == float(sb["step"]) == it + 1
@@ -1893,6 +1895,41 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monke
             base = 0.25 * (i + 1)
             scale = float(r.abs().max()) + 1e-12
             assert float((gg.double() - base - r).abs().max()) <= (2e-5 * max(1.0, (rows / 1000) ** 0.5)) * scale + 4e-7 * base, (form, i, rows)
+
+
+@pytest.mark.parametrize("rows", [1, 300, 70001])
+def test_f32_loss_sums_ride_on_the_weight_gradient_reduction(tg, dev, rows):
+    """forward_loss(sums_out=...) + backward_fused() of an fp32 net: the weight-gradient reduction launch adds the chain kernel's
+    per-workgroup loss sums into the caller's f64 [4] in a fixed order -- equal to the sums the plain call returns (f64 rounding),
+    accumulating over calls, bit-reproducible; the gradients do not depend on which form ran."""
+    from trajopt_grpo_amd import mlp as M
+    torch.manual_seed(rows)
+    net = tg.NeuralNetwork(5, 1, (128, 128), "ReLU").to(dev)
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    m = M.GemmMLP(net, torch.float32)
+    X, act = torch.randn(rows, 5, device=dev), torch.randn(rows, 1, device=dev)
+    lpo, adv = (-0.5 * torch.rand(rows, device=dev) - 1.0).contiguous(), torch.randn(rows, device=dev)
+    kw = dict(act=act, logp_old=lpo, adv=adv, var=torch.full((1,), 0.3), epsilon=0.2, surr_coef=-1.0 / rows, kl_coef=0.5 / rows)
+    xp = m.prepare_input(X)
+    s = m.forward_loss(xp, 0, **kw).clone()
+    m.backward_fused()
+    g_plain = [p.grad.clone() for p in net.parameters()]
+    outs = []
+    for rep in range(2):
+        for p in net.parameters():
+            p.grad.zero_()
+        out = torch.zeros(4, dtype=torch.float64, device=dev)
+        for n in (1, 2):
+            assert m.forward_loss(xp, 0, sums_out=out, **kw) is None
+            m.backward_fused()
+            torch.cuda.synchronize()
+            assert float((out - n * s).abs().max()) <= 1e-12 * n * float(s.abs().max() + 1.0), n
+            assert float(out[3]) == n * rows
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    for p, g in zip(net.parameters(), g_plain):
+        assert float((p.grad - 2 * g).abs().max()) <= 2e-6 * float(g.abs().max() + 1e-30)
 
 
 def test_rollout_register_stream_is_rebuilt_by_the_step_launch(tg, dev):

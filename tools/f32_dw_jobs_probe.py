@@ -16,7 +16,7 @@ J = {"mm": job(0, dz, a, H, wg, bg, H, H), "x": job(0, dz, x, 8, w0, bg, H, 5), 
 def run(names):
     arr = (N.F32DwJob * len(names))(*[J[n] for n in names])
     def f():
-        N.check(lib.tg_mlp_f32_weight_grad(H, arr, len(names), rows, ws.data_ptr(), ws.numel() * 4, N.stream_ptr(dev)))
+        N.check(lib.tg_mlp_f32_weight_grad(H, arr, len(names), rows, ws.data_ptr(), ws.numel() * 4, None, 0, None, N.stream_ptr(dev)))
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

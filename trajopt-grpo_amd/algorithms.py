@@ -93,6 +93,7 @@ class _GpuLearner(Algorithm):
         self.fused_mlp = fused_mlp
         self._bucket = None
         self._fused_adam = None
+        self._adam_covers_bucket = False
         self._refresher = None
         self._mlps = {}
         self._ws = M._Workspace()       # per-iteration tensors whose size follows the number of valid rows
@@ -184,13 +185,27 @@ class _GpuLearner(Algorithm):
             if m is not None:
                 m.refresh()
 
-    def _optimizer_step(self, *nets):
+    def _zero_grads(self):
+        """`optimizer.zero_grad()` (grpo.py:143, ppo.py:181) on the flat bucket -- skipped when the previous update's Adam launch
+        already left every gradient zero (FusedAdam.step(zero_grads=True))."""
+        fa = self._fused_adam
+        if fa and fa.grads_zeroed:
+            fa.grads_zeroed = False
+            return
+        self.bucket.zero_()
+
+    def _optimizer_step(self, *nets, last=True):
         """`optimizer.step()` (grpo.py:145, ppo.py:183) and the refresh of every weight layout derived from `nets`.  A plain default
         torch.optim.Adam takes ONE launch on its own state tensors (optim.FusedAdam: bit-identical to torch's ~8) and one gather
-        rebuilds all layouts; anything else -- hooks, a patched step, another optimizer -- runs as written, layouts refreshed lazily."""
+        rebuilds all layouts; anything else -- hooks, a patched step, another optimizer -- runs as written, layouts refreshed lazily.
+        last=False: another update of this learn() follows -- the Adam launch also zeroes the gradients it consumed (the final
+        update's gradients stay in .grad, as after the reference's learn())."""
         if self._fused_adam is None:
             self._fused_adam = O.FusedAdam(self.optimizer) if _FUSED_ADAM else False
-        stepped = bool(self._fused_adam) and self._fused_adam.step()
+            if self._fused_adam:
+                owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+                self._adam_covers_bucket = all(id(p) in owned for p in self.bucket.params)
+        stepped = bool(self._fused_adam) and self._fused_adam.step(zero_grads=not last and self._adam_covers_bucket)
         if not stepped:
             self.optimizer.step()
         self._refresh(*nets)
@@ -287,18 +302,19 @@ class GRPO(_GpuLearner):
         self._refresh(actor, self.old_policy.actor)
         xin = self._prep(actor, X, traj.T * traj.n)
         old_logp = self._logp_nograd(self.old_policy.actor, xin, act, var)  # grpo.py:118-119
-        Js = []
-        for _ in range(self.updates_per_iter):
-            self.bucket.zero_()
-            sums = torch.zeros(4, dtype=torch.float64, device=X.device)
+        all_sums = torch.zeros(max(self.updates_per_iter, 1), 4, dtype=torch.float64, device=X.device)
+        for u in range(self.updates_per_iter):
+            self._zero_grads()
+            sums = all_sums[u]
             m_actor = self._mlp(actor)
             fuse = m_actor is not None and m_actor.can_fuse_head()
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
                 if fuse:        # loss head + head gradient inside the forward chain (tg_mlp_forward_chain_loss)
-                    s = m_actor.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], var=var,
-                                             epsilon=self.epsilon, surr_coef=coef)
+                    m_actor.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], var=var,
+                                         epsilon=self.epsilon, surr_coef=coef, sums_out=sums)
                     m_actor.backward_fused()
+                    continue
                 else:
                     mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
                     _, s, g_mean, _ = K.surrogate_loss(mean.detach(), None, act[lo:hi], old_logp[lo:hi], adv[lo:hi], None,
@@ -306,11 +322,10 @@ class GRPO(_GpuLearner):
                     self._backward(actor, mean, g_mean)
                 sums += s
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
-            self._optimizer_step(actor)
-            Js.append(sums)
+            self._optimizer_step(actor, last=u == self.updates_per_iter - 1)
         self._copy_policy_to_old()                                          # grpo.py:148
-        if Js:
-            allJ = torch.stack(Js)
+        if self.updates_per_iter > 0:
+            allJ = all_sums
             D.allreduce_sum_(allJ, self.process_group)
             self._stats_pending = lambda: {"J": (allJ[:, 0] / G_global).tolist(), "n_valid": allJ[0, 3].item()}
 
@@ -351,24 +366,23 @@ class PPO(_GpuLearner):
             out[lo:hi] = self._forward(self.policy.critic, xin[lo:hi]).reshape(-1)
         return out
 
-    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out):
+    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out, last=True):
         """One optimizer step on the given rows (all local rows, or one minibatch)."""
         actor, critic = self.policy.actor, self.policy.critic
-        self.bucket.zero_()
-        sums = torch.zeros(4, dtype=torch.float64, device=xin.device)
+        self._zero_grads()
+        both = torch.zeros(2, 4, dtype=torch.float64, device=xin.device)    # [actor | critic] loss sums
+        sums = both[0]
         m_a, m_c = self._mlp(actor), self._mlp(critic)
         fuse = m_a is not None and m_c is not None and m_a.can_fuse_head() and m_c.can_fuse_head()
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
             if fuse:            # both loss heads + head gradients inside the forward chains (tg_mlp_forward_chain_loss)
                 nh = self._norm_host
-                s = m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2], var=var,
-                                     epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global)
+                m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2], var=var,
+                                 epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global, sums_out=both[0])
                 m_a.backward_fused()
-                s2 = m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4], critic_coef=self.c1 / n_global)
+                m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4], critic_coef=self.c1 / n_global, sums_out=both[1])
                 m_c.backward_fused()
-                sums += s
-                sums[1] += s2[1]
                 continue
             mean = self._forward(actor, xin[lo:hi], train=True, view=True)         # the loss kernel takes a row stride
             vout = self._forward(critic, xin[lo:hi], train=True)
@@ -380,8 +394,8 @@ class PPO(_GpuLearner):
             self._backward(critic, vout, g_val.view_as(vout))
             sums += s
         self.bucket.allreduce(self.process_group)                            # one RCCL all-reduce / step
-        self._optimizer_step(actor, critic)
-        sums_out.append(sums)
+        self._optimizer_step(actor, critic, last=last)
+        sums_out.append(both)
 
     def _learn(self, buffer) -> None:
         traj = device_trajectory(buffer, self.policy.device)
@@ -420,10 +434,11 @@ class PPO(_GpuLearner):
         old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)
         M = X.shape[0]
         all_sums = []
-        for _ in range(self.updates_per_iter):
+        for u in range(self.updates_per_iter):
+            final = u == self.updates_per_iter - 1
             if self.batch_size is None:
                 # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
-                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums)
+                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums, last=final)
             else:
                 if self.permutation_fn is not None:
                     perm = self.permutation_fn(M, X.device)
@@ -438,10 +453,13 @@ class PPO(_GpuLearner):
                 for k in range(n_steps):
                     b = perm[k * local_bs:(k + 1) * local_bs]
                     self._step(xin.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
-                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums)
+                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums,
+                               last=final and k == n_steps - 1)
         self._copy_policy_to_old()                                          # ppo.py:186
         if all_sums:
-            S = torch.stack(all_sums)
+            S2 = torch.stack(all_sums)                                      # [steps][actor | critic][4]
+            S = S2[:, 0].contiguous()
+            S[:, 1] += S2[:, 1, 1]                                          # the critic's squared error
             D.allreduce_sum_(S, self.process_group)
             nn = S[:, 3]
             ent = 0.5 * act.shape[1] * (1.0 + math.log(2 * math.pi)) + 0.5 * float(torch.log(var).sum())

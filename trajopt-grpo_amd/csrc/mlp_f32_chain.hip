@@ -1118,7 +1118,12 @@ struct F32FinishDesc {
     int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;     // first_elem: in UNITS (below) once the launcher has laid them out
     int32_t vec;                                                // a unit = 4 consecutive floats of a row (else 1 float)
 };
-struct F32FinishArgs { F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total; };
+struct F32FinishArgs {
+    F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total;
+    // optional rider of the launch: sums[k] += sum over rows [0, n_loss_rows) of loss_work[row][k], in a fixed order (the chain
+    // kernel's per-workgroup loss sums: this launch follows it in stream order, so no device-scope hand-off is needed)
+    const double* loss_work; double* loss_sums; int32_t n_loss_rows; int32_t n_blocks;
+};
 
 // A workgroup = 32 consecutive output units x 8 slab chunks: thread (el, c) adds slabs c, c + 8, ... of its unit (8 loads in
 // flight), the 8 chunk sums meet in LDS and are added in chunk order: a fixed order whatever the launch, and ~500 slabs of 64-85 KB
@@ -1126,6 +1131,17 @@ struct F32FinishArgs { F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t to
 // where the window allows it (the H x H gradients: 512 contiguous bytes per workgroup and slab instead of 128).
 __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa) {
     __shared__ float4 part[8][32];
+    if ((int)blockIdx.x == fa.n_blocks) {                   // the extra workgroup: the loss sums (one wave)
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x, k = lane & 3, p16 = lane >> 2;     // 16 lanes per quantity: rows p16, p16 + 16, ...
+            double t = 0.0;
+            for (int r = p16; r < fa.n_loss_rows; r += 16) t += fa.loss_work[(int64_t)r * 4 + k];
+#pragma unroll
+            for (int off = 32; off >= 4; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane < 4) fa.loss_sums[lane] += t;
+        }
+        return;
+    }
     const int el = threadIdx.x & 31, c = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     float4 sum = float4{0.f, 0.f, 0.f, 0.f};
@@ -1302,7 +1318,7 @@ int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
 }
 
 int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
-                           int64_t workspace_bytes, void* stream) {
+                           int64_t workspace_bytes, const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums, void* stream) {
     TG_REQUIRE(jobs && d_workspace, "tg_mlp_f32_weight_grad: null pointer");
     TG_REQUIRE(hidden == 64 || hidden == 128, "tg_mlp_f32_weight_grad: hidden width %d unsupported (64, 128)", hidden);
     TG_REQUIRE(n_jobs >= 1 && n_jobs <= kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d jobs outside 1..%d", n_jobs, kF32DwMaxJobs);
@@ -1452,6 +1468,10 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         units += d.vec ? cnt / 4 : cnt;
     }
     fa.total = units;
+    TG_REQUIRE((d_loss_work == nullptr) == (d_loss_sums == nullptr) && n_loss_rows >= 0 && n_loss_rows <= 65536,
+               "tg_mlp_f32_weight_grad: loss-sum rider needs both pointers and 0..65536 rows");
+    fa.n_blocks = (int32_t)ceil_div(units, 32);
+    fa.loss_work = d_loss_work; fa.loss_sums = d_loss_sums; fa.n_loss_rows = n_loss_rows;
     hipStream_t st = (hipStream_t)stream;
     if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
@@ -1465,7 +1485,7 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, st, args, rows, (float*)d_workspace);
     }
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad");
-    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)ceil_div(units, 32)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(mlp_f32_dw_finish_kernel, dim3((unsigned)(fa.n_blocks + (d_loss_sums ? 1 : 0))), dim3(256), 0, st, fa);
     TG_LAUNCH_CHECK("tg_mlp_f32_weight_grad (finish)");
     return TG_OK;
 }

@@ -14,11 +14,12 @@
 
 namespace tg {
 
-struct AdamTensor { float* p; const float* g; float* m; float* v; int64_t first; };   // first = index of element 0 in the launch
+struct AdamTensor { float* p; float* g; float* m; float* v; int64_t first; };   // first = index of element 0 in the launch
 constexpr int kAdamMaxTensors = 64;
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total,
-                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size) {
+                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size,
+                                                   int32_t zero_grads) {
 #pragma clang fp contract(off)
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
     // torch._foreach_addcdiv_(param, exp_avg, denom, step_size): self + value * (t1 / t2)
     p = fmaf(step_size, m / s, p);
     d.m[i] = m; d.v[i] = v; d.p[i] = p;
+    if (zero_grads) d.g[i] = 0.0f;          // the next step's optimizer.zero_grad(set_to_none=False), while the line is here
 }
 
 struct GatherSegment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; };
@@ -70,7 +72,7 @@ using namespace tg;
 extern "C" {
 
 int tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
-                 int64_t step, void* stream) {
+                 int64_t step, int32_t zero_grads, void* stream) {
     TG_REQUIRE(d_table, "tg_adam_step: null table");
     TG_REQUIRE(n_tensors >= 1 && n_tensors <= kAdamMaxTensors, "tg_adam_step: %d tensors outside 1..%d", n_tensors, kAdamMaxTensors);
     TG_REQUIRE(total >= 0 && step >= 1, "tg_adam_step: bad sizes (total %lld, step %lld)", (long long)total, (long long)step);
@@ -82,7 +84,7 @@ int tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total
     static_assert(sizeof(tg_adam_tensor) == sizeof(AdamTensor), "ABI struct and kernel struct must agree");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)bc2_sqrt, (float)eps, (float)step_size);
+                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads);
     TG_LAUNCH_CHECK("tg_adam_step");
     return TG_OK;
 }

@@ -350,13 +350,19 @@ class GemmMLP:
 
     @torch.no_grad()
     def forward_loss(self, xp: torch.Tensor, kind: int, *, act=None, logp_old=None, adv=None, ret=None, norm=None, var=None,
-                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0) -> torch.Tensor:
+                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0, sums_out=None) -> torch.Tensor:
         """Training forward pass with the loss head inside it (kind 0: actor, clipped surrogate; kind 1: critic, squared error).
         Stores what backward_fused() needs, adds the head's weight / bias gradient into their windows and returns the f64 sums
-        [surrogate, squared error, KL, count] of these rows."""
+        [surrogate, squared error, KL, count] of these rows -- or, given `sums_out` (f64 [4] on the device), ADDS them there and
+        returns None; on the fp32 chain learner that addition rides on backward_fused()'s reduction launch (no launches of its own),
+        so `sums_out` is complete once backward_fused() has been enqueued."""
         lib = N.load()
         if self._f32 is not None:
-            return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef)
+            return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out)
+        if sums_out is not None:
+            sums_out += self.forward_loss(xp, kind, act=act, logp_old=logp_old, adv=adv, ret=ret, norm=norm, var=var, epsilon=epsilon,
+                                          surr_coef=surr_coef, critic_coef=critic_coef, kl_coef=kl_coef)
+            return None
         self._fresh("chain")
         L = len(self.linears)
         rows, H, dev = xp.shape[0], self._chain.H, xp.device
@@ -434,7 +440,7 @@ class GemmMLP:
         a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
         return a
 
-    def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef):
+    def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out=None):
         """forward_loss() of an fp32 net: forward + loss head + backward-data pass in ONE launch (tg_mlp_f32_forward_backward);
         every hidden layer's activation and dZ is written for backward_fused() (tg_mlp_f32_weight_grad)."""
         lib = N.load()
@@ -468,6 +474,11 @@ class GemmMLP:
             self.fwd_events.append((ev[0], ev[1], rows, 2 * H * f.in_pad + 4 * (nh - 1) * H * H, f"tg::mlp_f32_chain_kernel<{H},true>"))
         grid = min(nblk, -(-rows // 256))
         self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
+        assert getattr(self, "_loss_rider", None) is None, "forward_loss(sums_out=...) must be followed by backward_fused()"
+        if sums_out is not None:
+            assert sums_out.dtype == torch.float64 and sums_out.is_cuda and sums_out.numel() == 4 and sums_out.is_contiguous()
+            self._loss_rider = (grid, sums_out)             # added by tg_mlp_f32_weight_grad's reduction launch
+            return None
         return self._head_ws[:grid * 4].view(grid, 4).sum(0)
 
     def _backward_fused_f32(self):
@@ -509,8 +520,11 @@ class GemmMLP:
         if self.dw_events is not None:
             ev = N.event_pair()
             ev[0].record()
-        N.check(N.load().tg_mlp_f32_weight_grad(H, arr, len(specs), rows, self._dw_ws.data_ptr(),
-                                                self._dw_ws.numel() * 4, N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
+        rider = getattr(self, "_loss_rider", None)
+        self._loss_rider = None
+        N.check(N.load().tg_mlp_f32_weight_grad(H, arr, len(specs), rows, self._dw_ws.data_ptr(), self._dw_ws.numel() * 4,
+                                                self._head_ws.data_ptr() if rider else None, rider[0] if rider else 0,
+                                                rider[1].data_ptr() if rider else None, N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
         if ev is not None:
             ev[1].record()
             self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * 32, f"tg::mlp_f32_dw_kernel<{H}>"))

@@ -25,6 +25,7 @@ class FusedAdam:
         self._sig = None
         self._tables = None          # per param group: (device int64 [T][5] table, n_tensors, total elements)
         self.tensor_ids = {}         # id(param) -> (group index, tensor index in the group's table)
+        self.grads_zeroed = False    # the last step() left every .grad zero (step(zero_grads=True)): the caller may skip its zero_grad
 
     @staticmethod
     def _plain_adam(opt) -> bool:
@@ -87,8 +88,11 @@ class FusedAdam:
         return self._tables[group]
 
     @torch.no_grad()
-    def step(self) -> bool:
-        """One optimizer step; False (nothing done) when the fused form does not apply -- the caller then runs optimizer.step()."""
+    def step(self, zero_grads: bool = False) -> bool:
+        """One optimizer step; False (nothing done) when the fused form does not apply -- the caller then runs optimizer.step().
+        zero_grads: the launch also zeroes every .grad it has consumed (the next update's optimizer.zero_grad() -- grpo.py:143,
+        ppo.py:181 -- folded in); `grads_zeroed` then tells the caller that its own zeroing launch can be skipped."""
+        self.grads_zeroed = False
         if not self.usable():
             return False
         self._init_state()
@@ -105,8 +109,9 @@ class FusedAdam:
             dev = g["params"][0].device
             with torch.cuda.device(dev):
                 N.check(lib.tg_adam_step(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
-                                         N.stream_ptr(dev)), "tg_adam_step")
+                                         1 if zero_grads else 0, N.stream_ptr(dev)), "tg_adam_step")
         N.RAW_PARAM_WRITES[0] += 1
+        self.grads_zeroed = bool(zero_grads)
         return True
 
 
