@@ -184,6 +184,7 @@ def ptr(t):
 # Bumped by every launch that writes parameters through raw pointers (optim.FusedAdam.step): torch's own version counters do not
 # see those writes, so anything that caches a function of the weights keys its freshness on (versions, this counter).
 RAW_PARAM_WRITES = [0]
+ALWAYS_REBUILD = os.environ.get("TG_ALWAYS_REBUILD", "0") == "1"    # 1: derived weight layouts never count as fresh (rounds 1-2 behaviour)
 
 
 def event_pair():
