@@ -432,6 +432,12 @@ def main():
     # rollout, one after learn() has enqueued the update.  The host is NOT synchronised between steps: the learner reads its loss
     # statistics lazily, so the next rollout is enqueued while the last updates still run (the timed region is bracketed by a
     # barrier + synchronize on both sides, as the contract says).
+    # The cyclic garbage collector is off inside the timed region (as `timeit` does): the per-launch event objects this script keeps
+    # -- 600 pairs per C4 step -- otherwise trigger a full collection somewhere in the region, a 70-150 ms host pause with nothing
+    # queued on the GPU (C4, 20 steps: 43 against 49 M env-steps/s; the pause never happens without the events)
+    import gc
+    gc.collect()
+    gc.disable()
     phase_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     step_units = []
     barrier()
@@ -464,9 +470,13 @@ def main():
             progress(f"step {_ + 1}/{args.steps}")
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     set_events(not args.no_launch_events)       # (the lists the code below reads)
     t_roll = sum(e[0].elapsed_time(e[1]) for e in phase_ev) * 1e-3
     t_learn = sum(e[1].elapsed_time(e[2]) for e in phase_ev) * 1e-3
+    if os.environ.get("TG_BENCH_STEP_TIMES"):
+        for k, e in enumerate(phase_ev):
+            print(f"step {k} on the GPU: rollout {e[0].elapsed_time(e[1]):.3f} ms, learn {e[1].elapsed_time(e[2]):.3f} ms, env-steps {step_units[k]}", file=sys.stderr, flush=True)
 
     fam_launches = {"bwd": [], "dw": [], "fwd": []}     # (ms, algorithmic bytes, rows, kernel name) per launch
     for m in learner_mlps:

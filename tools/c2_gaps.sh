@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/c2gaps
-rocprofv3 --kernel-trace --output-format csv -d /tmp/c2gaps -- python3 $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline --no-launch-events > $OUT/c2_gaps_bench.json 2> $OUT/c2_gaps.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/c2gaps -- python3 $R/bench.py --config ${CONFIG:-c2} --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-launch-events > $OUT/c2_gaps_bench.json 2> $OUT/c2_gaps.err
 python3 - "$(find /tmp/c2gaps -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -40,7 +40,7 @@ print("one step, kernel by kernel (start us, gap us, duration us):")
 for e in ev[a:b + 1]:
     g = (e[0] - prev_end) / 1e3
     d = (e[1] - e[0]) / 1e3
-    if g > 4 or d > 20:
+    if g > float(__import__("os").environ.get("GAP_US", "4")) or d > float(__import__("os").environ.get("DUR_US", "20")):
         print("  %8.1f  gap %6.1f  dur %7.1f  %s" % ((e[0] - t0) / 1e3, g, d, e[2][:70]))
     prev_end = max(prev_end, e[1])
 PY

@@ -14,5 +14,8 @@ TG_F32_RECOMPUTE=0 timeout -k 10 200 python3 tools/f32_chain_probe.py --iters 30
 for f in r03_bench_c2 r03_bench_c2_r02_path_same_box r03_bench_c2_stored_operands_same_box r03_bench_c2_all_launches_timed_same_box; do
   python3 -c "import json; d=json.load(open('$OUT/$f.json')); print('$f', round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms')"
 done
+TG_ALWAYS_REBUILD=1 timeout -k 10 300 python3 bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/r03_bench_c2_always_rebuild_same_box.json 2>/dev/null || exit 1
+python3 -c "import json; d=json.load(open('$OUT/r03_bench_c2_always_rebuild_same_box.json')); print('always_rebuild', round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms')"
 bash $R/tools/profile_c2.sh | head -12
 cp $OUT/bench_c2_kernel_stats.csv $OUT/r03_bench_c2_kernel_stats.csv
+bash $R/tools/c2_gaps.sh > $OUT/r03_c2_gaps.txt 2>&1; head -12 $OUT/r03_c2_gaps.txt

@@ -31,6 +31,7 @@ from . import optim as O
 from .rollout import DeviceTrajectory
 
 
+_NONZERO_STATIC = os.environ.get("TG_NONZERO_STATIC", "1") == "1"  # 0: torch.nonzero (a host round trip for the shape) even when the count is known
 _FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
 
 
@@ -108,6 +109,15 @@ class _GpuLearner(Algorithm):
             frag = getattr(getattr(getattr(buffer, "rollout_manager", None), "engine", None), "_frag", None)
             ok = hasattr(frag, "segments") and getattr(frag, "lin", None) == [m for m in self.policy.actor.network if isinstance(m, torch.nn.Linear)]
             self._rollout_stream = frag if ok else None
+            # every per-row workspace (activations, dZ, mask bits, gathered rows) is allocated ONCE for the largest chunk an
+            # iteration of this buffer can bring: 288 GB of HBM are there to be used, and growth by re-allocation stalls the queue
+            traj = getattr(buffer, "device_traj", None)
+            if traj is not None:
+                cap = min(self.chunk_rows, traj.T * traj.n)
+                self._ws.default_cap = max(self._ws.default_cap, cap)
+                for m in self._mlps.values():
+                    if m is not None:
+                        m._ws.default_cap = max(m._ws.default_cap, cap)
             self._learn(buffer)
 
     @property
@@ -177,6 +187,8 @@ class _GpuLearner(Algorithm):
         if key not in self._mlps:
             ok = self.fused_mlp and M.supports(net) and next(net.parameters()).is_cuda
             self._mlps[key] = M.GemmMLP(net, self.autocast_dtype or torch.float32) if ok else None
+            if self._mlps[key] is not None:
+                self._mlps[key]._ws.default_cap = self._ws.default_cap
         return self._mlps[key]
 
     def _refresh(self, *nets):
@@ -247,7 +259,7 @@ class _GpuLearner(Algorithm):
     def _gather_valid(self, traj):
         """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
         flat = traj.mask.reshape(-1)
-        if traj.host_valid_rows is not None and hasattr(torch, "nonzero_static"):
+        if traj.host_valid_rows is not None and hasattr(torch, "nonzero_static") and _NONZERO_STATIC:
             # the count is on the host already (it rode on the rollout's statistics): no host-device round trip for the shape
             idx = torch.nonzero_static(flat, size=int(traj.host_valid_rows())).squeeze(1)
         else:

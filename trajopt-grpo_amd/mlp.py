@@ -106,12 +106,16 @@ class _Workspace:
     def __init__(self):
         self._buf = {}
 
+    default_cap = 0     # rows every buffer is sized for when it is (re)allocated (the learner sets it to its chunk size: the
+                        # row count of an iteration grows while a policy learns to survive, and a GB-sized buffer that is re-allocated
+                        # a little larger every iteration costs tens of milliseconds of hipMalloc / hipFree with the GPU busy)
+
     def get(self, name: str, rows: int, cols: int, dtype, device, cap_rows: int = 0) -> torch.Tensor:
-        """[rows][cols] view of buffer `name`; a (re)allocation sizes it for max(rows, cap_rows) rows."""
+        """[rows][cols] view of buffer `name`; a (re)allocation sizes it for max(rows, cap_rows, default_cap) rows."""
         need = rows * cols
         b = self._buf.get(name)
         if b is None or b.numel() < need or b.dtype != dtype or b.device != device:
-            self._buf[name] = b = torch.empty(max(rows, cap_rows) * cols, dtype=dtype, device=device)
+            self._buf[name] = b = torch.empty(max(rows, cap_rows, self.default_cap) * cols, dtype=dtype, device=device)
         return b[:need].view(rows, cols)
 
 
