@@ -105,3 +105,73 @@ def test_f32_chain_weight_stream_layout():
     assert M.f32_chain_supported(tg.NeuralNetwork(5, 1, (32, 32), "ReLU")) == 0
     assert M.f32_chain_supported(tg.NeuralNetwork(5, 8, (64, 64), "ReLU")) == 0
     assert M.f32_chain_supported(tg.NeuralNetwork(5, 1, (128,) * 5, "ReLU")) == 0
+
+
+def test_avg_reward_keeps_the_reference_list_semantics(tmp_path):
+    """`Rollout_Buffer.avg_reward` is a property since the device path reads its statistic lazily; for every other use it is the
+    reference's plain list (rollout_buffer.py:70, :104-121): appended by store(), replaced by load(), assignable, len() = entries."""
+    g = load_golden("rollout_cartpole.npz")
+    buf = tg.Rollout_Buffer(types.SimpleNamespace(env_fn=lambda: None))
+    assert buf.avg_reward == []
+    t = tuple(torch.from_numpy(g[f"reset_{k}"]) for k in ("obs", "act", "rew", "len", "mask"))
+    buf.store(*t)
+    buf.store(*t)
+    assert len(buf.avg_reward) == 2 and isinstance(buf.avg_reward, list)
+    buf.avg_reward = [1.0, 2.0, 3.0]
+    assert buf.avg_reward == [1.0, 2.0, 3.0]
+    buf.save(str(tmp_path))
+    other = tg.Rollout_Buffer(types.SimpleNamespace(env_fn=lambda: None))
+    assert other.load(str(tmp_path)) == 3 and other.avg_reward == [1.0, 2.0, 3.0]
+
+
+def test_learner_statistics_are_a_lazily_resolved_property():
+    """`last_stats` resolves a pending reader once, caches the dict and stays assignable (the learners set the reader at the end of
+    learn(); nothing is read from the device until someone asks)."""
+    from trajopt_grpo_amd import algorithms as ALG
+    obj = ALG.GRPO.__new__(ALG.GRPO)                        # (no policy / optimizer: only the statistics bookkeeping is exercised)
+    obj._stats, obj._stats_pending = {}, None
+    calls = []
+    obj._stats_pending = lambda: (calls.append(1), {"J": [1.0]})[1]
+    assert obj.last_stats == {"J": [1.0]} and obj.last_stats == {"J": [1.0]} and calls == [1]
+    obj.last_stats = {"x": 2}
+    assert obj.last_stats == {"x": 2} and obj._stats_pending is None
+
+
+def test_workspace_is_sized_for_its_capacity_once():
+    """mlp._Workspace: a buffer is (re)allocated for max(rows, cap_rows, default_cap) rows and then only re-viewed -- the learner
+    sets default_cap to its chunk size so that a growing row count never re-allocates GB-sized blocks mid-run."""
+    from trajopt_grpo_amd import mlp as M
+    ws = M._Workspace()
+    a = ws.get("a", 10, 4, torch.float32, torch.device("cpu"))
+    assert a.shape == (10, 4) and ws._buf["a"].numel() == 40
+    ws.default_cap = 100
+    b = ws.get("b", 10, 4, torch.float32, torch.device("cpu"))
+    big = ws._buf["b"]
+    assert b.shape == (10, 4) and big.numel() == 400
+    c = ws.get("b", 90, 4, torch.float32, torch.device("cpu"))
+    assert c.shape == (90, 4) and ws._buf["b"] is big
+    d = ws.get("b", 120, 4, torch.float32, torch.device("cpu"), cap_rows=50)
+    assert d.shape == (120, 4) and ws._buf["b"].numel() == 480
+
+
+def test_derived_layout_keys_follow_torch_version_counters_and_raw_writes():
+    """The key every derived weight layout is stamped with (mlp.GemmMLP._key / RegisterStreamF32._key): changes with any in-place
+    write through torch, with a re-bound parameter and with _native.RAW_PARAM_WRITES (the fused Adam launch), and with nothing else."""
+    from trajopt_grpo_amd import _native as N
+    from trajopt_grpo_amd import mlp as M
+    net = tg.NeuralNetwork(5, 1, (128, 128), "ReLU")
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    key = lambda: (tuple((p.data_ptr(), p._version) for l in lin for p in (l.weight, l.bias)), N.RAW_PARAM_WRITES[0])
+    obj = types.SimpleNamespace(linears=lin, lin=lin)
+    assert M.GemmMLP._key(obj) == key() == M.RegisterStreamF32._key(obj)
+    k0 = key()
+    assert M.GemmMLP._key(obj) == k0                      # reading changes nothing
+    with torch.no_grad():
+        lin[1].bias.add_(1.0)
+    k1 = M.GemmMLP._key(obj)
+    assert k1 != k0
+    N.RAW_PARAM_WRITES[0] += 1
+    k2 = M.GemmMLP._key(obj)
+    assert k2 != k1
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    assert M.GemmMLP._key(obj) != k2
