@@ -156,7 +156,7 @@ class _GpuLearner(Algorithm):
                 k = mn._key()
                 for what, attr, fields in (("f32", "_f32", ("stream",)), ("chain", "_chain", ("stream", "bias"))):
                     sn, so = getattr(mn, attr, None), getattr(mo, attr, None)
-                    if sn is None or so is None or what in mn._stale or mn.__dict__.get("_built", {}).get(what) != k:
+                    if sn is None or so is None or what in mn._stale or mn._built.get(what) != k:
                         continue
                     ts = [(getattr(sn, f_), getattr(so, f_)) for f_ in fields]
                     if all(a.shape == b.shape and a.dtype == b.dtype for a, b in ts):

@@ -176,6 +176,7 @@ class GemmMLP:
                 self._bchain = FragmentStream(net, H, layout="chain", transposed=True)
         self.bias_out_f32 = torch.zeros(self.out_pad, dtype=torch.float32, device=dev)
         self._log_path(net)
+        self._built = {}            # derived operand -> the key (_key()) of the weights it was last built from
         self.refresh()
 
     def disable_f32_chain(self):
@@ -187,7 +188,7 @@ class GemmMLP:
         self.in_pad = _round_up(self.in_dim, 32)
         w0 = self.w[0]
         self.w[0] = torch.zeros(w0.shape[0], self.in_pad, dtype=w0.dtype, device=w0.device)
-        self.__dict__.setdefault("_built", {}).clear()              # (a re-allocated operand: nothing built counts any more)
+        self._built.clear()                                         # (a re-allocated operand: nothing built counts any more)
         self.refresh()
 
     def _log_path(self, net):
@@ -216,8 +217,7 @@ class GemmMLP:
         backward-data fragments) is rebuilt the next time the path that reads it runs -- with the chain kernels active
         the per-layer copies are never touched (17 of 36 tiny launches per update and net)."""
         k = self._key()
-        built = self.__dict__.setdefault("_built", {})
-        self._stale = {w for w in ("w", "chain", "bchain", "dx", "f32") if N.ALWAYS_REBUILD or built.get(w) != k}
+        self._stale = {w for w in ("w", "chain", "bchain", "dx", "f32") if N.ALWAYS_REBUILD or self._built.get(w) != k}
 
     def _key(self):
         """What every derived operand is a function of: the master tensors' storage and torch version counters, and the count of
@@ -229,7 +229,7 @@ class GemmMLP:
         """`what` has just been rebuilt from the current weights by someone else (optim.StreamRefresher, a copy of an identical
         net's stream)."""
         self._stale.discard(what)
-        self.__dict__.setdefault("_built", {})[what] = self._key()
+        self._built[what] = self._key()
 
     def _fresh(self, what: str):
         if what not in self._stale:
