@@ -230,6 +230,17 @@ def _pmc_bytes_per_row(family):
         return None, None
 
 
+def _f32_pmc_bytes_per_row(family):
+    """HBM traffic per row of the fp32 chain learner's kernels (5-128-128-1, 2^20-row probe: profiles/r03_f32_chain_pmc.json)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r03_f32_chain_pmc.json")) as f:
+            d = json.load(f)
+        k = d["kernels"]["forward_backward" if family == "fwd" else "weight_grad"]
+        return k["traffic_bytes_per_launch"] / d["rows"], "r03_f32_chain_pmc.json"
+    except Exception:
+        return None, None
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -628,7 +639,14 @@ def main():
                 nflop = sum(b for _, b, _, _ in ls)
                 nrows = sum(r for _, _, r, _ in ls)
                 ach = nflop / dur / 1e12
-                kernels[fam] = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                # (HBM traffic of these matrix-bound kernels, for the record: PMC bytes per row of the 5-128-128-1 probe x rows per launch;
+                #  only quoted for that net shape)
+                pmc_row, pmc_file = _f32_pmc_bytes_per_row(fam) if (args.config == "c2" and hidden == (128, 128)) else (None, None)
+                kernels[fam] = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                                "traffic": pmc_row * nrows / len(ls) if pmc_row else None,
+                                "traffic_source": (f"profiles/{pmc_file}: 2 x FETCH_SIZE + WRITE_SIZE per row of the 2^20-row probe, times this "
+                                                   "run's average rows per launch (1.001 x / 1.04 x the algorithmic bytes: the kernel is bound "
+                                                   "by the matrix pipe, not by these)") if pmc_row else None,
                                 "kernel": ls[0][3], "flops_per_row": nflop / nrows, "launches": len(ls),
                                 "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
                                 "total_ms_per_step": 1e3 * dur / max(timed_steps, 1),
