@@ -282,6 +282,40 @@ def test_graph_replay_matches_eager(tg, dev):
     assert a.env_steps() == b.env_steps() > 0
 
 
+@pytest.mark.parametrize("how", ["torch_adam", "fused_adam"])
+@pytest.mark.parametrize("hidden,cd", [((64, 64), None), ((128, 128, 128), torch.bfloat16), ((48, 48), None)])
+def test_captured_rollout_graph_follows_weight_updates(tg, dev, hidden, cd, how):
+    """the captured per-step graph holds the forward launches only, so the operands they read must be rebuilt
+    in front of every replay -- a replay after an optimizer step (torch's, or the raw-pointer fused one) has to act with the NEW
+    weights.  An eager engine with the same seed is the witness; the first action is also checked against the policy itself."""
+    T, G, Eps = 16, 2, 128
+    torch.manual_seed(5)
+    pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, hidden, cov=1e-10, device=dev)
+    kw = dict(seed=4, fused=False, compute_dtype=cd)
+    eager = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps, use_graph=False, **kw)
+    graph = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps, use_graph=True, **kw)
+    opt = torch.optim.Adam(pol.parameters(), lr=2e-2)
+    fused = tg.optim.FusedAdam(opt)
+    x_fix = torch.randn(8, 20, device=dev)
+    before = pol.actor(x_fix).detach().clone()
+    for it in range(3):
+        a, b = eager.run(), graph.run()
+        torch.cuda.synchronize()
+        assert graph._graph is not None
+        assert torch.equal(a.len, b.len) and torch.equal(a.mask, b.mask)
+        assert torch.allclose(a.act, b.act, atol=1e-5), f"replay {it} acted with other weights than the eager engine"
+        mean0 = pol.actor(b.obs[:, 0, :].t().float())
+        tol = 5e-2 if cd == torch.bfloat16 else 1e-4
+        assert float((b.act[:, 0, :].t() - mean0).abs().max()) < tol, f"replay {it}: first action is not the current policy's mean"
+        for p in pol.parameters():                       # a visible step: the mean moves by far more than the tolerances
+            p.grad = torch.randn_like(p)
+        if how == "fused_adam":
+            assert fused.step(), "the fused optimizer step did not apply"
+        else:
+            opt.step()
+    assert float((pol.actor(x_fix) - before).abs().max()) > 1e-2, "the updates did not move the policy: the test proves nothing"
+
+
 # --------------------------------------------------------------------------------------------
 # returns / advantages
 # --------------------------------------------------------------------------------------------
@@ -2069,9 +2103,12 @@ def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A
     """PPO.learn / GRPO.learn at 20-256x5 and 5-128x4 on ~4,000 rows, 2 updates, against the reference's loss scalars,
     gradients and post-step weights (pipelines/quadpole_pipeline_ppo.py:55-58, algorithms/grpo.py:106-148).
     The FIRST update's gradients are taken on the reference's own initial weights: one forward / backward pass, nothing else.
-      fp32 (per-layer GemmMLP path): first gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on
-        the GPU sits at the same 3-5e-3 in three critic layers (a ReLU that flips for one row between the CPU's and the
-        GPU's summation order), everything else at 1e-6; post-step weights <= 1e-5 (<= 0.5 % Adam-amplified outliers).
+      fp32: h128 (5-128x4) runs on the fp32 chain learner (tg_mlp_f32_forward_backward / tg_mlp_f32_weight_grad -- asserted
+        below: a gate that regresses must not silently re-test hipBLASLt), h256 on the per-layer GemmMLP path (library GEMMs +
+        HIP glue).  First gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on the GPU sits at
+        the same 3-5e-3 in three critic layers (a ReLU that flips for one row between the CPU's and the GPU's summation
+        order), everything else at 1e-6; post-step weights <= 1e-5 (<= 0.5 % Adam-amplified outliers).  (The tight anchors of
+        the fp32 chain kernels are test_f32_chain_update_matches_fp64_autograd and test_c2_size_grpo_learn_matches_the_oracle.)
       bf16 (tg_mlp_forward_chain / tg_mlp_backward_chain / tg_mlp_weight_grad): operands and stored activations are rounded
         to 8 significant bits, which costs torch's OWN bf16 autocast + autograd 0.3 % (head) to 10-12 % (first layer) of a
         first gradient in L2 at this depth.  The chain kernels must stay within 1.3 x that (measured in the same test with
@@ -2098,9 +2135,17 @@ def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A
         return pol, named, init, first, algo
 
     pol, named, init, first, algo = run(True)
+    nets = [pol.actor] + ([pol.critic] if kind == "ppo" else [])
     if cdt is not None:                                           # the chain kernels really ran
-        m = algo._mlp(pol.actor)
-        assert m._chain is not None and m._bchain is not None and m._dw_ws is not None
+        for net in nets:
+            m = algo._mlp(net)
+            assert m._chain is not None and m._bchain is not None and m._dw_ws is not None
+    elif tag == "h128":                                           # ... and so did the fp32 chain learner
+        for net in nets:
+            m = algo._mlp(net)
+            assert m._f32 is not None and m._dw_ws is not None, "5-128x4 fp32 fell off the fp32 chain learner"
+    else:
+        assert all(algo._mlp(net)._f32 is None for net in nets)   # (256 wide: outside mlp_f32_chain.hip's gate)
     st = algo.last_stats
     assert st["n_valid"] == int(g["n_valid"])
     lt = 2e-5 if cdt is None else 2e-3

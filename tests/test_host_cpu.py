@@ -175,3 +175,38 @@ def test_derived_layout_keys_follow_torch_version_counters_and_raw_writes():
     assert k2 != k1
     net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
     assert M.GemmMLP._key(obj) != k2
+
+
+def test_ones_column_mark_follows_the_prepared_bytes_not_their_address():
+    """"this input has the ones column" is marked on the STORAGE prepare_input() wrote, as a byte range.
+    Slices of whole rows see it; a partial-row view, a caller's own buffer and -- the failure the old address list had -- a NEW
+    allocation at a recycled address do not; a row copy (PPO's minibatch index_select) inherits it explicitly."""
+    import gc
+    from trajopt_grpo_amd import mlp as M
+    xp = torch.zeros(64, 32, dtype=torch.bfloat16)
+    assert not M.has_ones_column(xp)
+    M._mark_ones_column(xp)
+    assert M.has_ones_column(xp) and M.has_ones_column(xp[8:24]) and M.has_ones_column(xp[63:])
+    assert not M.has_ones_column(xp[:, :16]) and not M.has_ones_column(xp.view(-1, 16)[1:3])      # not whole rows
+    assert not M.has_ones_column(xp.view(32, 64))                                                    # another row length
+    own = torch.zeros(64, 32, dtype=torch.bfloat16)
+    assert not M.has_ones_column(own)
+    # a view over a larger workspace buffer: only the prepared rows count
+    big = torch.zeros(128 * 32, dtype=torch.bfloat16)
+    part = big[:40 * 32].view(40, 32)
+    M._mark_ones_column(part)
+    assert M.has_ones_column(big[:10 * 32].view(10, 32)) and not M.has_ones_column(big[: 50 * 32].view(50, 32))
+    # the mark dies with the allocation: whatever lands on the recycled address starts unmarked
+    addr = xp.data_ptr()
+    del xp
+    gc.collect()
+    for _ in range(64):
+        y = torch.zeros(64, 32, dtype=torch.bfloat16)
+        assert not M.has_ones_column(y)
+        if y.data_ptr() == addr:
+            break
+    # row copies
+    mb = part.index_select(0, torch.tensor([3, 1, 7]))
+    assert not M.has_ones_column(mb)
+    assert M.has_ones_column(M.inherit_ones_column(mb, part))
+    assert not M.has_ones_column(M.inherit_ones_column(own.index_select(0, torch.tensor([0, 1])), own))

@@ -444,7 +444,7 @@ class PPO(_GpuLearner):
         adv = adv_full.reshape(-1).index_select(0, idx)
         ret = rtg.reshape(-1).index_select(0, idx)
         old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)
-        M = X.shape[0]
+        n_rows = X.shape[0]
         all_sums = []
         for u in range(self.updates_per_iter):
             final = u == self.updates_per_iter - 1
@@ -453,18 +453,19 @@ class PPO(_GpuLearner):
                 self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums, last=final)
             else:
                 if self.permutation_fn is not None:
-                    perm = self.permutation_fn(M, X.device)
+                    perm = self.permutation_fn(n_rows, X.device)
                 else:
                     if self._gen is None:
                         self._gen = torch.Generator(device=X.device)
                         self._gen.manual_seed(self._seed)
-                    perm = torch.randperm(M, device=X.device, generator=self._gen)
+                    perm = torch.randperm(n_rows, device=X.device, generator=self._gen)
                 # every rank takes the same number of optimizer steps (each one is a collective); a rank that has run
                 # out of rows joins the remaining ones with an empty slice
-                local_bs, n_steps, sizes = D.minibatch_schedule(M, self.batch_size, self.process_group, X.device)
+                local_bs, n_steps, sizes = D.minibatch_schedule(n_rows, self.batch_size, self.process_group, X.device)
                 for k in range(n_steps):
                     b = perm[k * local_bs:(k + 1) * local_bs]
-                    self._step(xin.index_select(0, b), act.index_select(0, b), adv.index_select(0, b),
+                    # (the minibatch's rows are copies: they keep the prepared input's ones column, and say so)
+                    self._step(M.inherit_ones_column(xin.index_select(0, b), xin), act.index_select(0, b), adv.index_select(0, b),
                                ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums,
                                last=final and k == n_steps - 1)
         self._copy_policy_to_old()                                          # ppo.py:186

@@ -41,9 +41,30 @@ _F32_RECOMPUTE = os.environ.get("TG_F32_RECOMPUTE", "1") == "1"   # 0: store the
 _LOG = logging.getLogger("trajopt_grpo_amd")
 _LOGGED_SHAPES = set()
 
-# address ranges of the input buffers some GemmMLP.prepare_input() gave a column of ones (a property of the buffer, shared by
-# the nets that read it: the learner's actor and critic take the same prepared input)
-_ONES_RANGES = []
+# "This input has a column of ones" is a property of the BYTES some GemmMLP.prepare_input() wrote, shared by the nets that read them
+# (the learner's actor and critic take the same prepared input).  It is carried on the tensor's storage object -- torch keeps ONE
+# Python object per live storage, so the mark is seen through every slice / view and dies with the allocation (a block the caching
+# allocator hands out again is a new storage: no stale mark) -- as the byte range that was prepared.
+def _mark_ones_column(xp: torch.Tensor) -> None:
+    lo = xp.storage_offset() * xp.element_size()
+    xp.untyped_storage()._tg_ones = (lo, lo + xp.numel() * xp.element_size(), xp.shape[1] * xp.element_size())
+
+
+def has_ones_column(xin: torch.Tensor) -> bool:
+    """`xin` is a contiguous run of whole rows of an input some prepare_input() gave the ones column."""
+    if xin.dim() != 2 or not xin.is_contiguous():
+        return False
+    r = getattr(xin.untyped_storage(), "_tg_ones", None)
+    lo = xin.storage_offset() * xin.element_size()
+    return (r is not None and xin.shape[1] * xin.element_size() == r[2] and r[0] <= lo and lo + xin.numel() * xin.element_size() <= r[1]
+            and (lo - r[0]) % r[2] == 0)
+
+
+def inherit_ones_column(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """`dst` holds whole rows copied out of `src` (index_select of a minibatch): it has the ones column iff `src` has."""
+    if dst.dim() == 2 and dst.is_contiguous() and dst.shape[1:] == src.shape[1:] and dst.dtype == src.dtype and has_ones_column(src):
+        _mark_ones_column(dst)
+    return dst
 
 
 def lin_ok(l) -> bool:
@@ -212,12 +233,20 @@ class GemmMLP:
             log("%s is outside the hand-written learner kernels' shapes (%s): its update runs on hipBLASLt GEMMs + per-layer "
                          "HIP kernels, several times slower per row", shape, why)
 
-    def refresh(self):
+    def refresh(self, force: bool = False):
         """The fp32 master weights changed: every derived operand (padded compute-dtype copies, chain streams, packed
         backward-data fragments) is rebuilt the next time the path that reads it runs -- with the chain kernels active
-        the per-layer copies are never touched (17 of 36 tiny launches per update and net)."""
+        the per-layer copies are never touched (17 of 36 tiny launches per update and net).  force=True: whatever the keys say
+        (an entry point that cannot know who wrote the weights since its last call)."""
         k = self._key()
-        self._stale = {w for w in ("w", "chain", "bchain", "dx", "f32") if N.ALWAYS_REBUILD or self._built.get(w) != k}
+        self._stale = {w for w in ("w", "chain", "bchain", "dx", "f32") if force or N.ALWAYS_REBUILD or self._built.get(w) != k}
+
+    def fresh_forward(self, force: bool = False):
+        """Rebuild NOW what the no-grad forward() reads.  A captured hipGraph holds the forward launches only (a rebuild enqueued
+        during the capture's warm-up leaves nothing stale for the capture itself to record), so the per-step rollout calls this
+        eagerly in front of every replay: the graph then reads the rebuilt operands through the same buffers."""
+        self.refresh(force)
+        self._fresh("f32" if self._f32 is not None else ("chain" if self._chain is not None else "w"))
 
     def _key(self):
         """What every derived operand is a function of: the master tensors' storage and torch version counters, and the count of
@@ -261,17 +290,18 @@ class GemmMLP:
         xp[:, :self.in_dim].copy_(X)
         if self.in_pad == 32 and self.in_dim < 32 and self._f32 is None:
             # a padding column of ones: the first layer's weights are zero there (the forward pass does not see it), and
-            # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0.  The address range is
-            # remembered: only inputs prepared HERE (or slices of them) take that path -- a caller that pads its own input
-            # with zeros gets the HX job of tg_mlp_weight_grad instead of a silently zero bias gradient.
+            # tg_mlp_backward_chain_w0 delivers the first layer's bias gradient as that column of dW0.  The prepared bytes are
+            # marked on their storage: only inputs prepared HERE (slices of them, row copies registered with
+            # inherit_ones_column) take that path -- a caller that pads its own input with zeros gets the HX job of
+            # tg_mlp_weight_grad instead of a silently zero bias gradient.
             xp[:, 31] = 1.0
-            lo = xp.data_ptr()
-            _ONES_RANGES[:] = [r for r in _ONES_RANGES if r[0] != lo][-15:] + [(lo, lo + xp.numel() * xp.element_size())]
+            _mark_ones_column(xp)
+        elif getattr(xp.untyped_storage(), "_tg_ones", None) is not None:
+            del xp.untyped_storage()._tg_ones                 # (a buffer re-prepared by a net that writes no ones column)
         return xp
 
     def _has_ones_column(self, xin: torch.Tensor) -> bool:
-        p = xin.data_ptr()
-        return xin.is_contiguous() and any(lo <= p and p + xin.numel() * xin.element_size() <= hi for lo, hi in _ONES_RANGES)
+        return has_ones_column(xin)
 
     def _chain_backward_ok(self) -> bool:
         """backward() can take the chain path (tg_mlp_backward_chain + tg_mlp_weight_grad): fp32 gradients with unit column

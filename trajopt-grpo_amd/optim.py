@@ -143,10 +143,23 @@ class StreamRefresher:
         src = torch.cat(parts).to(stream_obj._idx.device)
         return src[stream_obj._idx].to(torch.int32)
 
+    def _signature(self):
+        """What the cached segment table is a function of: the optimizer's tensor table (the masters' pointers) AND every
+        destination buffer -- a stream that was dropped or re-allocated since (GemmMLP.disable_f32_chain, a re-created rollout
+        engine) must not be written through its old address."""
+        dst = []
+        for m in self.mlps:
+            for s_ in (m._chain, m._bchain, m._f32):
+                dst.append(None if s_ is None else (s_.stream.data_ptr(), getattr(s_, "bias", s_.stream).data_ptr()))
+        for x in self.extra:
+            dst.append((x.stream.data_ptr(), x.table.data_ptr()))
+        return (self.adam._sig, tuple(dst))
+
     def _build(self):
-        if self.adam._sig == self._sig and self._seg is not None:
-            return True
-        self._sig, self._seg, self._marks = self.adam._sig, None, []
+        sig = self._signature()
+        if sig == self._sig:
+            return self._seg is not None                  # (an unsupported layout is not re-attempted at every step)
+        self._sig, self._seg, self._marks = sig, None, []
         segs, keep, first = [], [], 0
         dev = None
         for m in self.mlps:
@@ -186,7 +199,8 @@ class StreamRefresher:
             if not self._build():
                 return False
         except (KeyError, AssertionError):
-            return False                                  # a net whose parameters are not in the optimizer's first group
+            self._seg = None                              # a net whose parameters are not in the optimizer's first group:
+            return False                                  # remembered under this signature, not rebuilt at every step
         seg, n, total, _, dev = self._seg
         tab, _, _ = self.adam.table(0)
         with torch.cuda.device(dev):

@@ -304,6 +304,12 @@ class DeviceRollout:
                     self._enqueue_steps(sample=True)
                 self._graph = g
                 self._graph_baked = baked
+            # The weights change with every learn().  The capture recorded no rebuild of the operands the forward launches read
+            # (its warm-up had just built them: nothing was stale), so they are rebuilt here, eagerly, in front of every replay;
+            # the graph reads them through the same buffers.  (The low-precision copies of a non-MLP actor ARE captured: their
+            # copies are unconditional.)
+            if self._mlp is not None:
+                self._mlp.fresh_forward()
             self._graph.replay()
 
 
