@@ -241,6 +241,127 @@ def _f32_pmc_bytes_per_row(family):
         return None, None
 
 
+class PowerSampler:
+    """Socket power (and the driver's sclk reading) of the device this rank runs on, sampled from a thread while a region runs:
+    hwmon's power1_input / freq1_input of the PCI device torch reports (microwatts / Hz; the files rocm-smi itself reads), or
+    `rocm-smi --showpower --json` when sysfs is not readable.  The update sits on the package power limit (power1_cap): the line
+    carries the evidence instead of a builder-kept profile."""
+
+    def __init__(self, torch, dev_index, period_s=0.025):
+        import glob
+        import threading
+        self.period, self.samples, self.sclk, self.marks = period_s, [], [], []
+        self._stop, self._thread, self._threading = threading.Event(), None, threading
+        self.hwmon = self.cap_W = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hits = glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*/power1_input")
+            if hits:
+                self.hwmon = os.path.dirname(hits[0])
+                with open(os.path.join(self.hwmon, "power1_cap")) as f:
+                    self.cap_W = int(f.read()) * 1e-6
+        except Exception:
+            self.hwmon = None
+        self.source = f"{self.hwmon}/power1_input" if self.hwmon else "rocm-smi --showpower --json"
+
+    def _read(self):
+        if self.hwmon:
+            with open(os.path.join(self.hwmon, "power1_input")) as f:
+                w = int(f.read()) * 1e-6
+            try:
+                with open(os.path.join(self.hwmon, "freq1_input")) as f:
+                    self.sclk.append(int(f.read()) * 1e-9)
+            except Exception:
+                pass
+            return w
+        out = subprocess.run(["rocm-smi", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+        card = next(iter(json.loads(out).values()))
+        return float(next(v for k, v in card.items() if "Power" in k))
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((time.perf_counter(), self._read()))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thread = self._threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2)
+
+    def window(self, t0, t1):
+        """Statistics of the samples taken in [t0, t1] (perf_counter times)."""
+        w = [v for t, v in self.samples if t0 <= t <= t1]
+        if not w:
+            return None
+        w.sort()
+        return {"mean": sum(w) / len(w), "median": w[len(w) // 2], "max": w[-1], "min": w[0], "samples": len(w), "cap": self.cap_W,
+                "source": self.source}
+
+
+def clock_probe_result(buf):
+    """(GHz, workgroups stamped) from a tg_clock_probe_attach buffer: shader-clock ticks / 100-MHz ticks, summed over workgroups."""
+    clk, real, n = (int(v) for v in buf[:3].tolist())
+    return (0.1 * clk / real if real > 0 else None), n
+
+
+def sustained_mfma_peak(tg, torch, dev, dtype_code, sampler=None):
+    """tg_mfma_sustained_probe run back to back: ~0.5 s to let the clock settle under the power limit, then ~100 ms timed by one HIP
+    event pair, its own in-kernel clock and the socket power beside it.  -> dict (TFLOP/s, GHz, W)."""
+    N_ = tg._native
+    lib = N_.load()
+    blocks = lib.tg_mfma_sustained_probe_blocks()
+    g = torch.Generator(device=dev).manual_seed(1)
+    if dtype_code == 0:
+        w = (torch.rand(32 * 1024, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        x = (torch.rand(blocks * 512 * 128, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        iters = 12000
+    else:
+        w = torch.rand(16 * 1024, device=dev, generator=g) * 2 - 1
+        x = torch.rand(blocks * 512 * 64, device=dev, generator=g) * 2 - 1
+        iters = 800
+    out = torch.empty(blocks * 512, device=dev)
+    probe = torch.zeros(N_.TG_CLOCK_PROBE_U64, dtype=torch.int64, device=dev)
+    st = N_.stream_ptr(dev)
+    launch = lambda: N_.check(lib.tg_mfma_sustained_probe(dtype_code, iters, w.data_ptr(), x.data_ptr(), out.data_ptr(), st), "tg_mfma_sustained_probe")
+    torch.cuda.synchronize()
+    launch()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); launch(); b.record()
+    torch.cuda.synchronize()
+    one_ms = a.elapsed_time(b)
+    n_warm, n_timed = max(4, int(500.0 / one_ms)), max(4, int(100.0 / one_ms))
+    for _ in range(n_warm):
+        launch()
+    torch.cuda.synchronize()
+    N_.check(lib.tg_clock_probe_attach(N_.TG_PROBE_MFMA_LOOP, probe.data_ptr()), "tg_clock_probe_attach")
+    t0 = time.perf_counter()
+    a.record()
+    for _ in range(n_timed):
+        launch()
+    b.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    N_.check(lib.tg_clock_probe_attach(N_.TG_PROBE_MFMA_LOOP, None), "tg_clock_probe_attach")
+    ms = a.elapsed_time(b)
+    ghz, _ = clock_probe_result(probe)
+    flops = lib.tg_mfma_sustained_probe_flops(dtype_code, iters) * n_timed
+    return {"TFLOPs": flops / ms / 1e9, "clock_GHz": ghz, "timed_ms": ms, "warm_ms": one_ms * n_warm,
+            "power_W": sampler.window(t0, t1) if sampler is not None else None,
+            "kernel": "tg::mfma_loop_bf16_kernel (v_mfma_f32_16x16x32_bf16)" if dtype_code == 0 else "tg::mfma_loop_f32_kernel (v_mfma_f32_32x32x2_f32)",
+            "what": "the chain kernels' bare inner loop (LDS A fragments, register B fragments, 2 waves per SIMD, no global traffic) run "
+                    "back to back: the matrix rate the package sustains under its power limit"}
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -347,8 +468,8 @@ def main():
 
     rank_check = None
     if args.check:
-        if world not in (2, 4):
-            raise SystemExit("--check compares an N-rank run with a one-rank run of 4-group cases: needs --gpus 2 or 4")
+        if world not in (2, 4, 8):
+            raise SystemExit("--check compares an N-rank run with a one-rank run of cases with max(4, N) groups: needs --gpus 2, 4 or 8")
         sys.path.insert(0, os.path.join(REPO, "tests"))
         import dist_product_worker as W
         solo = None
@@ -359,8 +480,8 @@ def main():
         names = [n for n in W.CASES if not n.endswith("ragged") or world == 2]
         with torch.cuda.device(dev):
             # (the worker runs on cuda:0 of the process; under nccl every rank has its own device, so make it current)
-            many = W.run_cases(names, rank, world, None, device=dev)
-            one = W.run_cases(names, 0, 1, solo, device=dev, emulate_world=world)
+            many = W.run_cases(names, rank, world, None, device=dev, groups=max(4, world))
+            one = W.run_cases(names, 0, 1, solo, device=dev, emulate_world=world, groups=max(4, world))
         rank_check = {n: W.check_case(one[n], [many[n]], n) for n in names}
         flag = torch.ones(1, device=dev)
         dist.all_reduce(flag)                                   # every rank got here: nobody raised
@@ -446,6 +567,20 @@ def main():
     # The cyclic garbage collector is off inside the timed region (as `timeit` does): the per-launch event objects this script keeps
     # -- 600 pairs per C4 step -- otherwise trigger a full collection somewhere in the region, a 70-150 ms host pause with nothing
     # queued on the GPU (C4, 20 steps: 43 against 49 M env-steps/s; the pause never happens without the events)
+    # ---- evidence that rides in the line: in-kernel clocks of the update's kernel families, socket power, collectives ----
+    N_ = tg._native
+    f32_learner = any(m._f32 is not None for m in learner_mlps)
+    chain_learner = any(m._chain is not None and m._bchain is not None for m in learner_mlps)
+    probe_fams = ({"fwd": N_.TG_PROBE_F32_CHAIN, "dw": N_.TG_PROBE_F32_WEIGHT_GRAD} if f32_learner else
+                  ({"fwd": N_.TG_PROBE_FWD_CHAIN, "bwd": N_.TG_PROBE_BWD_CHAIN, "dw": N_.TG_PROBE_WEIGHT_GRAD} if chain_learner else {}))
+    probe_bufs = {}
+    if rank == 0 and not args.no_launch_events:
+        torch.cuda.synchronize()
+        for fam, code in probe_fams.items():
+            probe_bufs[fam] = torch.zeros(N_.TG_CLOCK_PROBE_U64, dtype=torch.int64, device=dev)
+            N_.check(N_.load().tg_clock_probe_attach(code, probe_bufs[fam].data_ptr()), "tg_clock_probe_attach")
+    sampler = PowerSampler(torch, dev.index).start() if rank == 0 else None
+    tg.distributed.COLLECTIVE_LOG = coll_log = []
     import gc
     gc.collect()
     gc.disable()
@@ -480,8 +615,21 @@ def main():
         if (_ + 1) % 5 == 0:
             progress(f"step {_ + 1}/{args.steps}")
     barrier()
-    dt = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt = t_end - t0
     gc.enable()
+    tg.distributed.COLLECTIVE_LOG = None
+    clocks = {}
+    for fam, code in probe_fams.items():
+        if fam in probe_bufs:
+            clocks[fam] = clock_probe_result(probe_bufs[fam])
+            N_.check(N_.load().tg_clock_probe_attach(code, None), "tg_clock_probe_attach")
+    power_timed = sampler.window(t0, t_end) if sampler is not None else None
+    # collectives of the timed region on this rank: count, bytes and stream time per tag
+    coll = {}
+    for tag, nbytes, a, b in coll_log:
+        c = coll.setdefault(tag, {"count": 0, "bytes": 0, "ms": 0.0})
+        c["count"] += 1; c["bytes"] += nbytes; c["ms"] += a.elapsed_time(b)
     set_events(not args.no_launch_events)       # (the lists the code below reads)
     t_roll = sum(e[0].elapsed_time(e[1]) for e in phase_ev) * 1e-3
     t_learn = sum(e[1].elapsed_time(e[2]) for e in phase_ev) * 1e-3
@@ -538,16 +686,27 @@ def main():
                            "achieved_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9,
                            "frac_of_2500_TFLOPs": 2.0 * n_par * eng.traj.env_steps() / ms / 1e9 / 2500.0}
         del eng
-    tot = torch.tensor([float(env_steps), dt, t_roll, t_learn, fixed[0] if fixed else 0.0, float(fixed[1]) if fixed else 0.0],
+    coll_ms = sum(c["ms"] for c in coll.values())
+    tot = torch.tensor([float(env_steps), dt, t_roll, t_learn, fixed[0] if fixed else 0.0, float(fixed[1]) if fixed else 0.0, coll_ms],
                        dtype=torch.float64, device=dev)
+    steps_minmax = (float(env_steps), float(env_steps))
+    coll_ms_max = coll_ms
     if in_group:
-        mx = tot.clone()
+        mx, mn = tot.clone(), tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_steps, dt, t_roll, t_learn = float(tot[0]), float(mx[1]), float(mx[2]), float(mx[3])
         fixed = (float(mx[4]), float(tot[5])) if fixed else None
+        steps_minmax, coll_ms_max = (float(mn[0]), float(mx[0])), float(mx[6])
     else:
         total_steps = float(env_steps)
+    sustained = None
+    if rank == 0 and probe_fams and not args.no_launch_events:
+        progress("sustained matrix-rate probe (~1 s) ...")
+        sustained = sustained_mfma_peak(tg, torch, dev, 1 if f32_learner else 0, sampler)
+    if sampler is not None:
+        sampler.stop()
 
     if rank == 0:
         n_nets = len(nets)
@@ -578,6 +737,18 @@ def main():
             "rollout_ms": 1e3 * t_roll / args.steps,
             "launch_events": None if args.no_launch_events else {"every_nth_step": event_every, "timed_steps": timed_steps},
             "env_steps_per_step": total_steps / args.steps,
+            # per rank: the smallest / largest number of valid env-steps a rank processed per step (ranks wait for the slowest at
+            # every gradient all-reduce)
+            "env_steps_per_step_per_rank": {"min": steps_minmax[0] / args.steps, "max": steps_minmax[1] / args.steps},
+            # every collective of the timed region (rank 0's log; events on the stream the collective is ordered on, so `ms`
+            # includes waiting for the slowest rank): "grad" = ONE flat gradient all-reduce per optimizer step
+            "collectives": {"backend": (args.backend if in_group else None),
+                            "per_step": sum(c["count"] for c in coll.values()) / args.steps,
+                            "allreduce_ms_per_step": coll_ms / args.steps,
+                            "allreduce_ms_per_step_max_over_ranks": coll_ms_max / args.steps,
+                            "allreduce_bytes_per_step": sum(c["bytes"] for c in coll.values()) / args.steps,
+                            "by_tag": {k: {"per_step": v["count"] / args.steps, "bytes_each": v["bytes"] / max(v["count"], 1),
+                                           "ms_per_step": v["ms"] / args.steps} for k, v in sorted(coll.items())}},
             # fixed work: independent of how long the policy survives (the number of valid rows grows as it learns)
             "update_ns_per_valid_row": 1e9 * t_learn * world / total_steps if total_steps else None,
             "update_ns_per_row_update_net": 1e9 * t_learn * world / total_steps / updates / n_nets if total_steps else None,
@@ -674,6 +845,23 @@ def main():
                             "kernel": ls[0][3], "bytes_per_row": nbytes / nrows, "launches": len(ls),
                             "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
                             "total_ms_per_step": 1e3 * dur / max(timed_steps, 1), "note": notes[fam]}
+        # ---- the power-limit evidence, in the line: per family the clock its kernels ran at (in-kernel stamps of
+        # the timed region), the socket power over the timed region, and the matrix rate the package sustains at that limit ----
+        for fam, k in kernels.items():
+            ghz, n_wg = clocks.get(fam, (None, 0))
+            k["clock_GHz"] = ghz
+            k["clock_source"] = (f"tg_clock_probe_attach: s_memtime / s_memrealtime at entry and exit of every workgroup of every launch of "
+                                 f"the timed region ({n_wg} workgroups)") if ghz else None
+            k["power_W"] = power_timed
+            if sustained is not None:
+                mine = k["achieved"] if k["bound"] == "mfma" else k["matrix_TFLOPs"]
+                k["sustained_peak"] = sustained["TFLOPs"]
+                k["sustained_peak_unit"] = "TFLOP/s"
+                k["frac_of_sustained"] = mine / sustained["TFLOPs"]
+                k["sustained_peak_clock_GHz"] = sustained["clock_GHz"]
+                k["sustained_peak_power_W"] = sustained["power_W"]["mean"] if sustained["power_W"] else None
+        if sustained is not None:
+            out["sustained_matrix_rate"] = sustained
         if kernels:
             top = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
             out["roofline"] = dict(kernels[top], family=top,

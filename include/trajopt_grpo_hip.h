@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 9
+#define TG_ABI_VERSION 10
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -479,6 +479,27 @@ int  tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t tota
                   int64_t step, int32_t zero_grads, void* stream);
 int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table,
                        void* stream);
+
+/* ---- Measurement instruments (bench.py's roofline object; nothing on the product path calls them) ----
+ * tg_clock_probe_attach: the update's persistent kernels are bound by the package power limit, i.e. by the shader clock the chip
+ *   can hold while they run -- a clock neither rocm-smi's sclk nor a kernel duration shows.  With a probe attached, thread 0 of
+ *   every workgroup of the named kernel family stamps s_memtime (shader-clock ticks) and s_memrealtime (100 MHz) at entry and
+ *   exit and adds the differences to d_probe[0] / d_probe[1] (and 1 to d_probe[2]): clock = 0.1 GHz x d_probe[0] / d_probe[1].
+ *   d_probe: DEVICE array of TG_CLOCK_PROBE_U64 zeroed uint64 (the entry stamps are parked behind the sums), NULL detaches.
+ *   Synchronous (a symbol write); per device.  Detached (the default) a kernel pays one scalar load and a branch.
+ * tg_mfma_sustained_probe: the chain kernels' bare inner loop -- A fragments from LDS (ds_read_b128), B fragments in registers,
+ *   dependent accumulator chains, two waves per SIMD, one workgroup per CU, random data, no global traffic after the prologue --
+ *   for `iters` iterations: dtype 0 = v_mfma_f32_16x16x32_bf16 (the bf16 chain kernels' shape), 1 = v_mfma_f32_32x32x2_f32 (the
+ *   fp32 chain learner's).  Run back to back until the clock has settled it measures the matrix rate the package sustains under
+ *   its power limit: the ceiling the roofline's `sustained_peak` quotes beside the datasheet peak.  d_w: 64 KiB of operands,
+ *   d_x: blocks x 512 x 256 B, d_out: blocks x 512 floats; tg_mfma_sustained_probe_flops: flops of one launch. */
+enum { TG_PROBE_FWD_CHAIN = 0, TG_PROBE_BWD_CHAIN = 1, TG_PROBE_WEIGHT_GRAD = 2, TG_PROBE_F32_CHAIN = 3, TG_PROBE_F32_WEIGHT_GRAD = 4,
+       TG_PROBE_MFMA_LOOP = 5, TG_PROBE_FWD_CHAIN_PLAIN = 6 /* tg_mlp_forward_chain without the loss head: no-grad passes */ };
+#define TG_CLOCK_PROBE_U64 (4 + 2 * 4096)
+int  tg_clock_probe_attach(int32_t family, void* d_probe);
+int  tg_mfma_sustained_probe_blocks(void);
+double tg_mfma_sustained_probe_flops(int32_t dtype, int32_t iters);
+int  tg_mfma_sustained_probe(int32_t dtype, int32_t iters, const void* d_w, const void* d_x, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

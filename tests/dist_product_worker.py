@@ -52,13 +52,15 @@ def union_permutation(m_global, T, n_envs, emulate_world, batch_size, device):
     return torch.cat(out).to(device)
 
 
-def run_cases(names, rank, world, group=None, device=None, emulate_world=2):
-    """group=None: the default process group (or no group at all); a one-rank subgroup runs the cases alone inside a larger job."""
+def run_cases(names, rank, world, group=None, device=None, emulate_world=2, groups=None):
+    """group=None: the default process group (or no group at all); a one-rank subgroup runs the cases alone inside a larger job.
+    groups: run every case with this many groups instead of its own 4 (bench.py --check on 8 ranks: one group per rank)."""
     import trajopt_grpo_amd as tg
     dev = device if device is not None else torch.device("cuda", 0)
     out = {}
     for name in names:
         algo_name, env_name, env_kw, S, A, hidden, cdt, G, E, restart, updates, bs = CASES[name]
+        G = G if groups is None else int(groups)
         torch.manual_seed(1234)                                   # identical initial weights on every rank
         cls = tg.GaussianActorCritic_NeuralNetwork if algo_name == "ppo" else tg.GaussianActor_NeuralNetwork
         pol = cls(S, A, hidden, cov=0.3, device=dev)

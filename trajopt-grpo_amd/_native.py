@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TG_NATIVE_LIB: another build of the same library (probe builds with different compile-time flags, tools/mall_probe.py)
 LIB_PATH = os.environ.get("TG_NATIVE_LIB") or os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 9                      # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 10                     # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -134,7 +134,16 @@ SIGNATURES = {
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
     "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP]),
     "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
+    "tg_clock_probe_attach": (C.c_int, [_I32, _VP]),
+    "tg_mfma_sustained_probe_blocks": (C.c_int, []),
+    "tg_mfma_sustained_probe_flops": (C.c_double, [_I32, _I32]),
+    "tg_mfma_sustained_probe": (C.c_int, [_I32, _I32, _VP, _VP, _VP, _VP]),
 }
+
+# tg_clock_probe_attach families, and the size of a probe buffer in uint64
+(TG_PROBE_FWD_CHAIN, TG_PROBE_BWD_CHAIN, TG_PROBE_WEIGHT_GRAD, TG_PROBE_F32_CHAIN, TG_PROBE_F32_WEIGHT_GRAD, TG_PROBE_MFMA_LOOP,
+ TG_PROBE_FWD_CHAIN_PLAIN) = range(7)
+TG_CLOCK_PROBE_U64 = 4 + 2 * 4096
 
 _lib = None
 

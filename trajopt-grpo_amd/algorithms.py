@@ -338,7 +338,7 @@ class GRPO(_GpuLearner):
         self._copy_policy_to_old()                                          # grpo.py:148
         if self.updates_per_iter > 0:
             allJ = all_sums
-            D.allreduce_sum_(allJ, self.process_group)
+            D.allreduce_sum_(allJ, self.process_group, "loss_stats")
             self._stats_pending = lambda: {"J": (allJ[:, 0] / G_global).tolist(), "n_valid": allJ[0, 3].item()}
 
     def save(self, path: str) -> None:
@@ -433,7 +433,7 @@ class PPO(_GpuLearner):
             adv_full, rtg = K.gae_scan(rew, V, traj.mask, self.gamma, self.lam)   # ppo.py:112-124
         # global (all ranks) moments of the valid advantages and returns -> fused normalisation
         m = torch.cat([K.masked_moments(adv_full, traj.mask, n), K.masked_moments(rtg, traj.mask, n)])   # [2][3]
-        D.allreduce_sum_(m, self.process_group)
+        D.allreduce_sum_(m, self.process_group, "ppo_moments")
         cnt, s1, s2 = m[:, 0], m[:, 1], m[:, 2]
         mean = s1 / cnt
         std = torch.sqrt(torch.clamp((s2 - s1 * mean) / (cnt - 1.0), min=0.0)).float()     # unbiased, ppo.py:138-139
@@ -473,7 +473,7 @@ class PPO(_GpuLearner):
             S2 = torch.stack(all_sums)                                      # [steps][actor | critic][4]
             S = S2[:, 0].contiguous()
             S[:, 1] += S2[:, 1, 1]                                          # the critic's squared error
-            D.allreduce_sum_(S, self.process_group)
+            D.allreduce_sum_(S, self.process_group, "loss_stats")
             nn = S[:, 3]
             ent = 0.5 * act.shape[1] * (1.0 + math.log(2 * math.pi)) + 0.5 * float(torch.log(var).sum())
             actor = (-S[:, 0] / nn)

@@ -125,7 +125,7 @@ class Rollout_Buffer(Buffer):
             stats = torch.empty(3, dtype=torch.float64, device=dev)
             stats[0:1] = traj.rew.sum(dtype=torch.float64)
             stats[1].fill_(float(traj.n))
-            D.allreduce_sum_(stats[0:2], getattr(mgr, "process_group", None))
+            D.allreduce_sum_(stats[0:2], getattr(mgr, "process_group", None), "avg_reward")
             stats[2:3].copy_(traj.counters[0:1])              # this rank's valid rows (tg_rollout_finish)
             if getattr(self, "_pinned", None) is None:
                 self._pinned = torch.empty(3, dtype=torch.float64).pin_memory()

@@ -18,4 +18,17 @@ int set_error(int code, const char* fmt, ...) {
 extern "C" {
 const char* tg_last_error(void) { return tg::g_err; }
 int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+int tg_clock_probe_attach(int32_t family, void* d_probe) {
+    switch (family) {
+        case TG_PROBE_FWD_CHAIN: return tg::attach_probe_fwd_chain(d_probe);
+        case TG_PROBE_BWD_CHAIN: return tg::attach_probe_bwd_chain(d_probe);
+        case TG_PROBE_WEIGHT_GRAD: return tg::attach_probe_weight_grad(d_probe);
+        case TG_PROBE_F32_CHAIN: return tg::attach_probe_f32(0, d_probe);
+        case TG_PROBE_F32_WEIGHT_GRAD: return tg::attach_probe_f32(1, d_probe);
+        case TG_PROBE_MFMA_LOOP: return tg::attach_probe_mfma_loop(d_probe);
+        case TG_PROBE_FWD_CHAIN_PLAIN: return tg::attach_probe_fwd_chain_plain(d_probe);
+        default: return tg::set_error(TG_ERR_ARG, "tg_clock_probe_attach: family %d", family);
+    }
+}
 }

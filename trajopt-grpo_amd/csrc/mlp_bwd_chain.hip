@@ -26,6 +26,7 @@
 namespace tg {
 
 constexpr int kBwdMaxLayers = 6;
+TG_CLOCK_PROBE_VAR(g_probe_bwd_chain, attach_probe_bwd_chain)
 struct BwdChainPtrs {
     uint16_t* dz[kBwdMaxLayers];            // outputs, top hidden layer first: bf16 [rows][H]
     const uint32_t* mask[kBwdMaxLayers];    // ReLU mask bits of the same layers (tg_mlp_forward_chain): u32 [rows][H/32]
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
 
     int pre_pos = 0, pre_slot = 0, cur_slot = 0;
     int mseq = 0;                                   // running layer number of this workgroup; its masks sit in buffer mseq % 3
+    TG_CLOCK_PROBE_BEGIN(g_probe_bwd_chain)
     dma_dzh(blockIdx.x);
     if constexpr (kFuse0) dma_x0(blockIdx.x, 0);
     dma_mask(blockIdx.x, 0, 0);
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_bwd_chain_kernel(const uint4*
                 slab[(32 * b + 16 * ((wave >> 1) & 1) + 4 * grp + r) * 32 + 16 * (wave & 1) + col] = acc0[b][r];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+    TG_CLOCK_PROBE_END(g_probe_bwd_chain)
 }
 
 // Per-workgroup column sums of a dZ matrix (the bias gradient), for callers of tg_mlp_backward_chain that pass d_partial:

@@ -523,10 +523,13 @@ __device__ static void dw_run(const DwArgs& args, const DwJob& job, int64_t rows
     }
 }
 
+TG_CLOCK_PROBE_VAR(g_probe_weight_grad, attach_probe_weight_grad)
+
 template <int H>
 __global__ __launch_bounds__(512, 2) void dw_kernel(DwArgs args, int64_t rows, float* __restrict__ ws) {
     extern __shared__ uint4 lds[];
     char* lds_c = reinterpret_cast<char*>(lds);
+    TG_CLOCK_PROBE_BEGIN(g_probe_weight_grad)
     if (threadIdx.x == 0) lds[DwGeom<H>::ZERO / 16] = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
     int j = 0;
@@ -541,6 +544,8 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(DwArgs args, int64_t rows, f
         case DW_RH: dw_run<H, DW_RH>(args, job, rows, ws, lds_c); break;
         default: dw_run<H, DW_HR>(args, job, rows, ws, lds_c); break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TG_CLOCK_PROBE_END(g_probe_weight_grad)
 }
 
 // grad[m][n] += sum over the job's slabs, in slab order.  One thread per output element; consecutive threads read

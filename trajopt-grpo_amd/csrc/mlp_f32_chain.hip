@@ -88,6 +88,10 @@ __device__ static inline void store_tile(float* __restrict__ g, int64_t row, int
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(p + 8 * q) = float4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
+TG_CLOCK_PROBE_VAR(g_probe_f32_chain, attach_probe_f32_chain)          // the training pass (kTrain) only
+TG_CLOCK_PROBE_VAR(g_probe_f32_dw, attach_probe_f32_dw)
+int attach_probe_f32(int which, void* d_probe) { return which == 0 ? attach_probe_f32_chain(d_probe) : attach_probe_f32_dw(d_probe); }
+
 template <int H, bool kTrain>
 __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     constexpr int MT = H / 32;                  // 32-feature tiles per layer
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
 
     const int64_t rows = a.rows;
     const int64_t n_rounds = (rows + 255) / 256;
+    if constexpr (kTrain) { TG_CLOCK_PROBE_BEGIN(g_probe_f32_chain) }
 
     // ---- resident tables ----
     for (int q = tid; q < MT * (K2 / 4) * 64; q += 512) w0s[q] = net.w0[q];
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
             a.loss.work[(int64_t)blockIdx.x * 4 + tid] = t;
         }
     }
+    if constexpr (kTrain) { TG_CLOCK_PROBE_END(g_probe_f32_chain) }
 }
 
 template <int H>
@@ -836,6 +842,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
     constexpr int TW = MT >= 4 ? 2 : 1;                 // a wave's block of output tiles is TW x TW (H = 128: 2 x 2; H = 64: 1 x 1)
     extern __shared__ uint4 lds[];
     char* lds_c = reinterpret_cast<char*>(lds);
+    TG_CLOCK_PROBE_BEGIN(g_probe_f32_dw)
 #if TG_F32DW_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_loop0 = 0, st_loop1 = 0;
@@ -864,6 +871,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
         if (job.recompute == 3) f32_dw_fused<H, true, true>(job, rows, lds_c, ws);
         else if (job.recompute == 2) f32_dw_fused<H, true, false>(job, rows, lds_c, ws);
         else f32_dw_fused<H, false, true>(job, rows, lds_c, ws);
+        TG_CLOCK_PROBE_END(g_probe_f32_dw)
         return;
     }
     if (!head && !narrow) {
@@ -1104,6 +1112,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
             }
         if (tid < H) slab[H * H + tid] = bsum;
     }
+    TG_CLOCK_PROBE_END(g_probe_f32_dw)
 #if TG_F32DW_STAMPS
     if (lane == 0 && blockIdx.x < 1024) {
         unsigned long long* o = g_f32_stamps2 + ((size_t)blockIdx.x * 4 + wave) * 6;

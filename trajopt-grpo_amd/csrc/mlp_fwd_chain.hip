@@ -32,6 +32,8 @@ namespace tg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChainMaxHidden = 8;
+TG_CLOCK_PROBE_VAR(g_probe_fwd_chain, attach_probe_fwd_chain)              // the learner's training pass (kHead)
+TG_CLOCK_PROBE_VAR(g_probe_fwd_chain_plain, attach_probe_fwd_chain_plain)  // every other instantiation (no-grad passes, plain stores)
 struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; };   // activations, ReLU mask bits (or null)
 
 // kHead: the loss head and the head's weight gradient inside the forward pass (tg_mlp_forward_chain_loss).  The clipped-surrogate
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
     const int grp = lane >> 4, col = lane & 15;
     const int64_t n_rounds = (rows + 32 * WPW - 1) / (32 * WPW);
     const int n_blocks = n_hh * MT + 2;
+    if constexpr (kHead) { TG_CLOCK_PROBE_BEGIN(g_probe_fwd_chain) } else { TG_CLOCK_PROBE_BEGIN(g_probe_fwd_chain_plain) }
 
     for (int q = threadIdx.x; q < (n_hh + 2) * H; q += 64 * WPW) bias_s[q] = bias[q];
     if constexpr (kHead) {
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+    if constexpr (kHead) { TG_CLOCK_PROBE_END(g_probe_fwd_chain) } else { TG_CLOCK_PROBE_END(g_probe_fwd_chain_plain) }
 }
 
 template <int H, bool kStore, int D, bool kA0, bool kHead = false>

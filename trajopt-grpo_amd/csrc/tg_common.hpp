@@ -48,6 +48,46 @@ __device__ static inline float rn_div(float a, float b) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- in-kernel clock probe (tg_clock_probe_attach; bench.py's roofline.clock_GHz) ----
+// A translation unit that owns a probed kernel declares TG_CLOCK_PROBE_VAR(var, attach_fn) at namespace scope: a per-TU device
+// pointer (no -fgpu-rdc: every TU has its own) and the host function that sets it.  The kernel brackets its body with
+// TG_CLOCK_PROBE_BEGIN(var) / TG_CLOCK_PROBE_END(var).  Nothing is held in registers in between (the chain kernels have none to
+// spare): thread 0 parks the entry stamps in the probe buffer itself -- a store issued BEFORE any LDS-DMA of the kernel, so the
+// rings' counted vmcnt waits, which count the operations issued BEHIND a block, are not affected -- and reads them back (volatile:
+// no forwarding through a register) at the exit, behind the kernel's final vmcnt(0).
+#define TG_CLOCK_PROBE_VAR(var, attach_fn)                                                                                 \
+    static __device__ unsigned long long* var = nullptr;                                                                   \
+    int attach_fn(void* d_probe) {                                                                                         \
+        unsigned long long* p = (unsigned long long*)d_probe;                                                              \
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(var), &p, sizeof(p));                                                  \
+        return e == hipSuccess ? TG_OK : set_error(TG_ERR_HIP, "tg_clock_probe_attach: %s", hipGetErrorString(e));        \
+    }
+#define TG_CLOCK_PROBE_BEGIN(var)                                                                                          \
+    if (threadIdx.x == 0) {                                                                                                \
+        volatile unsigned long long* pr__ = var;                                                                           \
+        if (pr__ != nullptr && blockIdx.x < 4096u) {                                                                       \
+            pr__[4 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();                                                       \
+            pr__[5 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                                   \
+        }                                                                                                                  \
+    }
+#define TG_CLOCK_PROBE_END(var)                                                                                            \
+    if (threadIdx.x == 0) {                                                                                                \
+        unsigned long long* pr__ = var;                                                                                    \
+        if (pr__ != nullptr && blockIdx.x < 4096u) {                                                                       \
+            const unsigned long long c1__ = __builtin_amdgcn_s_memtime(), r1__ = __builtin_amdgcn_s_memrealtime();         \
+            const volatile unsigned long long* pk__ = pr__ + 4 + 2 * blockIdx.x;                                           \
+            atomicAdd(pr__ + 0, c1__ - pk__[0]);                                                                           \
+            atomicAdd(pr__ + 1, r1__ - pk__[1]);                                                                           \
+            atomicAdd(pr__ + 2, 1ull);                                                                                     \
+        }                                                                                                                  \
+    }
+int attach_probe_fwd_chain(void*);
+int attach_probe_fwd_chain_plain(void*);
+int attach_probe_bwd_chain(void*);
+int attach_probe_weight_grad(void*);
+int attach_probe_f32(int which, void*);
+int attach_probe_mfma_loop(void*);
+
 // Per-DEVICE launch state (one process may drive several GPUs): the device ordinal of the calling thread, its CU count,
 // and the opt-in to more than 64 KiB of dynamic LDS per kernel (gfx950 has 160 KiB per CU), cached per device.
 constexpr int kMaxDevices = 16;

@@ -38,10 +38,29 @@ def shard_groups(num_groups: int, rank: int, world: int) -> Tuple[int, int]:
 _ALWAYS = os.environ.get("TG_COLLECTIVES_AT_WORLD_1", "0") == "1"
 
 
-def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+# When set to a list, every collective of the path appends (tag, bytes, start event, end event) -- HIP events on the stream the
+# collective is ordered on (bench.py: `collectives` in the JSON line, so that a scaling curve can be read against the time and
+# the bytes its all-reduces took).  Tags: "grad" (the flat gradient bucket, one per optimizer step), "ppo_moments", "avg_reward",
+# "loss_stats", "minibatch_rows".
+COLLECTIVE_LOG = None
+
+
+def _collective(t: torch.Tensor, group, tag: str) -> None:
+    log = COLLECTIVE_LOG
+    if log is None or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(torch.cuda.current_stream(t.device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    b.record(torch.cuda.current_stream(t.device))
+    log.append((tag, t.numel() * t.element_size(), a, b))
+
+
+def allreduce_sum_(t: torch.Tensor, group=None, tag: str = "other") -> torch.Tensor:
     _, world = rank_world(group)
     if world > 1 or (_ALWAYS and dist.is_available() and dist.is_initialized()):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _collective(t, group, tag)
     return t
 
 
@@ -58,7 +77,7 @@ def minibatch_schedule(m_local: int, batch_size: int, group=None, device=None):
     if world > 1 or (_ALWAYS and dist.is_available() and dist.is_initialized()):
         t = torch.zeros(world, dtype=torch.int64, device=device)
         t[dist.get_rank(group)] = int(m_local)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)          # an all-gather of one integer per rank
+        _collective(t, group, "minibatch_rows")                        # an all-gather of one integer per rank
         counts = [int(v) for v in t.tolist()]
     n_steps = max(-(-c // local_bs) for c in counts)
     sizes = [sum(min(max(c - k * local_bs, 0), local_bs) for c in counts) for k in range(n_steps)]
@@ -89,7 +108,7 @@ class GradBucket:
             off += p.numel()
 
     def allreduce(self, group=None):
-        allreduce_sum_(self.flat, group)
+        allreduce_sum_(self.flat, group, "grad")
 
 
 def unbiased_moments(count: float, s1: float, s2: float) -> Tuple[float, float]:
