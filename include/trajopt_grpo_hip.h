@@ -480,6 +480,37 @@ int  tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t tota
 int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table,
                        void* stream);
 
+/* ---- The learner's prologue (algorithms/grpo.py:66-115, algorithms/ppo.py:126-139: returns, group statistics, `x[mask]`) ----
+ * tg_returns_moments: tg_rtg_scan + tg_masked_moments of the returns in two launches instead of three, in the form for rollouts of
+ *   a few thousand envs (a workgroup stages 64-step strips of 32 envs through LDS; one lane per env runs the recurrence in the
+ *   reference's order): d_rtg and d_moments are BIT-identical to tg_rtg_scan / tg_masked_moments.  d_work: f64 [3*n] scratch.
+ * tg_learn_count: valid entries per 1,024-entry chunk of the flat mask u8 [entries] (time-major [T][n]) and their exclusive prefix
+ *   into d_work (tg_learn_count_workspace(entries) bytes); d_total[0] = the number of valid entries, d_total[1] = 1 when
+ *   expected_rows >= 0 and differs from it (the host sized its buffers from the rollout's own statistic: a mask edited since then,
+ *   or a hand-built trajectory, must not pass silently).
+ * tg_learn_compact: for every valid (t, e), in time-major order (the order of `mask.nonzero()`), row r = its rank:
+ *     d_idx[r] = t*n + e;   d_xin[r][0..in_pad) = obs[.][t][e] converted to bf16 (xin_bf16) or f32, zero padded, 1 in column
+ *     `ones_col` (or -1);   d_act_rows[r][0..A) = act[.][t][e] (optional);   d_dst0[r] = d_src0[t*n + e],  d_dst1[r] = d_src1[..]
+ *   (optional [T][n] f32 sources; with d_moments, d_dst0 is tg_group_normalize(mode = norm_mode) of d_src0 evaluated for the valid
+ *   entries only -- same arithmetic, bit-identical).  d_offsets = tg_learn_count's d_work.  Rows >= rows_cap are not written.
+ *   obs: [S] planes of obs_feat_stride elements (TG_F32 / TG_F64), entry (t, e) at t*n + e; act: f32 [A][T][n]. */
+typedef struct tg_compact_args {
+    const uint8_t* d_mask; const void* d_offsets;
+    int64_t n; int32_t T; int32_t S; int32_t A; int32_t obs_dtype;
+    const void* d_obs; int64_t obs_feat_stride; const float* d_act;
+    void* d_xin; int32_t in_pad; int32_t xin_bf16; int32_t ones_col; int32_t norm_mode;
+    float* d_act_rows; int64_t* d_idx;
+    const float* d_src0; float* d_dst0; const float* d_src1; float* d_dst1;
+    const double* d_moments; int64_t group_size;
+    int64_t rows_cap;
+} tg_compact_args;
+int  tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg, int64_t n, int32_t T,
+                        int64_t group_size, double* d_moments, double* d_work, void* stream);
+int64_t tg_learn_count_workspace(int64_t entries);
+int  tg_learn_count(const uint8_t* d_mask, int64_t entries, int64_t expected_rows, void* d_work, int64_t work_bytes, int64_t* d_total,
+                    void* stream);
+int  tg_learn_compact(const tg_compact_args* args, void* stream);
+
 /* ---- Measurement instruments (bench.py's roofline object; nothing on the product path calls them) ----
  * tg_clock_probe_attach: the update's persistent kernels are bound by the package power limit, i.e. by the shader clock the chip
  *   can hold while they run -- a clock neither rocm-smi's sclk nor a kernel duration shows.  With a probe attached, thread 0 of

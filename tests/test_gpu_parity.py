@@ -1200,6 +1200,118 @@ def test_grpo_on_a_swarm_buffer_uses_group_statistics_across_bodies(tg, dev):
 
 
 # --------------------------------------------------------------------------------------------
+# the learner's prologue as native launches (csrc/learn_kernels.hip)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,n,E", [(1, 1, 1), (63, 31, 31), (64, 32, 8), (65, 33, 11), (128, 100, 25), (500, 4096, 64), (256, 96, 32), (300, 4100, 4100)])
+@pytest.mark.parametrize("gamma", [0.5, 0.999])
+def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, n, E, gamma):
+    """tg_returns_moments (LDS-staged strips, one lane per env on the recurrence: the form for a few thousand envs) against
+    tg_rtg_scan + tg_masked_moments, which are pinned to the reference (grpo.py:66-74,110-115): same bits, ragged episode lengths,
+    strips that do not divide the horizon, env counts that do not fill a workgroup, masks with holes."""
+    K = tg.hip_ops
+    g = torch.Generator(device="cpu").manual_seed(T * 1000 + n)
+    rew = torch.randn(T, n, generator=g).to(dev)
+    lens = torch.randint(0, T + 1, (n,), generator=g)
+    mask = (torch.arange(T).view(T, 1) < lens.view(1, n))
+    if T > 2:
+        mask[T // 2, ::7] = False                                # a hole: the reference's recurrence cuts the carry there
+    mask = mask.to(torch.uint8).to(dev)
+    rtg0 = K.rtg_scan(rew, mask, gamma)
+    mom0 = K.masked_moments(rtg0, mask, E)
+    rtg1, mom1 = K.returns_moments(rew, mask, gamma, E)
+    torch.cuda.synchronize()
+    assert torch.equal(rtg0, rtg1)
+    assert torch.equal(mom0.view(torch.int64), mom1.view(torch.int64))       # bit for bit (NaN-safe)
+
+
+@pytest.mark.parametrize("env_name,S,A,hidden,cdt,dtype", [("CartPole", 5, 1, (128, 128), None, torch.float32),
+                                                           ("QuadPole", 20, 4, (256, 256, 256), torch.bfloat16, torch.float32),
+                                                           ("QuadPole", 20, 4, (64, 64), None, torch.float64),
+                                                           ("QuadPole2D", 10, 2, (48, 48), None, torch.float32)])
+def test_learn_prepare_matches_the_torch_prologue(tg, dev, env_name, S, A, hidden, cdt, dtype):
+    """tg_learn_count + tg_learn_compact against what they replace (mask.nonzero(), three index_selects, prepare_input, the [T][n]
+    group normalisation): the same rows in the same (time-major) order, the same bits -- bf16 chain input with its ones column,
+    fp32 chain input padded to 8, per-layer fp32 input padded to 32, f64 trajectories; then the count check."""
+    from trajopt_grpo_amd import mlp as M
+    K = tg.hip_ops
+    T, G, E = 48, 6, 20
+    torch.manual_seed(1)
+    pol = tg.GaussianActor_NeuralNetwork(S, A, hidden, cov=0.6, device=dev)
+    env_cls = getattr(tg, env_name)
+    mgr = tg.RolloutManager(lambda: env_cls(max_steps=T), pol, num_workers=G, num_episodes_per_worker=E, seed=3, dtype=dtype,
+                            compute_dtype=cdt, fused=False if dtype == torch.float64 else None)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    tr = buf.device_traj
+    tr.mask[T // 3, ::5] = 0                                     # holes too: the compaction follows the mask, not the lengths
+    rows_true = int(tr.mask.sum())
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.9, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), updates_per_iter=1,
+                   autocast_dtype=cdt)
+    m = algo._mlp(pol.actor)
+    rew = tr.rew.float()
+    rtg = K.rtg_scan(rew, tr.mask, 0.9)
+    mom = K.masked_moments(rtg, tr.mask, tr.E)
+    tr.host_valid_rows = None                                    # (the statistic predates the holes: count on the device, read it back)
+    idx, xin, act, adv, ret = algo._prepare(tr, m, src0=rtg, moments=mom, norm_mode=0, group_size=tr.E, src1=rtg)
+    torch.cuda.synchronize()
+    idx0 = tr.mask.reshape(-1).nonzero().squeeze(1)
+    assert idx.numel() == rows_true and torch.equal(idx, idx0)
+    X0 = tr.obs_rows().index_select(0, idx0).float()
+    xin0 = m.prepare_input(X0)
+    assert xin.dtype == xin0.dtype and xin.shape == xin0.shape
+    assert torch.equal(xin.view(torch.int16 if xin.dtype == torch.bfloat16 else torch.int32), xin0.view(torch.int16 if xin.dtype == torch.bfloat16 else torch.int32))
+    assert M.has_ones_column(xin) == M.has_ones_column(xin0)
+    assert torch.equal(act, tr.act_rows().index_select(0, idx0))
+    adv0 = K.group_normalize(rtg, tr.mask, mom, 0, tr.E).reshape(-1).index_select(0, idx0)
+    assert torch.equal(adv.view(torch.int32), adv0.view(torch.int32)) and torch.equal(ret, rtg.reshape(-1).index_select(0, idx0))
+    # the host-known count: right -> no complaint; wrong -> the NEXT learn() entry raises, nothing is written out of bounds
+    tr.host_valid_rows = lambda: rows_true
+    algo._prepare(tr, m)
+    algo._check_row_count()
+    tr.host_valid_rows = lambda: rows_true - 3
+    idx_short = algo._prepare(tr, m)[0]
+    assert idx_short.numel() == rows_true - 3 and torch.equal(idx_short, idx0[:rows_true - 3])
+    with pytest.raises(RuntimeError, match="valid rows"):
+        algo._check_row_count()
+
+
+@pytest.mark.parametrize("kind,cdt,hidden", [("grpo", None, (128, 128)), ("grpo", torch.bfloat16, (128, 128, 128)), ("ppo", torch.bfloat16, (256, 256, 256)),
+                                             ("ppo", None, (64, 64)), ("ppo", None, (40, 40))])
+def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, kind, cdt, hidden):
+    """learn() on the native prologue (tg_returns_moments / tg_learn_count / tg_learn_compact) against the same learn() on the torch
+    prologue it replaces (TG_NATIVE_PREPARE=0): identical weights, bit for bit, after two updates."""
+    from trajopt_grpo_amd import algorithms as Alg
+
+    def run(native):
+        Alg._NATIVE_PREPARE = native
+        try:
+            torch.manual_seed(11)
+            cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
+            pol = cls(20, 4, hidden, cov=0.3, device=dev)
+            mgr = tg.RolloutManager(lambda: tg.QuadPole(max_steps=120), pol, num_workers=6, num_episodes_per_worker=40, seed=5, compute_dtype=cdt,
+                                    restart=kind == "grpo")
+            buf = tg.Rollout_Buffer(mgr)
+            buf.sample()
+            opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+            if kind == "ppo":
+                algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, gamma=0.99, batch_size=None, autocast_dtype=cdt)
+            else:
+                algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.9, policy=pol, optimizer=opt, updates_per_iter=2, autocast_dtype=cdt)
+            algo.learn(buf)
+            buf.sample()
+            algo.learn(buf)
+            torch.cuda.synchronize()
+            return [p.detach().clone() for p in pol.parameters()], algo.last_stats
+        finally:
+            Alg._NATIVE_PREPARE = True
+
+    (wa, sa), (wb, sb) = run(True), run(False)
+    assert sa["n_valid"] == sb["n_valid"] and sa["n_valid"] < 6 * 40 * 120          # (episodes do end early: ragged rows)
+    for a, b in zip(wa, wb):
+        assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------------------------
 # edge shapes
 # --------------------------------------------------------------------------------------------
 def test_degenerate_shapes(tg, dev):

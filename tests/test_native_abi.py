@@ -49,6 +49,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(N.LossArgs) == 8 * 11 + 8 * 4 + 4 * 5 + 4 + 8 * 5   # incl. 4 bytes of padding before d_grad_mean
     assert C.sizeof(N.DwJob) == 4 * 8 + 8 + 3 * 4 + 4 + 8 and N.DwJob.d_aux.offset == 56   # tg_dw_job (ABI 4: d_aux appended)
     assert (N.TG_DW_HH, N.TG_DW_HX, N.TG_DW_DH, N.TG_DW_HR, N.TG_DW_RH) == (0, 1, 2, 3, 4)
+    assert C.sizeof(N.CompactArgs) == 160 and N.CompactArgs.d_moments.offset == 136 and N.CompactArgs.rows_cap.offset == 152   # tg_compact_args
 
 
 def test_env_dims_and_default_params_follow_the_reference():

@@ -78,6 +78,16 @@ class ChainLoss(C.Structure):
                 ("critic_coef", C.c_float), ("kl_coef", C.c_float), ("d_dout8", C.c_void_p), ("d_head_slabs", C.c_void_p),
                 ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p)]
 
+class CompactArgs(C.Structure):
+    """tg_compact_args (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("d_mask", C.c_void_p), ("d_offsets", C.c_void_p), ("n", C.c_int64), ("T", C.c_int32), ("S", C.c_int32), ("A", C.c_int32),
+                ("obs_dtype", C.c_int32), ("d_obs", C.c_void_p), ("obs_feat_stride", C.c_int64), ("d_act", C.c_void_p),
+                ("d_xin", C.c_void_p), ("in_pad", C.c_int32), ("xin_bf16", C.c_int32), ("ones_col", C.c_int32), ("norm_mode", C.c_int32),
+                ("d_act_rows", C.c_void_p), ("d_idx", C.c_void_p), ("d_src0", C.c_void_p), ("d_dst0", C.c_void_p),
+                ("d_src1", C.c_void_p), ("d_dst1", C.c_void_p), ("d_moments", C.c_void_p), ("group_size", C.c_int64),
+                ("rows_cap", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/trajopt_grpo_hip.h declares
 _P, _I32, _I64, _U64, _F, _VP = C.POINTER, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 SIGNATURES = {
@@ -134,6 +144,10 @@ SIGNATURES = {
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
     "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP]),
     "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
+    "tg_returns_moments": (C.c_int, [_VP, _VP, _F, _VP, _I64, _I32, _I64, _VP, _VP, _VP]),
+    "tg_learn_count_workspace": (C.c_int64, [_I64]),
+    "tg_learn_count": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP, _VP]),
+    "tg_learn_compact": (C.c_int, [C.POINTER(CompactArgs), _VP]),
     "tg_clock_probe_attach": (C.c_int, [_I32, _VP]),
     "tg_mfma_sustained_probe_blocks": (C.c_int, []),
     "tg_mfma_sustained_probe_flops": (C.c_double, [_I32, _I32]),

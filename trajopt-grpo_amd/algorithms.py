@@ -33,6 +33,8 @@ from .rollout import DeviceTrajectory
 
 _NONZERO_STATIC = os.environ.get("TG_NONZERO_STATIC", "1") == "1"  # 0: torch.nonzero (a host round trip for the shape) even when the count is known
 _FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
+_NATIVE_PREPARE = os.environ.get("TG_NATIVE_PREPARE", "1") == "1"  # 0: the prologue as torch launches (nonzero, index_selects, pads: A/B runs)
+_SMALL_N_RETURNS = 16384                                           # envs up to which tg_returns_moments replaces tg_rtg_scan + tg_masked_moments
 
 
 class Algorithm(ABC):
@@ -118,6 +120,7 @@ class _GpuLearner(Algorithm):
                 for m in self._mlps.values():
                     if m is not None:
                         m._ws.default_cap = max(m._ws.default_cap, cap)
+            self._check_row_count()
             self._learn(buffer)
 
     @property
@@ -273,6 +276,57 @@ class _GpuLearner(Algorithm):
         act = torch.index_select(acts_all, 0, idx, out=self._ws.get("act", idx.numel(), traj.A, acts_all.dtype, idx.device, cap))
         return idx, X, act
 
+    # ---- the prologue as four launches (csrc/learn_kernels.hip) ------------------------------------------------------
+    def _check_row_count(self):
+        """The flag of the previous learn()'s tg_learn_count, read long after it was written: the valid rows the mask held were not
+        the number the rollout's statistic gave the host (a mask edited after sample(), a hand-built trajectory)."""
+        pend = getattr(self, "_count_pending", None)
+        if pend is None:
+            return
+        host, ev, expected = pend
+        self._count_pending = None
+        ev.synchronize()
+        total, flag = host.tolist()
+        if flag:
+            raise RuntimeError(f"the trajectory's mask held {total} valid rows, the rollout's statistic said {expected}: the last learn() "
+                               "ran on truncated / padded rows (was the mask edited after sample()?)")
+
+    def _prepare(self, traj, m, src0=None, moments=None, norm_mode=0, group_size=0, src1=None):
+        """What `obs[mask]`, `act[mask]`, `adv[mask]` (algorithms/ppo.py:126-135, grpo.py:76-112) and GemmMLP.prepare_input() produce,
+        straight from the device trajectory into the learner's workspaces: (idx int64 [rows], xin [rows][in_pad] compute dtype with the
+        ones column, act [rows][A], src0's valid entries (normalised with `moments` when given), src1's valid entries).  None when
+        this net has no GemmMLP or the trajectory's dtype is not f32 / f64 (the torch path then does it)."""
+        if m is None or not _NATIVE_PREPARE or traj.obs.dtype not in (torch.float32, torch.float64) or m.in_pad > 64 or traj.S > m.in_pad:
+            return None
+        if m.in_pad % (8 if m.cd == torch.bfloat16 else 4) or m.cd not in (torch.bfloat16, torch.float32):
+            return None
+        dev, cap = traj.mask.device, traj.T * traj.n
+        work = self._ws.get("cnt_work", (K.learn_count_workspace(cap) + 3) // 4, 1, torch.int32, dev)
+        total = torch.empty(2, dtype=torch.int64, device=dev)
+        if traj.host_valid_rows is not None:
+            rows = int(traj.host_valid_rows())                   # on the host already: no round trip, the launches go out back to back
+            K.learn_count(traj.mask, rows, work, total)
+            if getattr(self, "_count_pinned", None) is None:
+                self._count_pinned = torch.empty(2, dtype=torch.int64).pin_memory()
+            self._check_row_count()
+            self._count_pinned.copy_(total, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._count_pending = (self._count_pinned, ev, rows)
+        else:
+            K.learn_count(traj.mask, -1, work, total)
+            rows = int(total[0].item())
+        idx = self._ws.get("idx", rows, 1, torch.int64, dev, cap).view(-1)
+        xin = self._ws.get("xin", rows, m.in_pad, m.cd, dev, cap)
+        act = self._ws.get("act", rows, traj.A, torch.float32, dev, cap)
+        d0 = self._ws.get("row0", rows, 1, torch.float32, dev, cap).view(-1) if src0 is not None else None
+        d1 = self._ws.get("row1", rows, 1, torch.float32, dev, cap).view(-1) if src1 is not None else None
+        ones = 31 if (m.in_pad == 32 and m.in_dim < 32 and m._f32 is None) else -1
+        if rows > 0:
+            K.learn_compact(traj, work, rows, xin, ones, act, idx, src0, d0, src1, d1, moments, norm_mode, group_size)
+        M.set_ones_column(xin, ones >= 0)
+        return idx, xin, act, d0, d1
+
     def _logp_nograd(self, actor, xin, act, var):
         out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
         for lo in range(0, xin.shape[0], self.chunk_rows):
@@ -302,17 +356,27 @@ class GRPO(_GpuLearner):
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
-        rtg = K.rtg_scan(rew, traj.mask, self.gamma)                        # grpo.py:66-74
-        moments = K.masked_moments(rtg, traj.mask, traj.E)                  # per group, grpo.py:110-115
-        adv_full = K.group_normalize(rtg, traj.mask, moments, 0, traj.E)
-        idx, X, act = self._gather_valid(traj)
-        adv = adv_full.reshape(-1).index_select(0, idx)
+        if traj.n <= _SMALL_N_RETURNS and _NATIVE_PREPARE:                  # grpo.py:66-74; per group, grpo.py:110-115
+            rtg, moments = K.returns_moments(rew, traj.mask, self.gamma, traj.E)
+        else:
+            rtg = K.rtg_scan(rew, traj.mask, self.gamma)
+            moments = K.masked_moments(rtg, traj.mask, traj.E)
+        actor = self.policy.actor
+        # the valid rows: index, padded input row, action and group-relative advantage (grpo.py:76-115) in one pass over the mask
+        prepared = self._prepare(traj, self._mlp(actor), src0=rtg, moments=moments, norm_mode=0, group_size=traj.E)
+        if prepared is not None:
+            idx, xin, act, adv, _ = prepared
+        else:
+            adv_full = K.group_normalize(rtg, traj.mask, moments, 0, traj.E)
+            idx, X, act = self._gather_valid(traj)
+            adv = adv_full.reshape(-1).index_select(0, idx)
         _, world = D.rank_world(self.process_group)
         G_global = traj.G * world
         coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
-        actor = self.policy.actor
         self._refresh(actor, self.old_policy.actor)
-        xin = self._prep(actor, X, traj.T * traj.n)
+        if prepared is None:
+            xin = self._prep(actor, X, traj.T * traj.n)
+        X = xin                                                             # (the loops below only ask for its row count and device)
         old_logp = self._logp_nograd(self.old_policy.actor, xin, act, var)  # grpo.py:118-119
         all_sums = torch.zeros(max(self.updates_per_iter, 1), 4, dtype=torch.float64, device=X.device)
         for u in range(self.updates_per_iter):
@@ -413,14 +477,20 @@ class PPO(_GpuLearner):
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         T, n = traj.T, traj.n
-        idx, X, act = self._gather_valid(traj)
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
         m_a, m_c = self._mlp(self.policy.actor), self._mlp(self.policy.critic)
         if m_a is not None and m_c is not None and m_a.in_pad != m_c.in_pad:
             m_a.disable_f32_chain()                       # (only one of the two fits the fp32 chain learner: both take the
             m_c.disable_f32_chain()                       #  per-layer path, so that they keep sharing ONE prepared input)
         self._refresh(self.policy.actor, self.policy.critic)
-        xin = self._prep(self.policy.actor, X, traj.T * traj.n)   # actor and critic share input width / compute dtype
+        # the valid rows (ppo.py:126-135): index, padded input row (actor and critic share input width / compute dtype), action
+        prepared = self._prepare(traj, m_a) if (m_c is not None and m_a is not None and m_c.in_pad == m_a.in_pad and m_c.cd == m_a.cd) else None
+        if prepared is not None:
+            idx, xin, act, _, _ = prepared
+        else:
+            idx, X, act = self._gather_valid(traj)
+            xin = self._prep(self.policy.actor, X, traj.T * traj.n)
+        X = xin                                                             # (below: row count and device only)
         # V on valid rows only; padded rows never reach a result (they are masked in both scans)
         v_valid = self._values_nograd(xin)                                  # ppo.py:93
         V = torch.zeros(T * n, dtype=torch.float32, device=X.device)

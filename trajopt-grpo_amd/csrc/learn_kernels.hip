@@ -1,0 +1,371 @@
+// The learner's prologue as a handful of launches: what /root/reference does between `buffer.sample()` and the first forward pass
+// of `learn()` (algorithms/grpo.py:66-115 -- reward-to-go, group statistics, masking; algorithms/ppo.py:126-139 -- the boolean-mask
+// gather `obs[mask]`, `act[mask]`, `adv[mask]`) and what rounds 1-3 ran as ~25 torch launches (nonzero, three index_selects, pads,
+// fills).
+//
+//   tg_returns_moments   reward-to-go AND the per-env masked moments of it in ONE launch, for rollouts of a few thousand envs.  The
+//                        stand-alone kernels (returns_kernels.hip) give every env one lane that walks its own time axis with 32 loads
+//                        in flight: right at 65,536 envs (HBM-bound), but at 4,096 envs the launch is 64 waves, each waiting for 16
+//                        rounds of dependent global-load latency (37 + 32 us for 18 MB).  Here a workgroup owns 32 envs: all four
+//                        waves stage a 64-step strip of rewards and masks into LDS with coalesced loads (the next strip in flight
+//                        behind the current one), ONE lane per env runs the recurrence out of LDS in the reference's order --
+//                        bit-identical to tg_rtg_scan -- and all waves store the strip; the moments are then accumulated per env
+//                        in ascending time order from the returns just written (bit-identical to tg_masked_moments' first stage).
+//   tg_learn_count       valid rows per 1,024-entry chunk of the flat [T*n] mask and their exclusive prefix: the row number of every
+//                        valid (t, n) in time-major order (what `mask.nonzero()` enumerates), the total, and a flag when the total is
+//                        not what the host was told (the rollout's own statistic).
+//   tg_learn_compact     one pass over the mask that writes, for every valid row, its flat index, the observation as a padded
+//                        compute-dtype input row (bf16 or f32, zero padding, the ones column the backward chain wants), the action
+//                        row, and up to two per-row scalars gathered from [T][n] arrays -- the first one optionally normalised on
+//                        the fly with tg_group_normalize's arithmetic (GRPO's advantage: no [T][n] advantage array at all).
+#include "tg_common.hpp"
+
+namespace tg {
+
+// ---------------------------------------------------------------------------------------------------------------
+// returns + per-env moments, small-n form
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRmEnvs = 32;          // envs per workgroup
+constexpr int kRmStrip = 64;         // time steps per LDS strip
+
+__global__ __launch_bounds__(256) void returns_moments_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ mask, float gamma,
+                                                              float* __restrict__ rtg, int64_t n, int32_t T, double* __restrict__ work) {
+    __shared__ float s_r[2][kRmStrip][kRmEnvs];
+    __shared__ float s_m[2][kRmStrip][kRmEnvs];
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * kRmEnvs;
+    const int le = tid & (kRmEnvs - 1), lt0 = tid / kRmEnvs;            // this thread's env column and its first row of a strip (8 rows apart)
+    const bool env_ok = e0 + le < n;
+    const int n_strips = (T + kRmStrip - 1) / kRmStrip;
+    // strip s covers time steps [t_lo, t_lo + 64) with t_lo = T - 64 (s + 1) (clamped at 0: the first strip of the walk is the LAST
+    // time steps); rows outside [0, T) are not loaded
+    auto load = [&](int s, float (&vr)[kRmStrip / 8], float (&vm)[kRmStrip / 8]) {
+        const int t_lo = T - kRmStrip * (s + 1);
+#pragma unroll
+        for (int k = 0; k < kRmStrip / 8; ++k) {
+            const int t = t_lo + lt0 + 8 * k;
+            vr[k] = 0.f; vm[k] = 0.f;
+            if (env_ok && t >= 0) {
+                const int64_t idx = (int64_t)t * n + e0 + le;
+                vr[k] = rew[idx];
+                vm[k] = (float)mask[idx];
+            }
+        }
+    };
+    auto park = [&](int buf, const float (&vr)[kRmStrip / 8], const float (&vm)[kRmStrip / 8]) {
+#pragma unroll
+        for (int k = 0; k < kRmStrip / 8; ++k) {
+            s_r[buf][lt0 + 8 * k][le] = vr[k];
+            s_m[buf][lt0 + 8 * k][le] = vm[k];
+        }
+    };
+    float vr[kRmStrip / 8], vm[kRmStrip / 8];
+    load(0, vr, vm);
+    park(0, vr, vm);
+    __syncthreads();
+    float carry = 0.0f;                       // (gamma * R[t+1]) * m[t+1] of this lane's env
+    for (int s = 0; s < n_strips; ++s) {
+        const int buf = s & 1, t_lo = T - kRmStrip * (s + 1);
+        if (s + 1 < n_strips) load(s + 1, vr, vm);                     // in flight under the recurrence
+        if (tid < kRmEnvs) {
+            // one lane per env, the reference's order (grpo.py:66-74): R = r m + carry; carry = (gamma R) m -- individually rounded
+#pragma unroll 8
+            for (int k = kRmStrip - 1; k >= 0; --k) {
+                if (t_lo + k < 0) break;
+                const float mf = s_m[buf][k][tid];
+                const float R = rn_add(rn_mul(s_r[buf][k][tid], mf), carry);
+                s_r[buf][k][tid] = R;
+                carry = rn_mul(rn_mul(gamma, R), mf);
+            }
+        }
+        __syncthreads();                                               // the strip's returns are in s_r[buf]
+#pragma unroll
+        for (int k = 0; k < kRmStrip / 8; ++k) {
+            const int t = t_lo + lt0 + 8 * k;
+            if (env_ok && t >= 0) rtg[(int64_t)t * n + e0 + le] = s_r[buf][lt0 + 8 * k][le];
+        }
+        if (s + 1 < n_strips) park(buf ^ 1, vr, vm);
+        __syncthreads();                                               // next strip parked; this strip's LDS may be reused after the next one
+    }
+    // ---- per-env moments over the valid steps, ascending in time (tg_masked_moments' env stage: same order, same fp64 sums) ----
+    // all waves stage strips of the returns just written (L2 hits) and of the masks; lane e of wave 0 accumulates
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int s = n_strips - 1; s >= 0; --s) {                           // ascending time = descending strip number
+        const int t_lo = T - kRmStrip * (s + 1);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kRmStrip / 8; ++k) {
+            const int t = t_lo + lt0 + 8 * k;
+            float v = 0.f, m = 0.f;
+            if (env_ok && t >= 0) {
+                const int64_t idx = (int64_t)t * n + e0 + le;
+                v = rtg[idx];
+                m = (float)mask[idx];
+            }
+            s_r[0][lt0 + 8 * k][le] = v;
+            s_m[0][lt0 + 8 * k][le] = m;
+        }
+        __syncthreads();
+        if (tid < kRmEnvs) {
+            for (int k = (t_lo < 0 ? -t_lo : 0); k < kRmStrip; ++k) {
+                if (s_m[0][k][tid] != 0.f) {
+                    const double d = (double)s_r[0][k][tid];
+                    cnt += 1.0; s1 += d; s2 += d * d;
+                }
+            }
+        }
+    }
+    if (tid < kRmEnvs && e0 + tid < n) {
+        work[e0 + tid] = cnt;
+        work[n + e0 + tid] = s1;
+        work[2 * n + e0 + tid] = s2;
+    }
+}
+
+// one workgroup per group: fixed-order reduction of the group's per-env partials (returns_kernels.hip::group_moments_kernel's twin:
+// that one is static to its translation unit)
+__global__ __launch_bounds__(256) void group_moments2_kernel(const double* __restrict__ work, int64_t n, int64_t group_size,
+                                                             double* __restrict__ moments) {
+    __shared__ double sh[3][4];
+    const int64_t g = blockIdx.x;
+    const int64_t base = g * group_size;
+    double acc[3] = {0, 0, 0};
+    for (int64_t e = threadIdx.x; e < group_size; e += blockDim.x) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += work[j * n + base + e];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sh[j][w] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int j = threadIdx.x;
+        moments[g * 3 + j] = ((sh[j][0] + sh[j][1]) + sh[j][2]) + sh[j][3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compaction of the valid rows
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kChunkElems = 1024;     // flat mask entries per workgroup (256 threads x 4)
+
+__device__ static inline uint32_t load_mask4(const uint8_t* __restrict__ mask, int64_t f0, int64_t M) {
+    // 4 consecutive mask bytes as flags in bits 0, 8, 16, 24 (entries past the end: 0)
+    if (f0 + 3 < M && ((uintptr_t)(mask + f0) & 3) == 0) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(mask + f0);
+        return ((w & 0x000000FFu) ? 1u : 0u) | ((w & 0x0000FF00u) ? 0x100u : 0u) | ((w & 0x00FF0000u) ? 0x10000u : 0u) |
+               ((w & 0xFF000000u) ? 0x1000000u : 0u);
+    }
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (f0 + k < M && mask[f0 + k]) v |= 1u << (8 * k);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t* __restrict__ mask, int64_t M, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t sh[4];
+    const int64_t f0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t c = __popc(load_mask4(mask, f0, M));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// counts[c] -> exclusive prefix in place; total[0] = sum, total[1] = (sum != expected) when expected >= 0.  One workgroup.
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(uint32_t* __restrict__ counts, int64_t n_chunks, int64_t expected,
+                                                          int64_t* __restrict__ total) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_chunks; base += 1024) {
+        const int64_t i = base + tid;
+        const uint64_t v = i < n_chunks ? counts[i] : 0u;
+        uint64_t x = v;                                                 // inclusive scan within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n_chunks) counts[i] = (uint32_t)(before + x - v);
+        __syncthreads();
+        if (tid == 1023) carry_s = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        total[0] = (int64_t)carry_s;
+        total[1] = (expected >= 0 && (int64_t)carry_s != expected) ? 1 : 0;
+    }
+}
+
+struct CompactArgs {
+    const uint8_t* mask; const uint32_t* offsets; int64_t M, n, rows_cap;
+    const void* obs; int64_t obs_feat_stride; int32_t S, obs_f64;
+    const float* act; int64_t act_comp_stride; int32_t A;
+    void* xin; int32_t in_pad, xin_bf16, ones_col;
+    float* act_rows; int64_t* idx;
+    const float* src0; float* dst0; const float* src1; float* dst1;
+    const double* moments; int32_t norm_mode; int64_t group_size;
+};
+
+__device__ static inline uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));    // round to nearest even, as torch's copy_
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
+    __shared__ uint32_t sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t f0 = ((int64_t)blockIdx.x * 256 + tid) * 4;
+    const uint32_t flags = load_mask4(a.mask, f0, a.M);
+    const uint32_t c = __popc(flags);
+    uint32_t x = c;                                                     // inclusive scan of the per-thread counts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += sh[w];
+    int64_t out = (int64_t)a.offsets[blockIdx.x] + before + x - c;     // row number of this thread's first valid entry
+    if (c == 0) return;
+    const OT* obs = reinterpret_cast<const OT*>(a.obs);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        if (!((flags >> (8 * k)) & 1u)) continue;
+        const int64_t f = f0 + k;
+        if (out >= a.rows_cap) return;                                  // more valid rows than the host was told: flagged by the scan
+        a.idx[out] = f;
+        // observation row: obs[s][t][e], element (t, e) = flat entry f of feature plane s (the plane holds T + 1 slots: f indexes the first T)
+        if (a.xin_bf16) {
+            uint32_t* row = reinterpret_cast<uint32_t*>(a.xin) + out * (a.in_pad / 2);
+            for (int s0 = 0; s0 < a.in_pad; s0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int s = s0 + j;
+                    v[j] = s < a.S ? (float)obs[(int64_t)s * a.obs_feat_stride + f] : (s == a.ones_col ? 1.0f : 0.0f);
+                }
+                *reinterpret_cast<uint4*>(row + s0 / 2) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                                  pack_bf16x2(v[6], v[7])};
+            }
+        } else {
+            float* row = reinterpret_cast<float*>(a.xin) + out * a.in_pad;
+            for (int s0 = 0; s0 < a.in_pad; s0 += 4) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = s0 + j;
+                    v[j] = s < a.S ? (float)obs[(int64_t)s * a.obs_feat_stride + f] : (s == a.ones_col ? 1.0f : 0.0f);
+                }
+                *reinterpret_cast<float4*>(row + s0) = float4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        if (a.act_rows) {
+            for (int j = 0; j < a.A; ++j) a.act_rows[out * a.A + j] = a.act[(int64_t)j * a.act_comp_stride + f];
+        }
+        if (a.dst0) {
+            float v = a.src0[f];
+            if (a.moments) {
+                // tg_group_normalize's arithmetic (returns_kernels.hip::group_normalize_kernel), for this one entry
+                const double* mo = a.moments + ((f % a.n) / a.group_size) * 3;
+                const double cnt = mo[0], s1 = mo[1], s2 = mo[2];
+                const double mean = s1 / cnt;
+                const double var = (s2 - s1 * mean) / (cnt - 1.0);
+                const float meanf = (float)mean;
+                const float stdf = (float)sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+                const float denom = a.norm_mode == 0 ? stdf : rn_add(stdf, 1e-8f);
+                v = rn_div(rn_sub(v, meanf), denom);
+            }
+            a.dst0[out] = v;
+        }
+        if (a.dst1) a.dst1[out] = a.src1[f];
+        ++out;
+    }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg, int64_t n, int32_t T, int64_t group_size,
+                       double* d_moments, double* d_work, void* stream) {
+    TG_REQUIRE(d_rew && d_mask && d_rtg && d_moments && d_work, "tg_returns_moments: null pointer");
+    TG_REQUIRE(n > 0 && T > 0 && group_size > 0 && n % group_size == 0,
+               "tg_returns_moments: n=%lld must be a positive multiple of group_size=%lld", (long long)n, (long long)group_size);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(returns_moments_kernel, dim3((unsigned)ceil_div(n, kRmEnvs)), dim3(256), 0, st, d_rew, d_mask, gamma, d_rtg, n, T, d_work);
+    TG_LAUNCH_CHECK("tg_returns_moments");
+    hipLaunchKernelGGL(group_moments2_kernel, dim3((unsigned)(n / group_size)), dim3(256), 0, st, d_work, n, group_size, d_moments);
+    TG_LAUNCH_CHECK("tg_returns_moments(group)");
+    return TG_OK;
+}
+
+int64_t tg_learn_count_workspace(int64_t entries) { return (ceil_div(entries > 0 ? entries : 1, kChunkElems) + 4) * (int64_t)sizeof(uint32_t); }
+
+int tg_learn_count(const uint8_t* d_mask, int64_t entries, int64_t expected_rows, void* d_work, int64_t work_bytes, int64_t* d_total,
+                   void* stream) {
+    TG_REQUIRE(d_mask && d_work && d_total, "tg_learn_count: null pointer");
+    TG_REQUIRE(entries > 0 && entries < ((int64_t)1 << 40), "tg_learn_count: %lld mask entries", (long long)entries);
+    TG_REQUIRE(work_bytes >= tg_learn_count_workspace(entries), "tg_learn_count: workspace of %lld B < %lld", (long long)work_bytes,
+               (long long)tg_learn_count_workspace(entries));
+    const int64_t n_chunks = ceil_div(entries, kChunkElems);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, d_mask, entries, (uint32_t*)d_work);
+    TG_LAUNCH_CHECK("tg_learn_count");
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, (uint32_t*)d_work, n_chunks, expected_rows, d_total);
+    TG_LAUNCH_CHECK("tg_learn_count(scan)");
+    return TG_OK;
+}
+
+int tg_learn_compact(const tg_compact_args* p, void* stream) {
+    TG_REQUIRE(p && p->d_mask && p->d_offsets && p->d_obs && p->d_xin && p->d_idx, "tg_learn_compact: null pointer");
+    TG_REQUIRE(p->n > 0 && p->T > 0 && p->S > 0 && p->S <= 64, "tg_learn_compact: bad sizes (n %lld, T %d, S %d)", (long long)p->n, p->T, p->S);
+    TG_REQUIRE(p->obs_dtype == TG_F32 || p->obs_dtype == TG_F64, "tg_learn_compact: obs dtype %d", p->obs_dtype);
+    TG_REQUIRE(p->in_pad >= p->S && p->in_pad <= 64 && p->in_pad % (p->xin_bf16 ? 8 : 4) == 0,
+               "tg_learn_compact: in_pad %d (a multiple of %d, >= S)", p->in_pad, p->xin_bf16 ? 8 : 4);
+    TG_REQUIRE(p->ones_col < p->in_pad && (p->ones_col < 0 || p->ones_col >= p->S), "tg_learn_compact: ones column %d inside the observation", p->ones_col);
+    TG_REQUIRE(!p->d_act_rows || (p->d_act && p->A > 0 && p->A <= 16), "tg_learn_compact: actions: null pointer or A = %d", p->A);
+    TG_REQUIRE((!p->d_dst0 || p->d_src0) && (!p->d_dst1 || p->d_src1), "tg_learn_compact: a per-row output without its source");
+    TG_REQUIRE(!p->d_moments || (p->d_dst0 && p->group_size > 0 && p->n % p->group_size == 0 && (p->norm_mode == 0 || p->norm_mode == 1)),
+               "tg_learn_compact: normalisation needs dst0, a group size dividing n and mode 0 / 1");
+    TG_REQUIRE(p->rows_cap >= 0, "tg_learn_compact: negative row capacity");
+    CompactArgs a{};
+    a.mask = p->d_mask; a.offsets = (const uint32_t*)p->d_offsets; a.M = (int64_t)p->T * p->n; a.n = p->n; a.rows_cap = p->rows_cap;
+    a.obs = p->d_obs; a.obs_feat_stride = p->obs_feat_stride; a.S = p->S; a.obs_f64 = p->obs_dtype == TG_F64;
+    a.act = p->d_act; a.act_comp_stride = (int64_t)p->T * p->n; a.A = p->A;
+    a.xin = p->d_xin; a.in_pad = p->in_pad; a.xin_bf16 = p->xin_bf16; a.ones_col = p->ones_col;
+    a.act_rows = p->d_act_rows; a.idx = p->d_idx;
+    a.src0 = p->d_src0; a.dst0 = p->d_dst0; a.src1 = p->d_src1; a.dst1 = p->d_dst1;
+    a.moments = p->d_moments; a.norm_mode = p->norm_mode; a.group_size = p->group_size;
+    if (p->rows_cap == 0) return TG_OK;
+    const int64_t n_chunks = ceil_div(a.M, kChunkElems);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.obs_f64) hipLaunchKernelGGL(compact_rows_kernel<double>, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(compact_rows_kernel<float>, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
+    TG_LAUNCH_CHECK("tg_learn_compact");
+    return TG_OK;
+}
+
+}  // extern "C"

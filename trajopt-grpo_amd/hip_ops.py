@@ -61,6 +61,59 @@ def group_normalize(x, mask, moments, mode: int, group_size: int) -> torch.Tenso
     return out
 
 
+def returns_moments(rew: torch.Tensor, mask: torch.Tensor, gamma: float, group_size: int):
+    """(rtg, moments) = (rtg_scan(rew, mask, gamma), masked_moments(rtg, mask, group_size)), bit-identical, in two launches built for
+    rollouts of a few thousand envs (tg_returns_moments: LDS-staged strips, one lane per env on the recurrence)."""
+    N.require_cuda(rew, mask)
+    assert rew.dtype == torch.float32 and mask.dtype == torch.uint8 and rew.is_contiguous() and mask.is_contiguous()
+    T, n = rew.shape
+    rtg = torch.empty_like(rew)
+    moments = torch.empty(n // group_size, 3, dtype=torch.float64, device=rew.device)
+    work = torch.empty(3 * n, dtype=torch.float64, device=rew.device)
+    N.check(N.load().tg_returns_moments(rew.data_ptr(), mask.data_ptr(), float(gamma), rtg.data_ptr(), n, T, int(group_size),
+                                        moments.data_ptr(), work.data_ptr(), _st(rew)), "tg_returns_moments")
+    return rtg, moments
+
+
+def learn_count(mask: torch.Tensor, expected_rows: int, work: torch.Tensor, total: torch.Tensor) -> None:
+    """tg_learn_count: per-chunk counts of the flat mask and their exclusive prefix into `work` (int32 buffer of
+    learn_count_workspace(mask.numel()) bytes); total int64 [2] = (valid entries, 1 if != expected_rows >= 0)."""
+    N.require_cuda(mask, work, total)
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and total.dtype == torch.int64 and total.numel() >= 2
+    N.check(N.load().tg_learn_count(mask.data_ptr(), mask.numel(), int(expected_rows), work.data_ptr(), work.numel() * work.element_size(),
+                                    total.data_ptr(), _st(mask)), "tg_learn_count")
+
+
+def learn_count_workspace(entries: int) -> int:
+    return int(N.load().tg_learn_count_workspace(int(entries)))
+
+
+def learn_compact(traj, offsets, rows_cap: int, xin: torch.Tensor, ones_col: int, act_rows, idx, src0=None, dst0=None, src1=None, dst1=None,
+                  moments=None, norm_mode: int = 0, group_size: int = 0) -> None:
+    """tg_learn_compact on a DeviceTrajectory: the valid rows' flat indices, padded input rows, action rows and up to two per-row
+    scalars (src0 optionally normalised with `moments`), in time-major order, in one launch."""
+    N.require_cuda(traj.mask, traj.obs, traj.act, xin, act_rows, idx, src0, dst0, src1, dst1, moments)
+    assert xin.dim() == 2 and xin.is_contiguous() and xin.dtype in (torch.bfloat16, torch.float32) and xin.shape[0] >= rows_cap
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() >= rows_cap
+    assert traj.obs.is_contiguous() and traj.act.is_contiguous() and traj.mask.is_contiguous()
+    a = N.CompactArgs()
+    a.d_mask, a.d_offsets, a.n, a.T, a.S, a.A = traj.mask.data_ptr(), offsets.data_ptr(), traj.n, traj.T, traj.S, traj.A
+    a.obs_dtype, a.d_obs, a.obs_feat_stride, a.d_act = N.dtype_code(traj.obs.dtype), traj.obs.data_ptr(), (traj.T + 1) * traj.n, traj.act.data_ptr()
+    a.d_xin, a.in_pad, a.xin_bf16, a.ones_col, a.norm_mode = xin.data_ptr(), xin.shape[1], int(xin.dtype == torch.bfloat16), int(ones_col), int(norm_mode)
+    if act_rows is not None:
+        assert act_rows.dtype == torch.float32 and act_rows.is_contiguous() and act_rows.shape[0] >= rows_cap and act_rows.shape[1] == traj.A
+    a.d_act_rows, a.d_idx = N.ptr(act_rows), idx.data_ptr()
+    for s_, d_ in ((src0, dst0), (src1, dst1)):
+        assert (s_ is None) == (d_ is None)
+        if s_ is not None:
+            assert s_.dtype == d_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous() and s_.numel() == traj.T * traj.n and d_.numel() >= rows_cap
+    a.d_src0, a.d_dst0, a.d_src1, a.d_dst1 = N.ptr(src0), N.ptr(dst0), N.ptr(src1), N.ptr(dst1)
+    if moments is not None:
+        assert moments.dtype == torch.float64 and moments.is_contiguous() and moments.numel() == 3 * (traj.n // group_size)
+    a.d_moments, a.group_size, a.rows_cap = N.ptr(moments), int(group_size), int(rows_cap)
+    N.check(N.load().tg_learn_compact(C.byref(a), _st(xin)), "tg_learn_compact")
+
+
 def _var_array(var):
     v = [float(x) for x in var]
     return (C.c_float * len(v))(*v), len(v)

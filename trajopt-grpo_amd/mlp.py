@@ -50,6 +50,14 @@ def _mark_ones_column(xp: torch.Tensor) -> None:
     xp.untyped_storage()._tg_ones = (lo, lo + xp.numel() * xp.element_size(), xp.shape[1] * xp.element_size())
 
 
+def set_ones_column(xp: torch.Tensor, has: bool) -> None:
+    """`xp` was just written by a prepare kernel other than prepare_input() (tg_learn_compact): record whether it carries the ones column."""
+    if has:
+        _mark_ones_column(xp)
+    elif getattr(xp.untyped_storage(), "_tg_ones", None) is not None:
+        del xp.untyped_storage()._tg_ones
+
+
 def has_ones_column(xin: torch.Tensor) -> bool:
     """`xin` is a contiguous run of whole rows of an input some prepare_input() gave the ones column."""
     if xin.dim() != 2 or not xin.is_contiguous():
