@@ -141,6 +141,12 @@ int  tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const
  * counters[1] = episodes ended.  rollout/rollout_worker.py:67-68 */
 int  tg_rollout_finish(const tg_traj* tr, void* stream);
 
+/* tg_rollout_finish + tg_rng_advance (d_rng may be NULL) + the statistics Rollout_Buffer.sample() reads
+ * (buffers/rollout_buffer.py:70: the average episode return), in two launches: d_stats f64 [3] = {sum of all rewards (fixed
+ * summation order: deterministic), n, sum of episode lengths}.  d_work: tg_rollout_finish_stats_workspace() bytes. */
+int  tg_rollout_finish_stats_workspace(void);
+int  tg_rollout_finish_stats(const tg_traj* tr, uint64_t* d_rng, double* d_stats, double* d_work, void* stream);
+
 /* The whole step range [t_begin, t_end) of a rollout in ONE persistent launch: actor MLP on the matrix cores
  * (bf16 weights, fp32 accumulate), sampling, Env.step, recording and termination, with the env state held in
  * registers.  Same results contract as tg_rollout_step in sampling mode (same Philox keys); the means differ
@@ -484,6 +490,7 @@ int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, 
  * tg_returns_moments: tg_rtg_scan + tg_masked_moments of the returns in two launches instead of three, in the form for rollouts of
  *   a few thousand envs (a workgroup stages 64-step strips of 32 envs through LDS; one lane per env runs the recurrence in the
  *   reference's order): d_rtg and d_moments are BIT-identical to tg_rtg_scan / tg_masked_moments.  d_work: f64 [3*n] scratch.
+ *   T <= tg_returns_moments_max_horizon() (the strips of a workgroup's 32 envs live in LDS).
  * tg_learn_count: valid entries per 1,024-entry chunk of the flat mask u8 [entries] (time-major [T][n]) and their exclusive prefix
  *   into d_work (tg_learn_count_workspace(entries) bytes); d_total[0] = the number of valid entries, d_total[1] = 1 when
  *   expected_rows >= 0 and differs from it (the host sized its buffers from the rollout's own statistic: a mask edited since then,
@@ -504,6 +511,7 @@ typedef struct tg_compact_args {
     const double* d_moments; int64_t group_size;
     int64_t rows_cap;
 } tg_compact_args;
+int  tg_returns_moments_max_horizon(void);
 int  tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg, int64_t n, int32_t T,
                         int64_t group_size, double* d_moments, double* d_work, void* stream);
 int64_t tg_learn_count_workspace(int64_t entries);

@@ -102,6 +102,8 @@ SIGNATURES = {
     "tg_rollout_begin": (C.c_int, [_P(Traj), C.c_int, C.c_int, _VP]),
     "tg_rollout_step": (C.c_int, [_P(EnvParams), _P(Traj), _I32, _VP, _I64, _P(_F), _VP, _I64, _VP]),
     "tg_rollout_finish": (C.c_int, [_P(Traj), _VP]),
+    "tg_rollout_finish_stats_workspace": (C.c_int, []),
+    "tg_rollout_finish_stats": (C.c_int, [_P(Traj), _VP, _VP, _VP, _VP]),
     "tg_fused_rollout": (C.c_int, [_P(EnvParams), _P(Traj), _VP, _VP, _I32, _I32, _P(_F), _VP, _I64, _I32, _I32, _VP]),
     "tg_fused_rollout_f32_supported": (C.c_int, [_I32, _I32]),
     "tg_fused_rollout_f32": (C.c_int, [_P(EnvParams), _P(Traj), _VP, _VP, _I32, _I32, _P(_F), _VP, _I64, _I32, _I32, _VP]),
@@ -144,6 +146,7 @@ SIGNATURES = {
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
     "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP]),
     "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
+    "tg_returns_moments_max_horizon": (C.c_int, []),
     "tg_returns_moments": (C.c_int, [_VP, _VP, _F, _VP, _I64, _I32, _I64, _VP, _VP, _VP]),
     "tg_learn_count_workspace": (C.c_int64, [_I64]),
     "tg_learn_count": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP, _VP]),

@@ -286,8 +286,8 @@ class _GpuLearner(Algorithm):
         host, ev, expected = pend
         self._count_pending = None
         ev.synchronize()
-        total, flag = host.tolist()
-        if flag:
+        total = int(host[0])
+        if total != expected:
             raise RuntimeError(f"the trajectory's mask held {total} valid rows, the rollout's statistic said {expected}: the last learn() "
                                "ran on truncated / padded rows (was the mask edited after sample()?)")
 
@@ -303,27 +303,33 @@ class _GpuLearner(Algorithm):
         dev, cap = traj.mask.device, traj.T * traj.n
         work = self._ws.get("cnt_work", (K.learn_count_workspace(cap) + 3) // 4, 1, torch.int32, dev)
         total = torch.empty(2, dtype=torch.int64, device=dev)
+        # Everything is enqueued BEFORE the host asks for the row count: the kernels take the buffers' capacity, not the count, so
+        # they queue up behind the rollout while the host is still waiting for the rollout's statistic -- and run while it prepares
+        # the first forward launch (asked first, the count cost the GPU ~30 us of idle time per step at 4,096 envs).
+        K.learn_count(traj.mask, -1, work, total)
+        idx_c = self._ws.get("idx", cap, 1, torch.int64, dev, cap).view(-1)
+        xin_c = self._ws.get("xin", cap, m.in_pad, m.cd, dev, cap)
+        act_c = self._ws.get("act", cap, traj.A, torch.float32, dev, cap)
+        d0_c = self._ws.get("row0", cap, 1, torch.float32, dev, cap).view(-1) if src0 is not None else None
+        d1_c = self._ws.get("row1", cap, 1, torch.float32, dev, cap).view(-1) if src1 is not None else None
+        ones = 31 if (m.in_pad == 32 and m.in_dim < 32 and m._f32 is None) else -1
+        K.learn_compact(traj, work, cap, xin_c, ones, act_c, idx_c, src0, d0_c, src1, d1_c, moments, norm_mode, group_size)
         if traj.host_valid_rows is not None:
-            rows = int(traj.host_valid_rows())                   # on the host already: no round trip, the launches go out back to back
-            K.learn_count(traj.mask, rows, work, total)
+            # the rollout's own statistic (on the host without a round trip); the count of the mask itself follows asynchronously and is
+            # compared with it at the next learn() entry
+            self._check_row_count()
             if getattr(self, "_count_pinned", None) is None:
                 self._count_pinned = torch.empty(2, dtype=torch.int64).pin_memory()
-            self._check_row_count()
             self._count_pinned.copy_(total, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
+            rows = int(traj.host_valid_rows())
             self._count_pending = (self._count_pinned, ev, rows)
         else:
-            K.learn_count(traj.mask, -1, work, total)
             rows = int(total[0].item())
-        idx = self._ws.get("idx", rows, 1, torch.int64, dev, cap).view(-1)
-        xin = self._ws.get("xin", rows, m.in_pad, m.cd, dev, cap)
-        act = self._ws.get("act", rows, traj.A, torch.float32, dev, cap)
-        d0 = self._ws.get("row0", rows, 1, torch.float32, dev, cap).view(-1) if src0 is not None else None
-        d1 = self._ws.get("row1", rows, 1, torch.float32, dev, cap).view(-1) if src1 is not None else None
-        ones = 31 if (m.in_pad == 32 and m.in_dim < 32 and m._f32 is None) else -1
-        if rows > 0:
-            K.learn_compact(traj, work, rows, xin, ones, act, idx, src0, d0, src1, d1, moments, norm_mode, group_size)
+        idx, xin, act = idx_c[:rows], xin_c[:rows], act_c[:rows]
+        d0 = d0_c[:rows] if d0_c is not None else None
+        d1 = d1_c[:rows] if d1_c is not None else None
         M.set_ones_column(xin, ones >= 0)
         return idx, xin, act, d0, d1
 
@@ -332,7 +338,7 @@ class _GpuLearner(Algorithm):
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
             mean = self._forward(actor, xin[lo:hi], view=True)
-            out[lo:hi] = K.gaussian_logp(mean, act[lo:hi], var)
+            K.gaussian_logp(mean, act[lo:hi], var, out=out[lo:hi])
         return out
 
 
@@ -356,7 +362,7 @@ class GRPO(_GpuLearner):
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
-        if traj.n <= _SMALL_N_RETURNS and _NATIVE_PREPARE:                  # grpo.py:66-74; per group, grpo.py:110-115
+        if traj.n <= _SMALL_N_RETURNS and traj.T <= K.returns_moments_max_horizon() and _NATIVE_PREPARE:   # grpo.py:66-74; per group, :110-115
             rtg, moments = K.returns_moments(rew, traj.mask, self.gamma, traj.E)
         else:
             rtg = K.rtg_scan(rew, traj.mask, self.gamma)

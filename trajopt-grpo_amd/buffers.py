@@ -122,11 +122,17 @@ class Rollout_Buffer(Buffer):
             traj = mgr.rollout_device()
             self.device_traj, self._ref, self._ref_is_full = traj, None, False
             dev = traj.rew.device
-            stats = torch.empty(3, dtype=torch.float64, device=dev)
-            stats[0:1] = traj.rew.sum(dtype=torch.float64)
-            stats[1].fill_(float(traj.n))
+            if getattr(traj, "stats_fresh", False):
+                # {sum of rewards, n, this rank's valid rows} came out of the rollout's own last launch (tg_rollout_finish_stats)
+                stats = traj.stats
+                if D.rank_world(getattr(mgr, "process_group", None))[1] > 1 or D._ALWAYS:
+                    stats = stats.clone()                     # (the all-reduce must not turn the trajectory's own record global)
+            else:
+                stats = torch.empty(3, dtype=torch.float64, device=dev)
+                stats[0:1] = traj.rew.sum(dtype=torch.float64)
+                stats[1].fill_(float(traj.n))
+                stats[2:3].copy_(traj.counters[0:1])          # this rank's valid rows (tg_rollout_finish)
             D.allreduce_sum_(stats[0:2], getattr(mgr, "process_group", None), "avg_reward")
-            stats[2:3].copy_(traj.counters[0:1])              # this rank's valid rows (tg_rollout_finish)
             if getattr(self, "_pinned", None) is None:
                 self._pinned = torch.empty(3, dtype=torch.float64).pin_memory()
             self._pinned.copy_(stats, non_blocking=True)

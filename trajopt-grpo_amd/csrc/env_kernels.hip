@@ -178,6 +178,74 @@ __global__ __launch_bounds__(256) void rollout_finish_kernel(const int32_t* __re
 
 __global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
 
+// ---- the launches around a rollout, folded (a 3-ms step at 4,096 envs spent 60 us in ~15 of them) ----
+// tg_rollout_begin: every buffer of the trajectory zeroed by ONE launch (six memsets before).
+struct ZeroRegions { void* p[6]; unsigned long long units[6]; unsigned long long bytes[6]; };   // units = ceil(bytes / 16)
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroRegions z, unsigned long long total_units) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += stride) {
+        unsigned long long v = u;
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (r == k && v >= z.units[k]) { v -= z.units[k]; r = k + 1; }
+        char* base = reinterpret_cast<char*>(z.p[r]);
+        if ((v + 1) * 16 <= z.bytes[r]) {
+            *reinterpret_cast<uint4*>(base + v * 16) = uint4{0u, 0u, 0u, 0u};
+        } else {
+            for (unsigned long long b = v * 16; b < z.bytes[r]; ++b) base[b] = 0;
+        }
+    }
+}
+
+// tg_rollout_finish_stats: what followed a rollout as ~8 launches (tg_rollout_finish, tg_rng_advance, a reward sum, fills and copies
+// in Rollout_Buffer.sample()) as two: per-workgroup partial reward sums in f64, then one workgroup that adds them in a fixed order
+// (deterministic), sums the episode lengths and advances the RNG stream.  stats = {sum of rewards, n, sum of lengths} as f64.
+template <typename R>
+__global__ __launch_bounds__(256) void reward_partial_kernel(const R* __restrict__ rew, int64_t M, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) acc += (double)rew[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void finish_stats_kernel(const int32_t* __restrict__ len, int64_t n, uint64_t* __restrict__ counters,
+                                                           const double* __restrict__ partial, int32_t n_partial, uint64_t* rng,
+                                                           double* __restrict__ stats) {
+    __shared__ unsigned long long s_sum[4], s_done[4];
+    __shared__ double s_part[256];
+    s_part[threadIdx.x] = (int)threadIdx.x < n_partial ? partial[threadIdx.x] : 0.0;      // (all partials in flight at once)
+    unsigned long long sum = 0, done = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t l = len[i];
+        sum += (unsigned long long)(l > 0 ? l : 0);
+        done += (l > 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off, 64);
+        done += __shfl_down(done, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_done[w] = done; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long steps = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        counters[0] = steps;
+        counters[1] = s_done[0] + s_done[1] + s_done[2] + s_done[3];
+        double r = 0.0;
+        for (int k = 0; k < n_partial; ++k) r += s_part[k];
+        stats[0] = r;
+        stats[1] = (double)n;
+        stats[2] = (double)steps;
+        if (rng != nullptr) rng[1] += 1;
+    }
+}
+
 // Quadrotor._dynamics (12-state, explicit Euler).  quadrotor_env.py:128-169
 template <typename R>
 __global__ __launch_bounds__(256) void quadrotor12_kernel(const R* __restrict__ st, int64_t ld,
@@ -425,16 +493,23 @@ int tg_rollout_begin(const tg_traj* tr, int obs_dim, int act_dim, void* stream) 
     const size_t rs = tr->dtype == TG_F64 ? 8 : 4;
     const size_t n = (size_t)tr->n, T = (size_t)tr->horizon;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    // the whole obs buffer in ONE linear fill (a strided 2-D memset that spares slot 0 runs at ~0.5 TB/s, 10x slower);
-    // the caller writes the initial states into slot 0 AFTER this call (tg_env_reset or a copy)
-    e = hipMemsetAsync(tr->d_obs, 0, (size_t)obs_dim * (T + 1) * n * rs, st);
-    if (e == hipSuccess) e = hipMemsetAsync(tr->d_act, 0, (size_t)act_dim * T * n * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(tr->d_rew, 0, T * n * rs, st);
-    if (e == hipSuccess) e = hipMemsetAsync(tr->d_mask, 0, T * n, st);
-    if (e == hipSuccess) e = hipMemsetAsync(tr->d_len, 0, n * sizeof(int32_t), st);
-    if (e == hipSuccess) e = hipMemsetAsync(tr->d_counters, 0, 4 * sizeof(uint64_t), st);
-    if (e != hipSuccess) return set_error(TG_ERR_HIP, "tg_rollout_begin: %s", hipGetErrorString(e));
+    // the whole obs buffer linearly (a strided 2-D fill that spares slot 0 runs at ~0.5 TB/s, 10x slower): the caller writes the
+    // initial states into slot 0 AFTER this call (tg_env_reset or a copy).  All six buffers in ONE launch (six memsets were
+    // six fill kernels: ~35 us of a 3-ms step at 4,096 envs).
+    ZeroRegions z{};
+    void* ptrs[6] = {tr->d_obs, tr->d_act, tr->d_rew, tr->d_mask, tr->d_len, tr->d_counters};
+    const size_t bytes[6] = {(size_t)obs_dim * (T + 1) * n * rs, (size_t)act_dim * T * n * sizeof(float), T * n * rs, T * n,
+                             n * sizeof(int32_t), 4 * sizeof(uint64_t)};
+    unsigned long long total = 0;
+    for (int k = 0; k < 6; ++k) {
+        TG_REQUIRE(((uintptr_t)ptrs[k] & 15) == 0, "tg_rollout_begin: buffer %d is not 16-byte aligned", k);
+        z.p[k] = ptrs[k]; z.bytes[k] = bytes[k]; z.units[k] = (bytes[k] + 15) / 16;
+        total += z.units[k];
+    }
+    const unsigned long long want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < (unsigned long long)device_cus() * 16 ? want : (unsigned long long)device_cus() * 16);
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(grid), dim3(256), 0, st, z, total);
+    TG_LAUNCH_CHECK("tg_rollout_begin");
     return TG_OK;
 }
 
@@ -462,6 +537,24 @@ int tg_rollout_finish(const tg_traj* tr, void* stream) {
     TG_REQUIRE(tr && tr->d_len && tr->d_counters && tr->n > 0, "tg_rollout_finish: bad trajectory");
     hipLaunchKernelGGL(rollout_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tr->d_len, tr->n, tr->d_counters);
     TG_LAUNCH_CHECK("tg_rollout_finish");
+    return TG_OK;
+}
+
+int tg_rollout_finish_stats_workspace(void) { return 256 * (int)sizeof(double); }
+
+int tg_rollout_finish_stats(const tg_traj* tr, uint64_t* d_rng, double* d_stats, double* d_work, void* stream) {
+    TG_REQUIRE(tr && tr->d_len && tr->d_counters && tr->d_rew && tr->n > 0 && tr->horizon > 0, "tg_rollout_finish_stats: bad trajectory");
+    TG_REQUIRE(d_stats && d_work, "tg_rollout_finish_stats: null pointer");
+    TG_REQUIRE(tr->dtype == TG_F32 || tr->dtype == TG_F64, "tg_rollout_finish_stats: bad dtype %d", tr->dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)tr->horizon * tr->n;
+    const int64_t want = ceil_div(M, 256 * 8);
+    const int nb = (int)(want < 256 ? want : 256);
+    if (tr->dtype == TG_F64) hipLaunchKernelGGL(reward_partial_kernel<double>, dim3((unsigned)nb), dim3(256), 0, st, (const double*)tr->d_rew, M, d_work);
+    else hipLaunchKernelGGL(reward_partial_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)tr->d_rew, M, d_work);
+    TG_LAUNCH_CHECK("tg_rollout_finish_stats(rewards)");
+    hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(256), 0, st, tr->d_len, tr->n, tr->d_counters, (const double*)d_work, nb, d_rng, d_stats);
+    TG_LAUNCH_CHECK("tg_rollout_finish_stats");
     return TG_OK;
 }
 

@@ -7,10 +7,10 @@
 //                        stand-alone kernels (returns_kernels.hip) give every env one lane that walks its own time axis with 32 loads
 //                        in flight: right at 65,536 envs (HBM-bound), but at 4,096 envs the launch is 64 waves, each waiting for 16
 //                        rounds of dependent global-load latency (37 + 32 us for 18 MB).  Here a workgroup owns 32 envs: all four
-//                        waves stage a 64-step strip of rewards and masks into LDS with coalesced loads (the next strip in flight
-//                        behind the current one), ONE lane per env runs the recurrence out of LDS in the reference's order --
-//                        bit-identical to tg_rtg_scan -- and all waves store the strip; the moments are then accumulated per env
-//                        in ascending time order from the returns just written (bit-identical to tg_masked_moments' first stage).
+//                        waves bring the block's whole [T][32] strip of rewards and masks into LDS with coalesced loads, ONE lane
+//                        per env runs the recurrence backwards out of LDS in the reference's order -- bit-identical to tg_rtg_scan
+//                        -- and then the masked moments forwards in ascending time (bit-identical to tg_masked_moments' first
+//                        stage), and all waves store the returns.  Horizons up to 1,024 steps (160 KiB of LDS).
 //   tg_learn_count       valid rows per 1,024-entry chunk of the flat [T*n] mask and their exclusive prefix: the row number of every
 //                        valid (t, n) in time-major order (what `mask.nonzero()` enumerates), the total, and a flag when the total is
 //                        not what the host was told (the rollout's own statistic).
@@ -26,99 +26,105 @@ namespace tg {
 // returns + per-env moments, small-n form
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRmEnvs = 32;          // envs per workgroup
-constexpr int kRmStrip = 64;         // time steps per LDS strip
+constexpr int kRmChunk = 32;         // time steps a lane takes into registers at a time
 
+// LDS: R[T][32] f32 (rewards in, returns out, in place) + M[T][32] u8.  T * 160 B <= 160 KiB, i.e. T <= 1024 (the host checks).
 __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ mask, float gamma,
                                                               float* __restrict__ rtg, int64_t n, int32_t T, double* __restrict__ work) {
-    __shared__ float s_r[2][kRmStrip][kRmEnvs];
-    __shared__ float s_m[2][kRmStrip][kRmEnvs];
+    extern __shared__ float s_dyn[];
+    float* s_r = s_dyn;                                                 // [T][32]
+    uint8_t* s_m = reinterpret_cast<uint8_t*>(s_dyn + (size_t)T * kRmEnvs);   // [T][32]
     const int tid = threadIdx.x;
     const int64_t e0 = (int64_t)blockIdx.x * kRmEnvs;
-    const int le = tid & (kRmEnvs - 1), lt0 = tid / kRmEnvs;            // this thread's env column and its first row of a strip (8 rows apart)
+    const int le = tid & (kRmEnvs - 1), lt0 = tid / kRmEnvs;            // env column; first row (rows 8 apart)
     const bool env_ok = e0 + le < n;
-    const int n_strips = (T + kRmStrip - 1) / kRmStrip;
-    // strip s covers time steps [t_lo, t_lo + 64) with t_lo = T - 64 (s + 1) (clamped at 0: the first strip of the walk is the LAST
-    // time steps); rows outside [0, T) are not loaded
-    auto load = [&](int s, float (&vr)[kRmStrip / 8], float (&vm)[kRmStrip / 8]) {
-        const int t_lo = T - kRmStrip * (s + 1);
+    // ---- all waves: the block's [T][32] strips of rewards and masks into LDS (coalesced 128-B / 32-B row segments, 8 rows per
+    // pass and thread group, every load of a pass in flight together) ----
+    // (unconditional loads from clamped addresses: a load under a branch is issued, waited for and only then followed by the next
+    // one -- the first version of this kernel spent 60 of its 78 us that way; 2 x 16 loads per thread are in flight here)
+    const int64_t e_c = env_ok ? e0 + le : n - 1;
+    for (int t0 = 0; t0 < T; t0 += 128) {
+        float vr[16]; uint8_t vm[16];
 #pragma unroll
-        for (int k = 0; k < kRmStrip / 8; ++k) {
-            const int t = t_lo + lt0 + 8 * k;
-            vr[k] = 0.f; vm[k] = 0.f;
-            if (env_ok && t >= 0) {
-                const int64_t idx = (int64_t)t * n + e0 + le;
-                vr[k] = rew[idx];
-                vm[k] = (float)mask[idx];
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int t = t0 + lt0 + 8 * k;
+            const int64_t idx = (int64_t)(t < T ? t : T - 1) * n + e_c;
+            vr[k] = rew[idx];
+            vm[k] = mask[idx];
         }
-    };
-    auto park = [&](int buf, const float (&vr)[kRmStrip / 8], const float (&vm)[kRmStrip / 8]) {
 #pragma unroll
-        for (int k = 0; k < kRmStrip / 8; ++k) {
-            s_r[buf][lt0 + 8 * k][le] = vr[k];
-            s_m[buf][lt0 + 8 * k][le] = vm[k];
+        for (int k = 0; k < 16; ++k) {
+            const int t = t0 + lt0 + 8 * k;
+            if (t < T) { s_r[t * kRmEnvs + le] = env_ok ? vr[k] : 0.f; s_m[t * kRmEnvs + le] = env_ok ? vm[k] : (uint8_t)0; }
         }
-    };
-    float vr[kRmStrip / 8], vm[kRmStrip / 8];
-    load(0, vr, vm);
-    park(0, vr, vm);
+    }
     __syncthreads();
-    float carry = 0.0f;                       // (gamma * R[t+1]) * m[t+1] of this lane's env
-    for (int s = 0; s < n_strips; ++s) {
-        const int buf = s & 1, t_lo = T - kRmStrip * (s + 1);
-        if (s + 1 < n_strips) load(s + 1, vr, vm);                     // in flight under the recurrence
-        if (tid < kRmEnvs) {
-            // one lane per env, the reference's order (grpo.py:66-74): R = r m + carry; carry = (gamma R) m -- individually rounded
-#pragma unroll 8
-            for (int k = kRmStrip - 1; k >= 0; --k) {
-                if (t_lo + k < 0) break;
-                const float mf = s_m[buf][k][tid];
-                const float R = rn_add(rn_mul(s_r[buf][k][tid], mf), carry);
-                s_r[buf][k][tid] = R;
-                carry = rn_mul(rn_mul(gamma, R), mf);
-            }
-        }
-        __syncthreads();                                               // the strip's returns are in s_r[buf]
+    if (tid < kRmEnvs) {
+        // ---- one lane per env.  Backward: R = r m + carry; carry = (gamma R) m -- the reference's order (grpo.py:66-74), individually
+        // rounded.  A chunk's operands are read into registers first (independent LDS reads), so the dependent chain is three
+        // vector operations per step and nothing else ----
+        // (no load and no arithmetic under a branch: the first version guarded every step of the unrolled chunk with `k < cnt`, and
+        // hipcc then waits for each LDS read where it stands -- 105 cycles per step instead of a dozen.  Full chunks run unguarded,
+        // the < 32 steps that remain one by one.)
+        float carry = 0.0f;
+        int t_hi = T;
+        for (; t_hi >= kRmChunk; t_hi -= kRmChunk) {
+            float r[kRmChunk], m[kRmChunk];
 #pragma unroll
-        for (int k = 0; k < kRmStrip / 8; ++k) {
-            const int t = t_lo + lt0 + 8 * k;
-            if (env_ok && t >= 0) rtg[(int64_t)t * n + e0 + le] = s_r[buf][lt0 + 8 * k][le];
-        }
-        if (s + 1 < n_strips) park(buf ^ 1, vr, vm);
-        __syncthreads();                                               // next strip parked; this strip's LDS may be reused after the next one
-    }
-    // ---- per-env moments over the valid steps, ascending in time (tg_masked_moments' env stage: same order, same fp64 sums) ----
-    // all waves stage strips of the returns just written (L2 hits) and of the masks; lane e of wave 0 accumulates
-    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int s = n_strips - 1; s >= 0; --s) {                           // ascending time = descending strip number
-        const int t_lo = T - kRmStrip * (s + 1);
-        __syncthreads();
+            for (int k = 0; k < kRmChunk; ++k) {
+                r[k] = s_r[(t_hi - 1 - k) * kRmEnvs + tid];
+                m[k] = (float)s_m[(t_hi - 1 - k) * kRmEnvs + tid];
+            }
 #pragma unroll
-        for (int k = 0; k < kRmStrip / 8; ++k) {
-            const int t = t_lo + lt0 + 8 * k;
-            float v = 0.f, m = 0.f;
-            if (env_ok && t >= 0) {
-                const int64_t idx = (int64_t)t * n + e0 + le;
-                v = rtg[idx];
-                m = (float)mask[idx];
+            for (int k = 0; k < kRmChunk; ++k) {
+                const float R = rn_add(rn_mul(r[k], m[k]), carry);
+                s_r[(t_hi - 1 - k) * kRmEnvs + tid] = R;
+                carry = rn_mul(rn_mul(gamma, R), m[k]);
             }
-            s_r[0][lt0 + 8 * k][le] = v;
-            s_m[0][lt0 + 8 * k][le] = m;
         }
-        __syncthreads();
-        if (tid < kRmEnvs) {
-            for (int k = (t_lo < 0 ? -t_lo : 0); k < kRmStrip; ++k) {
-                if (s_m[0][k][tid] != 0.f) {
-                    const double d = (double)s_r[0][k][tid];
-                    cnt += 1.0; s1 += d; s2 += d * d;
-                }
+        for (int t = t_hi - 1; t >= 0; --t) {
+            const float mf = (float)s_m[t * kRmEnvs + tid];
+            const float R = rn_add(rn_mul(s_r[t * kRmEnvs + tid], mf), carry);
+            s_r[t * kRmEnvs + tid] = R;
+            carry = rn_mul(rn_mul(gamma, R), mf);
+        }
+        // ---- forward: masked moments over the valid steps in ascending time (tg_masked_moments' env stage: same order, same fp64
+        // sums).  Selects instead of a branch per step: adding +0.0 to a sum that started at +0.0 changes no bit, and the fused
+        // multiply-add is what `s2 += d * d` compiles to there ----
+        double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+        auto add = [&](float v, uint8_t mk) {
+            const double d = (double)v;
+            const double q = __builtin_fma(d, d, s2);
+            cnt += mk ? 1.0 : 0.0;
+            s1 += mk ? d : 0.0;
+            s2 = mk ? q : s2;
+        };
+        int t0 = 0;
+        for (; t0 + kRmChunk <= T; t0 += kRmChunk) {
+            float v[kRmChunk]; uint8_t m[kRmChunk];
+#pragma unroll
+            for (int k = 0; k < kRmChunk; ++k) {
+                v[k] = s_r[(t0 + k) * kRmEnvs + tid];
+                m[k] = s_m[(t0 + k) * kRmEnvs + tid];
             }
+#pragma unroll
+            for (int k = 0; k < kRmChunk; ++k) add(v[k], m[k]);
+        }
+        for (; t0 < T; ++t0) add(s_r[t0 * kRmEnvs + tid], s_m[t0 * kRmEnvs + tid]);
+        if (e0 + tid < n) {
+            work[e0 + tid] = cnt;
+            work[n + e0 + tid] = s1;
+            work[2 * n + e0 + tid] = s2;
         }
     }
-    if (tid < kRmEnvs && e0 + tid < n) {
-        work[e0 + tid] = cnt;
-        work[n + e0 + tid] = s1;
-        work[2 * n + e0 + tid] = s2;
+    __syncthreads();
+    // ---- all waves: the returns out ----
+    for (int t0 = 0; t0 < T; t0 += 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + lt0 + 8 * k;
+            if (env_ok && t < T) rtg[(int64_t)t * n + e0 + le] = s_r[t * kRmEnvs + le];
+        }
     }
 }
 
@@ -309,13 +315,20 @@ using namespace tg;
 
 extern "C" {
 
+int tg_returns_moments_max_horizon(void) { return 1024; }
+
 int tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg, int64_t n, int32_t T, int64_t group_size,
                        double* d_moments, double* d_work, void* stream) {
     TG_REQUIRE(d_rew && d_mask && d_rtg && d_moments && d_work, "tg_returns_moments: null pointer");
     TG_REQUIRE(n > 0 && T > 0 && group_size > 0 && n % group_size == 0,
                "tg_returns_moments: n=%lld must be a positive multiple of group_size=%lld", (long long)n, (long long)group_size);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(returns_moments_kernel, dim3((unsigned)ceil_div(n, kRmEnvs)), dim3(256), 0, st, d_rew, d_mask, gamma, d_rtg, n, T, d_work);
+    TG_REQUIRE(T <= tg_returns_moments_max_horizon(), "tg_returns_moments: horizon %d > %d (the block's [T][32] strips live in LDS: use tg_rtg_scan + tg_masked_moments)",
+               T, tg_returns_moments_max_horizon());
+    const size_t shmem = (size_t)T * kRmEnvs * 5;
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)returns_moments_kernel, shmem, opt_in, "tg_returns_moments")) return rc;
+    hipLaunchKernelGGL(returns_moments_kernel, dim3((unsigned)ceil_div(n, kRmEnvs)), dim3(256), shmem, st, d_rew, d_mask, gamma, d_rtg, n, T, d_work);
     TG_LAUNCH_CHECK("tg_returns_moments");
     hipLaunchKernelGGL(group_moments2_kernel, dim3((unsigned)(n / group_size)), dim3(256), 0, st, d_work, n, group_size, d_moments);
     TG_LAUNCH_CHECK("tg_returns_moments(group)");

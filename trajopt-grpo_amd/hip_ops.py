@@ -75,6 +75,10 @@ def returns_moments(rew: torch.Tensor, mask: torch.Tensor, gamma: float, group_s
     return rtg, moments
 
 
+def returns_moments_max_horizon() -> int:
+    return int(N.load().tg_returns_moments_max_horizon())
+
+
 def learn_count(mask: torch.Tensor, expected_rows: int, work: torch.Tensor, total: torch.Tensor) -> None:
     """tg_learn_count: per-chunk counts of the flat mask and their exclusive prefix into `work` (int32 buffer of
     learn_count_workspace(mask.numel()) bytes); total int64 [2] = (valid entries, 1 if != expected_rows >= 0)."""
@@ -119,15 +123,17 @@ def _var_array(var):
     return (C.c_float * len(v))(*v), len(v)
 
 
-def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var) -> torch.Tensor:
+def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var, out: torch.Tensor = None) -> torch.Tensor:
     """log N(act; mean, diag(var)) per row (actor_critic.py:159-160).  mean [M][A] f32 (row stride free),
-    act any 2-D strided [M][A] f32."""
-    N.require_cuda(mean, act)
+    act any 2-D strided [M][A] f32.  out: a contiguous f32 [M] to write into (e.g. a slice of a larger result)."""
+    N.require_cuda(mean, act, out)
     assert mean.dtype == act.dtype == torch.float32 and mean.dim() == 2 and mean.stride(1) == 1
     M, A = mean.shape
     va, k = _var_array(var)
     assert k == A
-    out = torch.empty(M, dtype=torch.float32, device=mean.device)
+    if out is None:
+        out = torch.empty(M, dtype=torch.float32, device=mean.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M
     N.check(N.load().tg_gaussian_logp(mean.data_ptr(), mean.stride(0), act.data_ptr(), act.stride(0), act.stride(1),
                                       va, A, out.data_ptr(), M, _st(mean)), "tg_gaussian_logp")
     return out

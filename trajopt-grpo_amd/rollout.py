@@ -38,6 +38,10 @@ class DeviceTrajectory:
         self.mask = torch.zeros(T, n, dtype=torch.uint8, device=device)
         self.len = torch.zeros(n, dtype=torch.int32, device=device)
         self.counters = torch.zeros(4, dtype=torch.int64, device=device)
+        # {sum of rewards, n, valid env-steps} of the last rollout (tg_rollout_finish_stats) and its scratch
+        self.stats = torch.zeros(3, dtype=torch.float64, device=device)
+        self._stats_work = torch.empty(256, dtype=torch.float64, device=device)
+        self.stats_fresh = False             # `stats` belongs to the rollout these tensors hold (a caller that edits them says so by clearing it)
         self.host_valid_rows = None          # callable -> this rollout's valid rows, already on the host (Rollout_Buffer.sample)
 
     def native(self) -> N.Traj:
@@ -192,6 +196,7 @@ class DeviceRollout:
         replace the RNG draws (teacher-forced parity runs)."""
         self.params = self.env.native_params()
         self.traj.host_valid_rows = None                 # (set again by Rollout_Buffer.sample for THIS rollout)
+        self.traj.stats_fresh = False
         # the policy's covariance is read fresh every rollout (the reference reads self.cov in every forward,
         # actor_critic.py:131-136; the learner reads policy.var in every learn())
         self._sigma = (C.c_float * self.A)(*[float(v) for v in torch.sqrt(self.policy.var)])
@@ -250,8 +255,13 @@ class DeviceRollout:
         if ev is not None:
             ev[1].record()
             self.step_events.append((None, ev[0], ev[1]))
-        N.check(lib.tg_rollout_finish(C.byref(tr), st), "tg_rollout_finish")
-        N.check(lib.tg_rng_advance(self.rng.data_ptr(), st), "tg_rng_advance")
+        self._enqueue_finish(tr, st)
+
+    def _enqueue_finish(self, tr, st):
+        """Episode counters, the statistics sample() reads, and the RNG stream's advance: two launches (tg_rollout_finish_stats)."""
+        N.check(self.lib.tg_rollout_finish_stats(C.byref(tr), self.rng.data_ptr(), self.traj.stats.data_ptr(), self.traj._stats_work.data_ptr(), st),
+                "tg_rollout_finish_stats")
+        self.traj.stats_fresh = True
 
     def _enqueue_steps(self, sample: bool):
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
@@ -276,8 +286,7 @@ class DeviceRollout:
             if ev is not None:
                 ev[1].record()
                 self.step_events.append((t, ev[0], ev[1]))
-        N.check(lib.tg_rollout_finish(C.byref(tr), st), "tg_rollout_finish")
-        N.check(lib.tg_rng_advance(self.rng.data_ptr(), st), "tg_rng_advance")
+        self._enqueue_finish(tr, st)
 
     # ---- hipGraph replay of the whole T-step loop ---------------------------------------------
     def _run_graph(self):
@@ -311,6 +320,7 @@ class DeviceRollout:
             if self._mlp is not None:
                 self._mlp.fresh_forward()
             self._graph.replay()
+            self.traj.stats_fresh = True                 # (the captured tg_rollout_finish_stats has just re-written them)
 
 
 # ---------------------------------------------------------------------------
