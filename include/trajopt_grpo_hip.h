@@ -331,6 +331,11 @@ typedef struct tg_chain_loss {
     float        var[4];
     float        epsilon, surr_coef, critic_coef, kl_coef;
     void*        d_dout8; float* d_head_slabs; double* d_work; float* d_bias_partial;
+    /* kind 0, tg_mlp_f32_forward_backward only (NULL elsewhere): the old policy IS the current one (ppo.py:142-143 always; GRPO when
+     * nothing has touched either net since `old_policy.load_state_dict(policy.state_dict())`, grpo.py:148): the row's log-probability
+     * is written here and used as its own old log-probability (ratio exactly 1, as in the reference, whose two forward passes are
+     * the same arithmetic) -- d_logp_old is not read, and the caller needs no no-grad pass of the old policy. */
+    float*       d_logp_old_out;
 } tg_chain_loss;
 int  tg_mlp_forward_chain_blocks(void);
 int  tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
@@ -485,6 +490,15 @@ int  tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t tota
                   int64_t step, int32_t zero_grads, void* stream);
 int  tg_gather_streams(const tg_gather_segment* d_segments, int32_t n_segments, int64_t total, const tg_adam_tensor* d_table,
                        void* stream);
+/* d_flag[0] |= 1 when, for any tensor of the table, an element of `p` differs bitwise from the same element of `g` (m, v unused). */
+int  tg_params_differ(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, int32_t* d_flag, void* stream);
+/* tg_adam_step + tg_gather_streams in ONE launch: the thread that updates element e of the launch's index space also writes the new
+ * value to every layout position derived from it -- d_inv_start int32 [total + 1] / d_inv_dst: the segments' codes inverted (CSR);
+ * a destination is (segment << 26 | element of that segment).  Positions whose code is negative (padding) are not touched: the
+ * layouts must have been built once by tg_gather_streams.  Same update, bit for bit. */
+int  tg_adam_step_push(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
+                       int64_t step, int32_t zero_grads, const tg_gather_segment* d_segments, int32_t n_segments,
+                       const int32_t* d_inv_start, const int32_t* d_inv_dst, void* stream);
 
 /* ---- The learner's prologue (algorithms/grpo.py:66-115, algorithms/ppo.py:126-139: returns, group statistics, `x[mask]`) ----
  * tg_returns_moments: tg_rtg_scan + tg_masked_moments of the returns in two launches instead of three, in the form for rollouts of

@@ -1311,6 +1311,117 @@ def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, ki
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["grpo", "ppo"])
+def test_first_update_can_stand_in_for_the_old_policy_pass(tg, dev, kind):
+    """When old_policy still IS the policy (grpo.py:148 copied it and nothing touched either since; PPO takes the old log-probabilities
+    from the current policy anyway, ppo.py:142-143) the fp32 chain learner's first update writes the old log-probabilities instead of
+    a no-grad pass computing them: the ratio of that update is exactly 1 -- as in the reference, whose two passes are the same
+    arithmetic.  Same result as the explicit pass up to the last bits of that ratio; a perturbed old policy is NOT folded."""
+    from trajopt_grpo_amd import algorithms as Alg
+    K = tg.hip_ops
+
+    def run(fold, perturb_old=False, iters=2):
+        Alg._FOLD_OLD_LOGP = fold
+        try:
+            torch.manual_seed(21)
+            cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
+            pol = cls(5, 1, (128, 128), cov=0.5, device=dev)
+            mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=60), pol, num_workers=8, num_episodes_per_worker=32, seed=9)
+            buf = tg.Rollout_Buffer(mgr)
+            opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+            if kind == "ppo":
+                algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=3, gamma=0.99, batch_size=None)
+            else:
+                algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=opt, updates_per_iter=3)
+            assert algo._mlp(pol.actor)._f32 is not None
+            seen = []
+            plain = Alg._GpuLearner._logp_nograd
+            algo._logp_nograd = lambda *a, **k: (seen.append(1), plain(algo, *a, **k))[1]
+            for it in range(iters):
+                buf.sample()
+                if perturb_old and kind == "grpo":
+                    with torch.no_grad():
+                        for p_ in algo.old_policy.parameters():
+                            p_.add_(1e-3)
+                algo.learn(buf)
+            torch.cuda.synchronize()
+            return [p.detach().clone() for p in pol.parameters()], algo.last_stats, len(seen)
+        finally:
+            Alg._FOLD_OLD_LOGP = True
+
+    (wf, sf, nf), (we, se, ne) = run(True), run(False)
+    assert nf == 0 and ne == 2, "the folded run must not run the no-grad pass, the explicit run one per learn()"
+    for a, b in zip(wf, we):
+        assert float((a - b).norm()) <= 2e-6 * float(b.norm()) + 1e-9
+    key = "J" if kind == "grpo" else "total_loss"
+    np.testing.assert_allclose(sf[key], se[key], rtol=1e-5, atol=1e-7)
+    if kind == "grpo":
+        (wp, _, n_p), (wq, _, n_q) = run(True, perturb_old=True), run(False, perturb_old=True)
+        assert n_p == n_q == 2, "an old policy that was written since the copy must get its own pass"
+        for a, b in zip(wp, wq):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind,cdt,hidden", [("grpo", None, (128, 128)), ("ppo", torch.bfloat16, (256, 256, 256)), ("ppo", None, (40, 40))])
+def test_weights_written_through_data_are_seen_by_the_next_rollout_and_learn(tg, dev, kind, cdt, hidden):
+    """a write through `param.data` moves no version counter, so keys alone would leave every derived layout (the
+    learner's streams, the fused fp32 rollout's register stream) stale.  Layouts are rebuilt at every learn() / rollout entry
+    whatever the keys say: a run whose weights are clamped through `.data` after every learn() must equal, bit for bit, the run
+    that clamps through torch (which does move the counters)."""
+    def run(through_data):
+        torch.manual_seed(31)
+        cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
+        S, A, env = (5, 1, lambda: tg.CartPole(max_steps=40)) if cdt is None else (20, 4, lambda: tg.QuadPole(max_steps=40))
+        pol = cls(S, A, hidden, cov=0.4, device=dev)
+        mgr = tg.RolloutManager(env, pol, num_workers=4, num_episodes_per_worker=32, seed=2, compute_dtype=cdt)
+        buf = tg.Rollout_Buffer(mgr)
+        opt = torch.optim.Adam(pol.parameters(), lr=1e-2)
+        algo = (tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, gamma=0.99, batch_size=None, autocast_dtype=cdt)
+                if kind == "ppo" else tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=opt, updates_per_iter=2, autocast_dtype=cdt))
+        trajs = []
+        for it in range(3):
+            buf.sample()
+            trajs.append(buf.device_traj.act.clone())
+            algo.learn(buf)
+            with torch.no_grad():
+                for p in pol.parameters():                 # weight surgery after every update, the way `.data` users do it
+                    if through_data:
+                        p.data.mul_(0.5)
+                    else:
+                        p.mul_(0.5)
+            if kind == "grpo":
+                algo.sync_old_policy()                     # (old_policy follows: this test is about the layouts, the next one about the fold)
+        buf.sample()
+        trajs.append(buf.device_traj.act.clone())
+        torch.cuda.synchronize()
+        return trajs, [p.detach().clone() for p in pol.parameters()]
+
+    (ta, wa), (tb, wb) = run(True), run(False)
+    for it, (x, y) in enumerate(zip(ta, tb)):
+        assert torch.equal(x, y), f"rollout {it} acted with stale weights after a write through .data"
+    for a, b in zip(wa, wb):
+        assert torch.equal(a, b)
+
+
+def test_folded_old_policy_pass_notices_weights_changed_behind_the_keys(tg, dev):
+    """GRPO lets the first update stand in for the old policy's pass while the version keys say old_policy is the policy.  A write
+    through `.data` breaks that silently: the bitwise comparison enqueued with the fold reports it when the statistics are read."""
+    torch.manual_seed(3)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=40), pol, num_workers=4, num_episodes_per_worker=32, seed=2)
+    buf = tg.Rollout_Buffer(mgr)
+    algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.5, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), updates_per_iter=2)
+    buf.sample(); algo.learn(buf)
+    assert np.isfinite(algo.last_stats["J"]).all()           # (old_policy is the policy: no complaint)
+    buf.sample(); algo.learn(buf)
+    algo.last_stats
+    with torch.no_grad():
+        pol.actor.network[0].weight.data.add_(0.25)          # behind the version counters
+    buf.sample(); algo.learn(buf)
+    with pytest.raises(RuntimeError, match="different weights"):
+        algo.last_stats
+
+
 # --------------------------------------------------------------------------------------------
 # edge shapes
 # --------------------------------------------------------------------------------------------
@@ -1875,6 +1986,23 @@ def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden):
         assert torch.equal(st.stream, stream)
         if bias is not None and not getattr(st, "transposed", False):
             assert torch.equal(st.bias, bias)
+
+    # once gathered, the optimizer step's own launch keeps every layout current (tg_adam_step_push: the inverse of the gather)
+    for it in range(2):
+        for p in pol.parameters():
+            p.grad = torch.randn_like(p) * 1e-3
+        assert fused.step(zero_grads=it == 0, refresher=ref) and fused.pushed
+    for m in mlps:
+        m.refresh()
+        have = {n for n in ("chain", "bchain", "f32") if getattr(m, "_" + n) is not None}
+        assert have and not (m._stale & have), m._stale                     # (the per-layer copies are not the gather's)
+    for st, _, _ in got:
+        pushed = (st.stream.clone(), st.bias.clone() if hasattr(st, "bias") else None)
+        st.stream.zero_()
+        st.refresh()
+        assert torch.equal(st.stream, pushed[0])
+        if pushed[1] is not None and not getattr(st, "transposed", False):
+            assert torch.equal(st.bias, pushed[1])
 
     def learn(fused_flag):
         torch.manual_seed(5)

@@ -9,3 +9,4 @@ build w16k_plain  "-DTG_PROBE_ROW_WINDOW=16384 -DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_
 build w64k_nt     "-DTG_PROBE_ROW_WINDOW=65536"                                            # ... with the product's non-temporal policies
 build nowin_plain "-DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_AUX=0"                                 # default cache policies, no window
 build dwstamps    "-DTG_F32DW_STAMPS=1"                                                    # fp32 weight-gradient kernel with s_memtime stamps
+build fusedbound  "-DTG_ABLATE_FUSED_CHAIN=1"                                            # upper bound of a fused bf16 forward + loss + backward chain kernel

@@ -76,7 +76,7 @@ class ChainLoss(C.Structure):
                 ("act_col_stride", C.c_int64), ("d_logp_old", C.c_void_p), ("d_adv", C.c_void_p), ("d_ret", C.c_void_p),
                 ("norm_mean", C.c_float), ("norm_inv", C.c_float), ("var", C.c_float * 4), ("epsilon", C.c_float), ("surr_coef", C.c_float),
                 ("critic_coef", C.c_float), ("kl_coef", C.c_float), ("d_dout8", C.c_void_p), ("d_head_slabs", C.c_void_p),
-                ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p)]
+                ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p), ("d_logp_old_out", C.c_void_p)]
 
 class CompactArgs(C.Structure):
     """tg_compact_args (include/trajopt_grpo_hip.h)."""
@@ -146,6 +146,8 @@ SIGNATURES = {
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
     "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP]),
     "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
+    "tg_params_differ": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
+    "tg_adam_step_push": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP, _I32, _VP, _VP, _VP]),
     "tg_returns_moments_max_horizon": (C.c_int, []),
     "tg_returns_moments": (C.c_int, [_VP, _VP, _F, _VP, _I64, _I32, _I64, _VP, _VP, _VP]),
     "tg_learn_count_workspace": (C.c_int64, [_I64]),
@@ -211,6 +213,10 @@ def ptr(t):
 # see those writes, so anything that caches a function of the weights keys its freshness on (versions, this counter).
 RAW_PARAM_WRITES = [0]
 ALWAYS_REBUILD = os.environ.get("TG_ALWAYS_REBUILD", "0") == "1"    # 1: derived weight layouts never count as fresh (rounds 1-2 behaviour)
+# Writes through `param.data` bypass torch's version counters, so at the ENTRY of every learn() / rollout the layouts are rebuilt
+# whatever the keys say (one gather launch when the optimizer step is the fused one); between the updates of a learn(), where every
+# write is the build's own, the keys decide.  1: trust the keys at the entries too (saves the two launches per iteration).
+TRUST_KEYS = os.environ.get("TG_TRUST_VERSION_KEYS", "0") == "1"
 
 
 def event_pair():

@@ -34,6 +34,7 @@ from .rollout import DeviceTrajectory
 _NONZERO_STATIC = os.environ.get("TG_NONZERO_STATIC", "1") == "1"  # 0: torch.nonzero (a host round trip for the shape) even when the count is known
 _FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
 _NATIVE_PREPARE = os.environ.get("TG_NATIVE_PREPARE", "1") == "1"  # 0: the prologue as torch launches (nonzero, index_selects, pads: A/B runs)
+_FOLD_OLD_LOGP = os.environ.get("TG_FOLD_OLD_LOGP", "1") == "1"    # 0: always a no-grad pass of the old policy for the old log-probabilities (A/B runs)
 _SMALL_N_RETURNS = 16384                                           # envs up to which tg_returns_moments replaces tg_rtg_scan + tg_masked_moments
 
 
@@ -120,8 +121,66 @@ class _GpuLearner(Algorithm):
                 for m in self._mlps.values():
                     if m is not None:
                         m._ws.default_cap = max(m._ws.default_cap, cap)
-            self._check_row_count()
+            self._rollout_engine = getattr(getattr(buffer, "rollout_manager", None), "engine", None) if ok else None
+            self._check_deferred()
             self._learn(buffer)
+
+    def _entry_refresh(self, *nets):
+        """The derived weight layouts of `nets` at the entry of learn(): rebuilt whatever the version keys say -- a weight written
+        through `.data` since the last learn() leaves no trace in them -- by the one gather launch when there is one (the fused
+        optimizer step's StreamRefresher), else by marking everything stale.  TG_TRUST_VERSION_KEYS=1: the keys decide, as they do
+        between the updates of a learn()."""
+        if M.N.TRUST_KEYS:
+            return self._refresh(*nets)
+        ref = self._refresher
+        if ref is not None and ref[0][:len(nets)] == tuple(id(n) for n in nets) and ref[1].run():
+            for net in nets:
+                m = self._mlp(net)
+                if m is not None:
+                    m.refresh()
+                    m._stale.update(("w", "dx"))           # (what the gather does not cover: rebuilt lazily, only if a path reads it)
+            return
+        for net in nets:
+            m = self._mlp(net)
+            if m is not None:
+                m.refresh(force=True)
+
+    def _check_deferred(self):
+        """Checks whose answers were copied to the host asynchronously during the last learn(): read here, long after they landed."""
+        self._check_row_count()
+        pend = getattr(self, "_fold_pending", None)
+        if pend is not None:
+            self._fold_pending = None
+            host, ev = pend
+            ev.synchronize()
+            if int(host[0]):
+                raise RuntimeError("policy.actor and old_policy.actor held different weights although nothing had written either through "
+                                   "torch since old_policy <- policy: they were modified through `.data` (or raw pointers).  The last "
+                                   "learn() took its old log-probabilities from the current policy; set TG_FOLD_OLD_LOGP=0, or follow "
+                                   "such a write with an in-place torch operation (p.add_(0)).")
+
+    def _verify_old_is_current(self):
+        """Enqueue the bitwise comparison of policy.actor with old_policy.actor (one launch; the flag is read at the next learn() entry
+        or when the statistics are): the fold of the old-policy pass relies on version keys, which `.data` writes do not move."""
+        a, b = list(self.policy.actor.parameters()), list(self.old_policy.actor.parameters())
+        sig = tuple(p.data_ptr() for p in a + b)
+        tab = getattr(self, "_differ_table", None)
+        if tab is None or tab[0] != sig:
+            rows, first = [], 0
+            for p, q in zip(a, b):
+                assert p.shape == q.shape and p.is_contiguous() and q.is_contiguous() and p.dtype == q.dtype == torch.float32
+                rows.append([p.data_ptr(), q.data_ptr(), 0, 0, first])
+                first += p.numel()
+            dev = a[0].device
+            self._differ_table = tab = (sig, torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first,
+                                        torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory())
+        _, table, n, total, flag, host = tab
+        flag.zero_()
+        K.N.check(K.N.load().tg_params_differ(table.data_ptr(), n, total, flag.data_ptr(), K.N.stream_ptr(flag.device)), "tg_params_differ")
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+        self._fold_pending = (host, ev)
 
     @property
     def last_stats(self) -> dict:
@@ -129,6 +188,7 @@ class _GpuLearner(Algorithm):
         end of learn(): the host goes on to enqueue the next rollout while the last updates still run."""
         if self._stats_pending is not None:
             self._stats, self._stats_pending = self._stats_pending(), None
+            self._check_deferred()
         return self._stats
 
     @last_stats.setter
@@ -171,12 +231,25 @@ class _GpuLearner(Algorithm):
                 mo.mark_built(what)                                         # (keyed on the old net's weights AFTER the copy)
         else:
             self.old_policy.load_state_dict(self.policy.state_dict())
+        self._old_synced = self._actor_keys()                               # old_policy.actor == policy.actor as long as both keys stand
+
+    def _actor_keys(self):
+        """(key of policy.actor's parameters, key of old_policy.actor's): storage, torch version counters, raw-write count."""
+        def key(net):
+            return (tuple((p.data_ptr(), p._version) for p in net.parameters()), M.N.RAW_PARAM_WRITES[0])
+        return key(self.policy.actor), key(self.old_policy.actor)
+
+    def _old_actor_is_current(self) -> bool:
+        """Nothing has written either actor since old_policy <- policy (grpo.py:148): their weights are the same bits, and so are
+        their log-probabilities -- the first update's own forward pass can stand in for the old policy's."""
+        return getattr(self, "_old_synced", None) is not None and self._old_synced == self._actor_keys()
 
     def sync_old_policy(self) -> None:
         """old_policy <- policy.  The constructors deep-copy the policy BEFORE a checkpoint is loaded into it
         (pipelines/pipeline.py:93-100 loads after construction), so a resume must re-synchronise the copy -- GRPO's
         first learn() would otherwise form its ratios against the random-init weights."""
         self.old_policy.load_state_dict(self.policy.state_dict())
+        self._old_synced = self._actor_keys()
 
     @property
     def bucket(self) -> D.GradBucket:
@@ -220,16 +293,22 @@ class _GpuLearner(Algorithm):
             if self._fused_adam:
                 owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
                 self._adam_covers_bucket = all(id(p) in owned for p in self.bucket.params)
-        stepped = bool(self._fused_adam) and self._fused_adam.step(zero_grads=not last and self._adam_covers_bucket)
-        if not stepped:
-            self.optimizer.step()
-        self._refresh(*nets)
-        if stepped:
+        refresher = None
+        if self._fused_adam:
             extra = [x for x in (getattr(self, "_rollout_stream", None),) if x is not None]
             key = tuple(id(n) for n in nets) + tuple(id(x) for x in extra)
             if self._refresher is None or self._refresher[0] != key:
                 self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets], extra))
-            self._refresher[1].run()
+                eng = getattr(self, "_rollout_engine", None)
+                if extra and eng is not None:
+                    eng.entry_refresh = self._refresher[1].run          # the rollout's own entry rebuild: this one gather
+            refresher = self._refresher[1]
+        stepped = bool(self._fused_adam) and self._fused_adam.step(zero_grads=not last and self._adam_covers_bucket, refresher=refresher)
+        if not stepped:
+            self.optimizer.step()
+        self._refresh(*nets)
+        if stepped and not self._fused_adam.pushed:
+            refresher.run()
 
     def _prep(self, net, X, cap_rows=0):
         m = self._mlp(net)
@@ -295,7 +374,12 @@ class _GpuLearner(Algorithm):
         """What `obs[mask]`, `act[mask]`, `adv[mask]` (algorithms/ppo.py:126-135, grpo.py:76-112) and GemmMLP.prepare_input() produce,
         straight from the device trajectory into the learner's workspaces: (idx int64 [rows], xin [rows][in_pad] compute dtype with the
         ones column, act [rows][A], src0's valid entries (normalised with `moments` when given), src1's valid entries).  None when
-        this net has no GemmMLP or the trajectory's dtype is not f32 / f64 (the torch path then does it)."""
+        this net has no GemmMLP or the trajectory's dtype is not f32 / f64 (the torch path then does it).
+        = _prepare_finish(_prepare_enqueue(...)): the first half only enqueues, the second half is where the host waits for the row
+        count -- whatever host work does not need the count belongs between the two."""
+        return self._prepare_finish(self._prepare_enqueue(traj, m, src0, moments, norm_mode, group_size, src1))
+
+    def _prepare_enqueue(self, traj, m, src0=None, moments=None, norm_mode=0, group_size=0, src1=None):
         if m is None or not _NATIVE_PREPARE or traj.obs.dtype not in (torch.float32, torch.float64) or m.in_pad > 64 or traj.S > m.in_pad:
             return None
         if m.in_pad % (8 if m.cd == torch.bfloat16 else 4) or m.cd not in (torch.bfloat16, torch.float32):
@@ -314,6 +398,13 @@ class _GpuLearner(Algorithm):
         d1_c = self._ws.get("row1", cap, 1, torch.float32, dev, cap).view(-1) if src1 is not None else None
         ones = 31 if (m.in_pad == 32 and m.in_dim < 32 and m._f32 is None) else -1
         K.learn_compact(traj, work, cap, xin_c, ones, act_c, idx_c, src0, d0_c, src1, d1_c, moments, norm_mode, group_size)
+        return traj, total, idx_c, xin_c, act_c, d0_c, d1_c, ones
+
+    def _prepare_finish(self, handle):
+        if handle is None:
+            return None
+        traj, total, idx_c, xin_c, act_c, d0_c, d1_c, ones = handle
+        dev = total.device
         if traj.host_valid_rows is not None:
             # the rollout's own statistic (on the host without a round trip); the count of the mask itself follows asynchronously and is
             # compared with it at the next learn() entry
@@ -354,6 +445,7 @@ class GRPO(_GpuLearner):
         self.maximize = maximize
         self._setup(policy, optimizer, chunk_rows, autocast_dtype, process_group, fused_mlp)
         self.old_policy = copy.deepcopy(self.policy)                        # grpo.py:48
+        self._old_synced = self._actor_keys()
 
     def _learn(self, buffer) -> None:
         if self.ref_model is not None:
@@ -368,33 +460,49 @@ class GRPO(_GpuLearner):
             rtg = K.rtg_scan(rew, traj.mask, self.gamma)
             moments = K.masked_moments(rtg, traj.mask, traj.E)
         actor = self.policy.actor
-        # the valid rows: index, padded input row, action and group-relative advantage (grpo.py:76-115) in one pass over the mask
-        prepared = self._prepare(traj, self._mlp(actor), src0=rtg, moments=moments, norm_mode=0, group_size=traj.E)
+        m_actor = self._mlp(actor)
+        # the valid rows: index, padded input row, action and group-relative advantage (grpo.py:76-115) in one pass over the mask --
+        # enqueued here; the host asks for the row count (and waits for the rollout's statistic) only after everything that does not
+        # depend on it has been enqueued too
+        handle = self._prepare_enqueue(traj, m_actor, src0=rtg, moments=moments, norm_mode=0, group_size=traj.E)
+        _, world = D.rank_world(self.process_group)
+        G_global = traj.G * world
+        coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
+        self._entry_refresh(actor)
+        self._refresh(self.old_policy.actor)
+        _ = self.bucket                                                     # (the gradient windows exist before can_fuse_head() asks)
+        # grpo.py:118-119.  When old_policy still IS the policy (the usual case: grpo.py:148 copied it at the end of the last learn()
+        # and nothing has touched either since), its log-probabilities are the ones the first update's forward pass computes
+        # anyway: that pass writes them (ratio exactly 1 there, as in the reference) and the no-grad pass is not run.
+        fold_old = (_FOLD_OLD_LOGP and self.updates_per_iter > 0 and m_actor is not None and m_actor.can_write_old_logp()
+                    and self._old_actor_is_current())
+        if fold_old and not M.N.TRUST_KEYS:
+            self._verify_old_is_current()
+        all_sums = torch.zeros(max(self.updates_per_iter, 1), 4, dtype=torch.float64, device=traj.mask.device)
+        if self.updates_per_iter > 0:
+            self._zero_grads()                                              # (the first update's, ahead of the wait below)
+        prepared = self._prepare_finish(handle)
         if prepared is not None:
             idx, xin, act, adv, _ = prepared
         else:
             adv_full = K.group_normalize(rtg, traj.mask, moments, 0, traj.E)
             idx, X, act = self._gather_valid(traj)
             adv = adv_full.reshape(-1).index_select(0, idx)
-        _, world = D.rank_world(self.process_group)
-        G_global = traj.G * world
-        coef = (-1.0 if self.maximize else 1.0) / G_global                  # J /= group_size, descent on J
-        self._refresh(actor, self.old_policy.actor)
-        if prepared is None:
             xin = self._prep(actor, X, traj.T * traj.n)
         X = xin                                                             # (the loops below only ask for its row count and device)
-        old_logp = self._logp_nograd(self.old_policy.actor, xin, act, var)  # grpo.py:118-119
-        all_sums = torch.zeros(max(self.updates_per_iter, 1), 4, dtype=torch.float64, device=X.device)
+        old_logp = (self._ws.get("old_logp", X.shape[0], 1, torch.float32, X.device, traj.T * traj.n).view(-1) if fold_old else
+                    self._logp_nograd(self.old_policy.actor, xin, act, var))
         for u in range(self.updates_per_iter):
-            self._zero_grads()
+            if u > 0:
+                self._zero_grads()
             sums = all_sums[u]
-            m_actor = self._mlp(actor)
             fuse = m_actor is not None and m_actor.can_fuse_head()
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
                 if fuse:        # loss head + head gradient inside the forward chain (tg_mlp_forward_chain_loss)
                     m_actor.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], var=var,
-                                         epsilon=self.epsilon, surr_coef=coef, sums_out=sums)
+                                         epsilon=self.epsilon, surr_coef=coef, sums_out=sums,
+                                         logp_old_out=old_logp[lo:hi] if (fold_old and u == 0) else None)
                     m_actor.backward_fused()
                     continue
                 else:
@@ -448,8 +556,10 @@ class PPO(_GpuLearner):
             out[lo:hi] = self._forward(self.policy.critic, xin[lo:hi]).reshape(-1)
         return out
 
-    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out, last=True):
-        """One optimizer step on the given rows (all local rows, or one minibatch)."""
+    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out, last=True, write_old=False):
+        """One optimizer step on the given rows (all local rows, or one minibatch).  write_old: this is the first step of a full-batch
+        learn() on the fp32 chain learner -- its forward pass WRITES `old_logp` (ppo.py:142-143 takes the old log-probabilities from
+        the current policy: the same numbers) instead of reading it."""
         actor, critic = self.policy.actor, self.policy.critic
         self._zero_grads()
         both = torch.zeros(2, 4, dtype=torch.float64, device=xin.device)    # [actor | critic] loss sums
@@ -461,7 +571,8 @@ class PPO(_GpuLearner):
             if fuse:            # both loss heads + head gradients inside the forward chains (tg_mlp_forward_chain_loss)
                 nh = self._norm_host
                 m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2], var=var,
-                                 epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global, sums_out=both[0])
+                                 epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global, sums_out=both[0],
+                                 logp_old_out=old_logp[lo:hi] if write_old else None)
                 m_a.backward_fused()
                 m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4], critic_coef=self.c1 / n_global, sums_out=both[1])
                 m_c.backward_fused()
@@ -488,7 +599,7 @@ class PPO(_GpuLearner):
         if m_a is not None and m_c is not None and m_a.in_pad != m_c.in_pad:
             m_a.disable_f32_chain()                       # (only one of the two fits the fp32 chain learner: both take the
             m_c.disable_f32_chain()                       #  per-layer path, so that they keep sharing ONE prepared input)
-        self._refresh(self.policy.actor, self.policy.critic)
+        self._entry_refresh(self.policy.actor, self.policy.critic)
         # the valid rows (ppo.py:126-135): index, padded input row (actor and critic share input width / compute dtype), action
         prepared = self._prepare(traj, m_a) if (m_c is not None and m_a is not None and m_c.in_pad == m_a.in_pad and m_c.cd == m_a.cd) else None
         if prepared is not None:
@@ -519,14 +630,20 @@ class PPO(_GpuLearner):
         self._norm_host = norm.tolist()          # (the fused loss head takes the four numbers as kernel arguments)
         adv = adv_full.reshape(-1).index_select(0, idx)
         ret = rtg.reshape(-1).index_select(0, idx)
-        old_logp = self._logp_nograd(self.policy.actor, xin, act, var)      # ppo.py:142-143 (current policy)
+        # ppo.py:142-143: the old log-probabilities come from the CURRENT policy -- on the fp32 chain learner the first full-batch
+        # update's own forward pass writes them (ratio exactly 1 there, as in the reference), no no-grad pass
+        _ = self.bucket                                                     # (the gradient windows exist before can_fuse_head() asks)
+        fold_old = (_FOLD_OLD_LOGP and self.batch_size is None and self.updates_per_iter > 0 and m_a is not None and m_c is not None
+                    and m_a.can_write_old_logp() and m_c.can_fuse_head())
+        old_logp = (self._ws.get("old_logp", X.shape[0], 1, torch.float32, X.device, traj.T * traj.n).view(-1) if fold_old else
+                    self._logp_nograd(self.policy.actor, xin, act, var))
         n_rows = X.shape[0]
         all_sums = []
         for u in range(self.updates_per_iter):
             final = u == self.updates_per_iter - 1
             if self.batch_size is None:
                 # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
-                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums, last=final)
+                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums, last=final, write_old=fold_old and u == 0)
             else:
                 if self.permutation_fn is not None:
                     perm = self.permutation_fn(n_rows, X.device)

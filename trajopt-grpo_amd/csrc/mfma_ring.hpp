@@ -43,6 +43,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef TG_DW_LOAD_AUX
 #define TG_DW_LOAD_AUX 2
 #endif
+// Probe builds only (tools/build_probe_libs.sh `fusedbound`): -DTG_ABLATE_FUSED_CHAIN=1 takes out of the bf16 chain kernels exactly
+// the memory traffic a single forward + loss + backward kernel would not have -- the forward chain's mask-bit and d loss / d output
+// stores, the backward chain's loads of them and its second read of the input row.  Results are meaningless; the timing is an
+// upper bound on what that fusion could gain, before its own costs.
+#ifndef TG_ABLATE_FUSED_CHAIN
+#define TG_ABLATE_FUSED_CHAIN 0
+#endif
 __device__ static inline int64_t mem_row(int64_t r) {
 #if TG_PROBE_ROW_WINDOW
     return r & (int64_t)(TG_PROBE_ROW_WINDOW - 1);

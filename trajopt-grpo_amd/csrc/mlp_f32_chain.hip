@@ -51,6 +51,7 @@ struct F32Loss {            // the loss head (as ChainLoss of mlp_fwd_chain.hip)
     int32_t kind, A;        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error)
     const float* act;       // actor: [rows][A] contiguous; critic: the returns [rows]
     const float* logp_old; const float* adv;
+    float* logp_old_out;    // non-null: the old policy is the current one -- the row's log-probability is its old log-probability, written here
     float n_m, n_i;         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
     float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
     float* dout4;           // out: d loss / d head output, f32 [rows][4] (columns >= A zero)
@@ -314,7 +315,13 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
                     quad += d * d * L.inv_var[k];
                 }
                 const float lp = -0.5f * quad + L.logp_const;
-                const float lpo = L.logp_old[rowc];
+                float lpo;
+                if (L.logp_old_out != nullptr) {
+                    lpo = lp;
+                    if (valid && h == 0) L.logp_old_out[row] = lp;
+                } else {
+                    lpo = L.logp_old[rowc];
+                }
                 const float adv = (L.adv[rowc] - L.n_m) * L.n_i;
                 const float rho = expf(lp - lpo);
                 const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
@@ -1275,7 +1282,7 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
     TG_REQUIRE(loss->kind == 0 || loss->kind == 1, "tg_mlp_f32_forward_backward: kind %d", loss->kind);
     TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_f32_forward_backward: %d outputs unsupported (1..4)", loss->act_dim);
     TG_REQUIRE(loss->d_dout8 && loss->d_work, "tg_mlp_f32_forward_backward: null output");
-    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && loss->d_logp_old && loss->d_adv),
+    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && (loss->d_logp_old || loss->d_logp_old_out) && loss->d_adv),
                "tg_mlp_f32_forward_backward: missing per-row input");
     TG_REQUIRE(loss->kind == 1 || (loss->act_col_stride == 1 && loss->act_row_stride == loss->act_dim),
                "tg_mlp_f32_forward_backward: the actions must be contiguous [rows][act_dim]");
@@ -1294,7 +1301,7 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
     F32Loss& L = a.loss;
     L.kind = loss->kind; L.A = loss->act_dim;
     L.act = loss->kind == 0 ? loss->d_act : loss->d_ret;
-    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv;
+    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv; L.logp_old_out = loss->kind == 0 ? loss->d_logp_old_out : nullptr;
     L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
     float logdet = 0.f;
     for (int k = 0; k < 4; ++k) {

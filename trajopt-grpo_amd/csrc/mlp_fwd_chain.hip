@@ -131,6 +131,10 @@ __device__ static inline uint32_t pair_mask_word(const bf16x8* x, int w, int nib
 // and the even lane stores the half-row's MT / 2 words.
 template <int MT>
 __device__ static inline void store_mask_words(uint32_t* __restrict__ g, int64_t row, int grp, const uint32_t (&w)[MT / 2]) {
+#if TG_ABLATE_FUSED_CHAIN
+    asm volatile("" ::"v"(w[0]), "v"(w[MT / 2 - 1]));          // (the words are still formed: a fused kernel needs them too)
+    return;
+#endif
     uint32_t full[MT / 2];
 #pragma unroll
     for (int i = 0; i < MT / 2; ++i) full[i] = w[i] | (uint32_t)__builtin_amdgcn_ds_swizzle((int)w[i], 0x401F);   // xor 0x10
@@ -461,7 +465,9 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         const uint4 o = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g[0], g[1]}, bf16x2)),
                                          __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g[2], g[3]}, bf16x2)), 0u, 0u};
+#if !TG_ABLATE_FUSED_CHAIN
                         if (valid) *reinterpret_cast<uint4*>(L.dout8 + rowc[c] * 8) = o;     // (a clamped duplicate must not zero the last row)
+#endif
                         lds_store16(dt + rl * 32, o);
                         lds_store16(dt + rl * 32 + 16, uint4{0u, 0u, 0u, 0u});
                     }
@@ -613,6 +619,7 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
                "tg_mlp_forward_chain_loss: missing per-row input");
     TG_REQUIRE(loss->kind == 1 || (loss->act_col_stride == 1 && loss->act_row_stride == loss->act_dim),
                "tg_mlp_forward_chain_loss: the actions must be contiguous [rows][act_dim]");
+    TG_REQUIRE(loss->d_logp_old_out == nullptr, "tg_mlp_forward_chain_loss: d_logp_old_out is tg_mlp_f32_forward_backward's (this kernel reads d_logp_old)");
     TG_REQUIRE(rows > 0, "tg_mlp_forward_chain_loss: no rows");
     ChainActs acts{};
     for (int l = 0; l < n_hidden_layers; ++l) {

@@ -17,9 +17,17 @@ namespace tg {
 struct AdamTensor { float* p; float* g; float* m; float* v; int64_t first; };   // first = index of element 0 in the launch
 constexpr int kAdamMaxTensors = 64;
 
+struct GatherSegment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; };
+constexpr int kGatherMaxSegments = 32;
+constexpr int kPushSegShift = 26;          // a push destination = segment << 26 | element of the segment
+
+// kPush: the thread that has just updated a parameter also writes it into every derived layout it appears in (inv_start / inv_dst:
+// the gather's codes inverted, CSR over the launch's element index) -- tg_gather_streams folded into the optimizer step.
+template <bool kPush>
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total,
                                                    float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size,
-                                                   int32_t zero_grads) {
+                                                   int32_t zero_grads, const GatherSegment* __restrict__ seg,
+                                                   const int32_t* __restrict__ inv_start, const int32_t* __restrict__ inv_dst) {
 #pragma clang fp contract(off)
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
@@ -45,10 +53,30 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
     p = fmaf(step_size, m / s, p);
     d.m[i] = m; d.v[i] = v; d.p[i] = p;
     if (zero_grads) d.g[i] = 0.0f;          // the next step's optimizer.zero_grad(set_to_none=False), while the line is here
+    if constexpr (kPush) {
+        for (int32_t q = inv_start[e]; q < inv_start[e + 1]; ++q) {
+            const int32_t dd = inv_dst[q];
+            const GatherSegment s_ = seg[dd >> kPushSegShift];
+            const int32_t j = dd & ((1 << kPushSegShift) - 1);
+            if (s_.is_bf16) reinterpret_cast<__bf16*>(s_.dst)[j] = (__bf16)p;        // (the conversion tg_gather_streams applies)
+            else reinterpret_cast<float*>(s_.dst)[j] = p;
+        }
+    }
 }
 
-struct GatherSegment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; };
-constexpr int kGatherMaxSegments = 32;
+// flag[0] |= 1 when any element of tensor pair (p, g) of the table differs bitwise (the learner's check that "old_policy is the
+// policy" really held when it let the first update stand in for the old policy's pass)
+__global__ __launch_bounds__(256) void params_differ_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total,
+                                                            int32_t* __restrict__ flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int k = 0;
+    for (int t = 1; t < n_tensors; ++t)
+        if (e >= table[t].first) k = t;
+    const AdamTensor d = table[k];
+    const int64_t i = e - d.first;
+    if (__float_as_uint(d.p[i]) != __float_as_uint(d.g[i])) atomicOr(flag, 1);
+}
 
 __global__ __launch_bounds__(256) void gather_streams_kernel(const GatherSegment* __restrict__ seg, int32_t n_seg, int64_t total,
                                                              const AdamTensor* __restrict__ table) {
@@ -82,10 +110,39 @@ int tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const double step_size = (lr / bc1) * -1.0, bc2_sqrt = pow(bc2, 0.5);
     static_assert(sizeof(tg_adam_tensor) == sizeof(AdamTensor), "ABI struct and kernel struct must agree");
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads);
+                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads, nullptr, nullptr, nullptr);
     TG_LAUNCH_CHECK("tg_adam_step");
+    return TG_OK;
+}
+
+int tg_adam_step_push(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
+                      int64_t step, int32_t zero_grads, const tg_gather_segment* d_segments, int32_t n_segments,
+                      const int32_t* d_inv_start, const int32_t* d_inv_dst, void* stream) {
+    TG_REQUIRE(d_table && d_segments && d_inv_start && d_inv_dst, "tg_adam_step_push: null pointer");
+    TG_REQUIRE(n_tensors >= 1 && n_tensors <= kAdamMaxTensors, "tg_adam_step_push: %d tensors outside 1..%d", n_tensors, kAdamMaxTensors);
+    TG_REQUIRE(n_segments >= 1 && n_segments <= kGatherMaxSegments, "tg_adam_step_push: %d segments outside 1..%d", n_segments, kGatherMaxSegments);
+    TG_REQUIRE(total >= 0 && step >= 1, "tg_adam_step_push: bad sizes (total %lld, step %lld)", (long long)total, (long long)step);
+    TG_REQUIRE(1.0 - beta1 < 0.5, "tg_adam_step_push: beta1 = %g: lerp's other branch (weight >= 0.5) is not implemented", beta1);
+    if (total == 0) return TG_OK;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = (lr / bc1) * -1.0, bc2_sqrt = pow(bc2, 0.5);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads, reinterpret_cast<const GatherSegment*>(d_segments),
+                       d_inv_start, d_inv_dst);
+    TG_LAUNCH_CHECK("tg_adam_step_push");
+    return TG_OK;
+}
+
+int tg_params_differ(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, int32_t* d_flag, void* stream) {
+    TG_REQUIRE(d_table && d_flag, "tg_params_differ: null pointer");
+    TG_REQUIRE(n_tensors >= 1 && n_tensors <= kAdamMaxTensors && total >= 0, "tg_params_differ: bad sizes");
+    if (total == 0) return TG_OK;
+    hipLaunchKernelGGL(params_differ_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, d_flag);
+    TG_LAUNCH_CHECK("tg_params_differ");
     return TG_OK;
 }
 

@@ -392,7 +392,7 @@ class GemmMLP:
 
     @torch.no_grad()
     def forward_loss(self, xp: torch.Tensor, kind: int, *, act=None, logp_old=None, adv=None, ret=None, norm=None, var=None,
-                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0, sums_out=None) -> torch.Tensor:
+                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0, sums_out=None, logp_old_out=None) -> torch.Tensor:
         """Training forward pass with the loss head inside it (kind 0: actor, clipped surrogate; kind 1: critic, squared error).
         Stores what backward_fused() needs, adds the head's weight / bias gradient into their windows and returns the f64 sums
         [surrogate, squared error, KL, count] of these rows -- or, given `sums_out` (f64 [4] on the device), ADDS them there and
@@ -400,7 +400,9 @@ class GemmMLP:
         so `sums_out` is complete once backward_fused() has been enqueued."""
         lib = N.load()
         if self._f32 is not None:
-            return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out)
+            return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out,
+                                          logp_old_out)
+        assert logp_old_out is None, "logp_old_out: the fp32 chain learner's loss head only (can_write_old_logp())"
         if sums_out is not None:
             sums_out += self.forward_loss(xp, kind, act=act, logp_old=logp_old, adv=adv, ret=ret, norm=norm, var=var, epsilon=epsilon,
                                           surr_coef=surr_coef, critic_coef=critic_coef, kl_coef=kl_coef)
@@ -461,15 +463,21 @@ class GemmMLP:
         self._dz_head = dz_head
         return sums
 
-    def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef) -> "N.ChainLoss":
+    def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out=None) -> "N.ChainLoss":
         a = N.ChainLoss()
         a.kind, a.act_dim = kind, self.out_dim
         if kind == 0:
-            N.require_cuda(act, logp_old, adv)
-            assert act.dtype == torch.float32 and logp_old.dtype == torch.float32 and adv.dtype == torch.float32
-            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim) and act.is_contiguous()
+            N.require_cuda(act, logp_old, adv, logp_old_out)
+            assert act.dtype == torch.float32 and adv.dtype == torch.float32
+            assert adv.is_contiguous() and act.shape == (rows, self.out_dim) and act.is_contiguous()
             a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
-            a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
+            if logp_old_out is not None:                 # the old policy is the current one: this pass WRITES the old log-probabilities
+                assert logp_old_out.dtype == torch.float32 and logp_old_out.is_contiguous() and logp_old_out.numel() == rows
+                a.d_logp_old_out = logp_old_out.data_ptr()
+            else:
+                assert logp_old.dtype == torch.float32 and logp_old.is_contiguous()
+                a.d_logp_old = logp_old.data_ptr()
+            a.d_adv = adv.data_ptr()
             va = [float(v) for v in (var.tolist() if isinstance(var, torch.Tensor) else var)]
             for i in range(self.out_dim):
                 a.var[i] = va[i]
@@ -482,7 +490,12 @@ class GemmMLP:
         a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
         return a
 
-    def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out=None):
+    def can_write_old_logp(self) -> bool:
+        """forward_loss(logp_old_out=...) is available: the fp32 chain learner's loss head."""
+        return self._f32 is not None and self.can_fuse_head()
+
+    def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out=None,
+                          logp_old_out=None):
         """forward_loss() of an fp32 net: forward + loss head + backward-data pass in ONE launch (tg_mlp_f32_forward_backward);
         every hidden layer's activation and dZ is written for backward_fused() (tg_mlp_f32_weight_grad)."""
         lib = N.load()
@@ -500,7 +513,7 @@ class GemmMLP:
         nblk = lib.tg_mlp_f32_blocks()
         if self._head_ws is None:
             self._head_ws = torch.empty(nblk * 4, dtype=torch.float64, device=dev)
-        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef)
+        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out)
         a.d_dout8, a.d_work = dout.data_ptr(), self._head_ws.data_ptr()
         ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in acts])
         zptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])

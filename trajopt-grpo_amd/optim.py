@@ -12,9 +12,14 @@ weight decay, ...) keeps torch's own `optimizer.step()` and the per-stream refre
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _native as N
+
+
+_PUSH = os.environ.get("TG_ADAM_PUSH", "1") == "1"        # 0: optimizer step and layout gather as two launches (A/B runs)
 
 
 class FusedAdam:
@@ -88,11 +93,15 @@ class FusedAdam:
         return self._tables[group]
 
     @torch.no_grad()
-    def step(self, zero_grads: bool = False) -> bool:
+    def step(self, zero_grads: bool = False, refresher: "StreamRefresher" = None) -> bool:
         """One optimizer step; False (nothing done) when the fused form does not apply -- the caller then runs optimizer.step().
         zero_grads: the launch also zeroes every .grad it has consumed (the next update's optimizer.zero_grad() -- grpo.py:143,
-        ppo.py:181 -- folded in); `grads_zeroed` then tells the caller that its own zeroing launch can be skipped."""
+        ppo.py:181 -- folded in); `grads_zeroed` then tells the caller that its own zeroing launch can be skipped.
+        refresher: the derived weight layouts of this optimizer's nets.  Once they have been built by a gather (StreamRefresher.run),
+        the step's own launch keeps them current (tg_adam_step_push: the thread that updates a weight writes it into every layout
+        position derived from it) and marks them fresh -- `self.pushed` says so; otherwise the caller runs refresher.run()."""
         self.grads_zeroed = False
+        self.pushed = False
         if not self.usable():
             return False
         self._init_state()
@@ -102,16 +111,26 @@ class FusedAdam:
                 return False
         self._build()
         lib = N.load()
-        for (tab, n, total), g in zip(self._tables, self.opt.param_groups):
+        push = refresher.push_tables() if (refresher is not None and _PUSH) else None
+        for gi, ((tab, n, total), g) in enumerate(zip(self._tables, self.opt.param_groups)):
             for p in g["params"]:
                 self.opt.state[p]["step"] += 1
             step = int(self.opt.state[g["params"][0]]["step"])
             dev = g["params"][0].device
             with torch.cuda.device(dev):
-                N.check(lib.tg_adam_step(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
-                                         1 if zero_grads else 0, N.stream_ptr(dev)), "tg_adam_step")
+                if push is not None and gi == 0:
+                    seg, n_seg, inv_start, inv_dst = push
+                    N.check(lib.tg_adam_step_push(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
+                                                  1 if zero_grads else 0, seg.data_ptr(), n_seg, inv_start.data_ptr(), inv_dst.data_ptr(),
+                                                  N.stream_ptr(dev)), "tg_adam_step_push")
+                else:
+                    N.check(lib.tg_adam_step(tab.data_ptr(), n, total, g["lr"], g["betas"][0], g["betas"][1], g["eps"], step,
+                                             1 if zero_grads else 0, N.stream_ptr(dev)), "tg_adam_step")
         N.RAW_PARAM_WRITES[0] += 1
         self.grads_zeroed = bool(zero_grads)
+        if push is not None:
+            refresher.mark_all()
+            self.pushed = True
         return True
 
 
@@ -126,6 +145,53 @@ class StreamRefresher:
         self.extra = [x for x in extra_streams if x is not None]
         self._sig = None
         self._seg = None
+        self._push = None            # (segment table, n segments, inv_start, inv_dst) once the layouts have been gathered under this signature
+        self._gathered_sig = None
+
+    def push_tables(self):
+        """The inverse of the gather's codes, for tg_adam_step_push -- or None until the layouts have been built once by run() under
+        the current signature (padding positions are only ever written by the gather), or when this launch cannot cover them."""
+        try:
+            if not self._build() or self._gathered_sig != self._layout_sig():
+                return None
+        except (KeyError, AssertionError):
+            self._seg = None
+            return None
+        if self._push is None:
+            seg, n, total, keep, dev = self._seg
+            tab, _, n_elem = self.adam.table(0)
+            firsts = tab[:, 4].cpu().tolist()
+            if any(c.numel() >= 1 << 26 for c in keep) or n > 32:
+                return None
+            elem, dst = [], []
+            first_of = torch.tensor(firsts, dtype=torch.int64, device=dev)
+            for si, code in enumerate(keep):
+                c = code.to(torch.int64)
+                ok = c >= 0
+                j = torch.arange(c.numel(), device=dev, dtype=torch.int64)[ok]
+                cc = c[ok]
+                elem.append(first_of[cc >> 24] + (cc & 0xFFFFFF))
+                dst.append((si << 26) | j)
+            elem, dst = torch.cat(elem), torch.cat(dst)
+            order = torch.argsort(elem, stable=True)
+            counts = torch.bincount(elem, minlength=n_elem)
+            inv_start = torch.zeros(n_elem + 1, dtype=torch.int64, device=dev)
+            inv_start[1:] = torch.cumsum(counts, 0)
+            self._push = (seg, n, inv_start.to(torch.int32).contiguous(), dst[order].to(torch.int32).contiguous())
+        return self._push
+
+    def _layout_sig(self):
+        """What "the layouts have been gathered" is a statement about: the master tensors and the destination buffers (not the
+        gradient or moment tensors, which the optimizer's own table signature also carries)."""
+        masters = tuple(t[0] for t in (self.adam._sig or ()))
+        return (masters, self._sig[1] if self._sig else None)
+
+    def mark_all(self):
+        """Every layout this refresher covers has just been brought up to date (by run(), or by the optimizer step's own launch)."""
+        for m, what in self._marks:
+            m.mark_built(what)
+        for x in self.extra:
+            x.mark_fresh()
 
     def _codes(self, stream_obj, group):
         """int32 code per element of `stream_obj._idx` (FragmentStream / F32ChainStream): master tensor << 24 | offset, -1 = zero."""
@@ -159,7 +225,7 @@ class StreamRefresher:
         sig = self._signature()
         if sig == self._sig:
             return self._seg is not None                  # (an unsupported layout is not re-attempted at every step)
-        self._sig, self._seg, self._marks = sig, None, []
+        self._sig, self._seg, self._marks, self._push = sig, None, [], None
         segs, keep, first = [], [], 0
         dev = None
         for m in self.mlps:
@@ -205,8 +271,6 @@ class StreamRefresher:
         tab, _, _ = self.adam.table(0)
         with torch.cuda.device(dev):
             N.check(N.load().tg_gather_streams(seg.data_ptr(), n, total, tab.data_ptr(), N.stream_ptr(dev)), "tg_gather_streams")
-        for m, what in self._marks:
-            m.mark_built(what)
-        for x in self.extra:
-            x.mark_fresh()
+        self._gathered_sig = self._layout_sig()
+        self.mark_all()
         return True

@@ -151,6 +151,9 @@ class DeviceRollout:
         # when set to a list, every tg_rollout_step launch is bracketed by HIP events on the launch
         # stream (bench.py reads them back for the dynamics kernel's roofline)
         self.step_events = None
+        # set by a learner whose fused optimizer step keeps this engine's weight stream current: callable -> True when it has just
+        # rebuilt the stream (one gather launch covering every layout of the policy); run() calls it at every entry
+        self.entry_refresh = None
 
     # ---- policy mean for time step t -------------------------------------------------
     def _refresh_weights(self):
@@ -236,8 +239,14 @@ class DeviceRollout:
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
         if self._frag is None:
             self._frag = (M.RegisterStreamF32 if self._fused_f32 else M.FragmentStream)(self.policy.actor, self._fused_H)
-        elif not getattr(self._frag, "is_fresh", lambda: False)():
-            self._frag.refresh()                                  # weights change every learn() (unless its last launch rebuilt this stream)
+        elif N.TRUST_KEYS and getattr(self._frag, "is_fresh", lambda: False)():
+            pass                                                  # (the learner's last launch rebuilt this stream, and the keys are trusted)
+        else:
+            # weights change every learn(); a write through `.data` leaves no trace in any key, so the stream is rebuilt at every
+            # entry: by the learner's one gather launch when it has registered one (entry_refresh), else by the stream's own refresh
+            hook = getattr(self, "entry_refresh", None)
+            if hook is None or not hasattr(self._frag, "segments") or not hook():
+                self._frag.refresh()
         n_hidden = len(self._linears) - 1
         ev = None
         if self.step_events is not None:
@@ -318,7 +327,7 @@ class DeviceRollout:
             # the graph reads them through the same buffers.  (The low-precision copies of a non-MLP actor ARE captured: their
             # copies are unconditional.)
             if self._mlp is not None:
-                self._mlp.fresh_forward()
+                self._mlp.fresh_forward(force=not N.TRUST_KEYS)
             self._graph.replay()
             self.traj.stats_fresh = True                 # (the captured tg_rollout_finish_stats has just re-written them)
 
