@@ -2231,10 +2231,23 @@ def test_rollout_register_stream_is_rebuilt_by_the_step_launch(tg, dev):
     frag._refresh()
     assert torch.equal(frag.stream, s) and torch.equal(frag.table, t)
     with torch.no_grad():
-        next(pol.actor.parameters()).mul_(1.0)              # a write through torch (version counter)
+        next(pol.actor.parameters()).mul_(1.5)              # a write through torch (version counter)
     assert not frag.is_fresh()
+    buf.sample()                                            # the entry rebuild: the learner's gather launch, registered with the engine
+    assert mgr.engine.entry_refresh is not None and not calls and frag.is_fresh()
+    s2, t2 = frag.stream.clone(), frag.table.clone()
+    frag._refresh()
+    assert torch.equal(frag.stream, s2) and torch.equal(frag.table, t2) and not torch.equal(s2, s)
+    with torch.no_grad():
+        next(pol.actor.parameters()).data.mul_(2.0)         # ... and a write the version counters do not see
+    assert frag.is_fresh()                                  # (the keys cannot know)
     buf.sample()
-    assert calls == [1] and frag.is_fresh()
+    s3 = frag.stream.clone()
+    frag._refresh()
+    assert torch.equal(frag.stream, s3) and not torch.equal(s3, s2), "the rollout ran on a stale weight stream after a .data write"
+    mgr.engine.entry_refresh = None                         # without a learner's gather the stream refreshes itself at every entry
+    buf.sample()
+    assert calls == [1]
 
 
 def test_c2_size_grpo_learn_matches_the_oracle(tg, dev):
