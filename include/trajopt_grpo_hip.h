@@ -406,6 +406,19 @@ typedef struct tg_dw_job {
     const void* d_aux;        /* RH: the top hidden layer's ReLU mask bits; otherwise unused */
 } tg_dw_job;
 int64_t tg_mlp_weight_grad_workspace(int32_t hidden);
+/* tg_mlp_weight_grad_ex: the same launch pair, with up to 4 more fixed-order slab reductions riding on the second launch -- the
+ * chain kernels' OWN partial gradients (tg_mlp_forward_chain_loss's head slabs and bias partials, tg_mlp_backward_chain_w0's
+ * first-layer slabs), which the learner otherwise adds with three torch launches each:
+ *   d_grad[m * grad_ld + n] += sum over s < n_slabs of d_slab[s * slab_stride + m * row_pitch + n],  m < m_out, n < n_out
+ * -- and, optionally, the forward chain's per-workgroup f64 loss sums: d_loss_sums[k] += sum over r < n_loss_rows of
+ * d_loss_work[r * 4 + k] (k < 4), rows in order.  Everything deterministic, no atomics. */
+typedef struct tg_slab_sum {
+    const float* d_slab; int64_t slab_stride; int32_t n_slabs; int32_t row_pitch;
+    float* d_grad; int64_t grad_ld; int32_t m_out, n_out;
+} tg_slab_sum;
+int  tg_mlp_weight_grad_ex(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag, const float* d_b0,
+                           const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, const tg_slab_sum* extra, int32_t n_extra,
+                           const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums, void* stream);
 int  tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag,
                         const float* d_b0, const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, void* stream);
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU idle time inside the C2 step: rocprofv3 kernel trace of bench.py --config c2, busy time vs wall span of the timed steps
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r03
+OUT=$R/gpurun_out/${ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/c2gaps

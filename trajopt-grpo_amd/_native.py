@@ -57,6 +57,12 @@ class DwJob(C.Structure):
 TG_DW_HH, TG_DW_HX, TG_DW_DH, TG_DW_HR, TG_DW_RH = 0, 1, 2, 3, 4
 
 
+class SlabSum(C.Structure):
+    """tg_slab_sum (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("d_slab", C.c_void_p), ("slab_stride", C.c_int64), ("n_slabs", C.c_int32), ("row_pitch", C.c_int32),
+                ("d_grad", C.c_void_p), ("grad_ld", C.c_int64), ("m_out", C.c_int32), ("n_out", C.c_int32)]
+
+
 class F32DwJob(C.Structure):
     """tg_f32_dw_job (include/trajopt_grpo_hip.h)."""
     _fields_ = [("d_p", C.c_void_p), ("d_q", C.c_void_p), ("d_wgrad", C.c_void_p), ("d_bgrad", C.c_void_p),
@@ -132,6 +138,7 @@ SIGNATURES = {
                                            C.POINTER(C.c_int32), _VP]),
     "tg_mlp_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_weight_grad": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "tg_mlp_weight_grad_ex": (C.c_int, [_I32, C.POINTER(DwJob), _I32, _I64, _VP, _VP, _VP, _VP, _I64, C.POINTER(SlabSum), _I32, _VP, _I32, _VP, _VP]),
     "tg_mlp_forward_chain": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _I32,
                                        _VP]),
     "tg_mlp_forward_chain_blocks": (C.c_int, []),

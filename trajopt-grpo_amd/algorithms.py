@@ -562,7 +562,8 @@ class PPO(_GpuLearner):
         the current policy: the same numbers) instead of reading it."""
         actor, critic = self.policy.actor, self.policy.critic
         self._zero_grads()
-        both = torch.zeros(2, 4, dtype=torch.float64, device=xin.device)    # [actor | critic] loss sums
+        # [actor | critic] loss sums: a row of the learn()'s pre-zeroed table when there is one (full batch: one fill per learn(), not per update)
+        both = self._sum_rows.pop() if getattr(self, "_sum_rows", None) else torch.zeros(2, 4, dtype=torch.float64, device=xin.device)
         sums = both[0]
         m_a, m_c = self._mlp(actor), self._mlp(critic)
         fuse = m_a is not None and m_c is not None and m_a.can_fuse_head() and m_c.can_fuse_head()
@@ -639,6 +640,8 @@ class PPO(_GpuLearner):
                     self._logp_nograd(self.policy.actor, xin, act, var))
         n_rows = X.shape[0]
         all_sums = []
+        self._sum_rows = (list(torch.zeros(self.updates_per_iter, 2, 4, dtype=torch.float64, device=X.device).unbind(0))
+                          if self.batch_size is None and self.updates_per_iter > 0 else None)
         for u in range(self.updates_per_iter):
             final = u == self.updates_per_iter - 1
             if self.batch_size is None:

@@ -556,14 +556,29 @@ struct DwFinishDesc {
     int64_t grad_ld;
     int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
 };
-struct DwFinishArgs { DwFinishDesc d[2 * kDwMaxJobs]; int32_t n; int32_t total; };
+constexpr int kDwMaxExtra = 4;          // the chain kernels' own partial gradients riding on this launch (tg_mlp_weight_grad_ex)
+constexpr int kDwMaxFinish = 2 * kDwMaxJobs + kDwMaxExtra;
+struct DwFinishArgs {
+    DwFinishDesc d[kDwMaxFinish]; int32_t n; int32_t total;
+    // optional rider: loss_sums[k] += sum over rows [0, n_loss_rows) of loss_work[row][k], k < 4, rows in order (the forward chain's
+    // per-workgroup f64 loss sums: this launch follows it in stream order)
+    const double* loss_work; double* loss_sums; int32_t n_loss_rows;
+};
 
 __global__ __launch_bounds__(256) void dw_finish_all_kernel(DwFinishArgs fa) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= fa.total) return;
+    if (e >= fa.total) {
+        if (e < fa.total + 4 && fa.loss_work != nullptr) {
+            const int k = e - fa.total;
+            double t = 0.0;
+            for (int r = 0; r < fa.n_loss_rows; ++r) t += fa.loss_work[(int64_t)r * 4 + k];
+            fa.loss_sums[k] += t;
+        }
+        return;
+    }
     int k = 0;
 #pragma unroll
-    for (int t = 1; t < 2 * kDwMaxJobs; ++t)
+    for (int t = 1; t < kDwMaxFinish; ++t)
         if (t < fa.n && e >= fa.d[t].first_elem) k = t;
     const DwFinishDesc d = fa.d[k];
     const int le = e - d.first_elem;
@@ -633,7 +648,20 @@ int64_t tg_mlp_weight_grad_workspace(int32_t hidden) {
 
 int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag, const float* d_b0,
                        const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, void* stream) {
+    return tg_mlp_weight_grad_ex(hidden, jobs, n_jobs, rows, d_w0frag, d_b0, d_whfrag, d_workspace, workspace_bytes, nullptr, 0, nullptr, 0,
+                                 nullptr, stream);
+}
+
+int tg_mlp_weight_grad_ex(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, int64_t rows, const void* d_w0frag, const float* d_b0,
+                          const void* d_whfrag, void* d_workspace, int64_t workspace_bytes, const tg_slab_sum* extra, int32_t n_extra,
+                          const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums, void* stream) {
     TG_REQUIRE(jobs && d_workspace, "tg_mlp_weight_grad: null pointer");
+    TG_REQUIRE(n_extra >= 0 && n_extra <= kDwMaxExtra && (n_extra == 0 || extra), "tg_mlp_weight_grad_ex: %d extra reductions outside 0..%d", n_extra, kDwMaxExtra);
+    TG_REQUIRE((d_loss_work == nullptr) == (d_loss_sums == nullptr) && n_loss_rows >= 0, "tg_mlp_weight_grad_ex: loss-sum rider needs both pointers");
+    for (int x = 0; x < n_extra; ++x)
+        TG_REQUIRE(extra[x].d_slab && extra[x].d_grad && extra[x].n_slabs >= 0 && extra[x].m_out >= 1 && extra[x].n_out >= 1 && extra[x].row_pitch >= extra[x].n_out &&
+                   extra[x].slab_stride >= (int64_t)(extra[x].m_out - 1) * extra[x].row_pitch + extra[x].n_out && extra[x].slab_stride < ((int64_t)1 << 31),
+                   "tg_mlp_weight_grad_ex: extra reduction %d is malformed", x);
     TG_REQUIRE(hidden == 128 || hidden == 256, "tg_mlp_weight_grad: hidden width %d unsupported (128, 256)", hidden);
     TG_REQUIRE(n_jobs >= 1 && n_jobs <= kDwMaxJobs, "tg_mlp_weight_grad: %d jobs outside 1..%d", n_jobs, kDwMaxJobs);
     TG_REQUIRE(rows >= 0, "tg_mlp_weight_grad: negative row count");
@@ -709,12 +737,19 @@ int tg_mlp_weight_grad(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs, in
         }
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
+    for (int x = 0; x < n_extra; ++x) {
+        DwFinishDesc& fd = fa.d[fa.n++];
+        fd = DwFinishDesc{extra[x].d_slab, extra[x].d_grad, extra[x].grad_ld, (int32_t)extra[x].slab_stride, extra[x].n_slabs, extra[x].row_pitch,
+                          extra[x].m_out, extra[x].n_out, elems};
+        elems += extra[x].m_out * extra[x].n_out;
+    }
+    fa.loss_work = d_loss_work; fa.loss_sums = d_loss_sums; fa.n_loss_rows = n_loss_rows;
     fa.total = elems;
     TG_REQUIRE(grid <= cus, "tg_mlp_weight_grad: %d workgroups for %d CUs (the workspace holds one slab per CU)", grid, cus);
     hipStream_t st = (hipStream_t)stream;
     int rc = hidden == 256 ? launch_dw<256>(args, grid, rows, (float*)d_workspace, st) : launch_dw<128>(args, grid, rows, (float*)d_workspace, st);
     if (rc != TG_OK) return rc;
-    hipLaunchKernelGGL(dw_finish_all_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(dw_finish_all_kernel, dim3((unsigned)ceil_div(elems + 4, 256)), dim3(256), 0, st, fa);
     TG_LAUNCH_CHECK("tg_mlp_weight_grad (finish)");
     return TG_OK;
 }

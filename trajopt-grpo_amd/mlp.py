@@ -81,7 +81,7 @@ _SPLIT_BATCHES = 128
 
 
 def weight_grad(hidden: int, jobs, rows: int, workspace: torch.Tensor, w0frag: torch.Tensor = None, b0: torch.Tensor = None,
-                whfrag: torch.Tensor = None):
+                whfrag: torch.Tensor = None, extra=(), loss_rider=None):
     """tg_mlp_weight_grad: every job's `wgrad += P^T Q` (and `bgrad += column sums of P`) in one persistent launch + one
     fixed-order reduction.  jobs = [(kind, P, Q, wgrad, bgrad or None[, aux])]; P / Q bf16 row-major [rows][*], wgrad a 2-D
     fp32 view with unit column stride (e.g. a window of the learner's flat gradient bucket).  Kind HR rebuilds its Q (the first
@@ -100,9 +100,19 @@ def weight_grad(hidden: int, jobs, rows: int, workspace: torch.Tensor, w0frag: t
         assert bgrad is None or (bgrad.dtype == torch.float32 and bgrad.is_contiguous() and bgrad.numel() == wgrad.shape[0])
         slot.d_p, slot.d_q, slot.d_wgrad, slot.d_bgrad = p.data_ptr(), q.data_ptr(), wgrad.data_ptr(), N.ptr(bgrad)
         slot.wgrad_ld, slot.kind, slot.m_out, slot.n_out = wgrad.stride(0), kind, wgrad.shape[0], wgrad.shape[1]
-    N.check(N.load().tg_mlp_weight_grad(hidden, arr, len(jobs), rows, N.ptr(w0frag), N.ptr(b0), N.ptr(whfrag), workspace.data_ptr(),
-                                        workspace.numel() * workspace.element_size(), N.stream_ptr(workspace.device)),
-            "tg_mlp_weight_grad")
+    # extra = [(slab tensor, element offset, slab_stride, n_slabs, row_pitch, grad, m_out, n_out)]: the chain kernels' own partial
+    # gradients, reduced by the same second launch (tg_mlp_weight_grad_ex); loss_rider = (f64 work [rows][4], n rows, f64 sums [4])
+    ex = (N.SlabSum * max(len(extra), 1))()
+    for slot, (slab, off, stride, n_slabs, pitch, grad, m_out, n_out) in zip(ex, extra):
+        N.require_cuda(slab, grad)
+        assert slab.dtype == grad.dtype == torch.float32 and slab.is_contiguous() and (grad.dim() == 1 or grad.stride(-1) == 1)
+        assert off + (n_slabs - 1) * stride + (m_out - 1) * pitch + n_out <= slab.numel() or n_slabs == 0
+        slot.d_slab, slot.slab_stride, slot.n_slabs, slot.row_pitch = slab.data_ptr() + 4 * off, stride, n_slabs, pitch
+        slot.d_grad, slot.grad_ld, slot.m_out, slot.n_out = grad.data_ptr(), (grad.stride(0) if grad.dim() == 2 else 1), m_out, n_out
+    lw, ln, ls = (loss_rider[0].data_ptr(), loss_rider[1], loss_rider[2].data_ptr()) if loss_rider else (None, 0, None)
+    N.check(N.load().tg_mlp_weight_grad_ex(hidden, arr, len(jobs), rows, N.ptr(w0frag), N.ptr(b0), N.ptr(whfrag), workspace.data_ptr(),
+                                           workspace.numel() * workspace.element_size(), ex, len(extra), lw, ln, ls,
+                                           N.stream_ptr(workspace.device)), "tg_mlp_weight_grad_ex")
 
 
 def weight_grad_workspace(hidden: int, device) -> torch.Tensor:
@@ -403,10 +413,7 @@ class GemmMLP:
             return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out,
                                           logp_old_out)
         assert logp_old_out is None, "logp_old_out: the fp32 chain learner's loss head only (can_write_old_logp())"
-        if sums_out is not None:
-            sums_out += self.forward_loss(xp, kind, act=act, logp_old=logp_old, adv=adv, ret=ret, norm=norm, var=var, epsilon=epsilon,
-                                          surr_coef=surr_coef, critic_coef=critic_coef, kl_coef=kl_coef)
-            return None
+        self._flush_riders()                 # (a forward_loss() that was never followed by backward_fused(): its head gradient is due)
         self._fresh("chain")
         L = len(self.linears)
         rows, H, dev = xp.shape[0], self._chain.H, xp.device
@@ -454,14 +461,30 @@ class GemmMLP:
             self.fwd_events.append((ev[0], ev[1], rows, per_row, f"tg::mlp_fwd_chain_kernel<{H},8,true,4,false,true>"))
         grid = min(nblk, -(-rows // 256))
         lin = self.linears[-1]
-        hw = slabs[:grid * 4 * 16 * H].view(grid * 4, 16, H)[:, :self.out_dim].sum(0)          # fixed order: deterministic
-        lin.weight.grad.add_(hw)                                  # (rows >= 4 of a slab are never written)
-        lin.bias.grad.add_(bpart[:grid * 4].view(grid, 4).sum(0)[:self.out_dim])
-        sums = work[:grid * 4].view(grid, 4).sum(0)
+        # the head's partial weight / bias gradients (rows >= 4 of a slab are never written) and -- with sums_out -- the loss sums are
+        # added by backward_fused()'s weight-gradient reduction launch, in a fixed order (three torch launches each before)
+        self._riders = ([(slabs, 0, 16 * H, grid * 4, H, lin.weight.grad, self.out_dim, H),
+                         (bpart, 0, 4, grid, 4, lin.bias.grad, 1, self.out_dim)],
+                        (work, grid, sums_out) if sums_out is not None else None)
+        if sums_out is not None:
+            assert sums_out.dtype == torch.float64 and sums_out.is_cuda and sums_out.numel() == 4 and sums_out.is_contiguous()
         self._acts = [xp] + hid
         self._bits = [None] + bits
         self._dz_head = dz_head
-        return sums
+        return None if sums_out is not None else work[:grid * 4].view(grid, 4).sum(0)
+
+    def _flush_riders(self):
+        """The partial gradients / loss sums a forward_loss() left for backward_fused()'s reduction launch, added here by torch instead
+        (same sums, torch's order): only when that backward_fused() never came."""
+        riders, loss_rider = getattr(self, "_riders", None) or ([], None)
+        self._riders = None
+        for slab, off, stride, n_slabs, pitch, grad, m_out, n_out in riders:
+            if n_slabs > 0:
+                v = torch.as_strided(slab, (n_slabs, m_out, n_out), (stride, pitch, 1), off).sum(0)
+                grad.add_(v.view_as(grad))
+        if loss_rider is not None:
+            work, n, sums = loss_rider
+            sums += work[:n * 4].view(n, 4).sum(0)
 
     def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out=None) -> "N.ChainLoss":
         a = N.ChainLoss()
@@ -690,10 +713,13 @@ class GemmMLP:
             n_stored = nh - (0 if store_top else 1) - (1 if fuse0 else 0)
             self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8) + n_stored * 2 * H + (64 if fuse0 else 0),
                                    f"tg::mlp_bwd_chain_kernel<{H},8,{'true' if fuse0 else 'false'}>"))
+        riders, loss_rider = getattr(self, "_riders", None) or ([], None)
+        self._riders = None
         if fuse0 and rows > 0:
-            part = self._w0_slabs[:n_slabs.value * H * 32].view(n_slabs.value, H, 32).sum(0)      # fixed order: deterministic
-            self.linears[0].weight.grad.add_(part[:, :self.in_dim])
-            self.linears[0].bias.grad.add_(part[:, 31])
+            # the first layer's partial gradients ([H][32] per slab; column 31 = the bias): added by the weight-gradient reduction launch
+            l0 = self.linears[0]
+            riders = riders + [(self._w0_slabs, 0, H * 32, n_slabs.value, 32, l0.weight.grad, H, self.in_dim),
+                               (self._w0_slabs, 31, H * 32, n_slabs.value, 32, l0.bias.grad, H, 1)]
         if self._dw_ws is None:
             self._dw_ws = weight_grad_workspace(H, device)
         lin = self.linears
@@ -714,7 +740,7 @@ class GemmMLP:
         if self.dw_events is not None:
             ev = N.event_pair()
             ev[0].record()
-        weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0], self._bchain.stream)
+        weight_grad(H, jobs, rows, self._dw_ws, self._chain.stream, self._chain.bias[0], self._bchain.stream, riders, loss_rider)
         if ev is not None:
             ev[1].record()
             per_row = sum({N.TG_DW_HH: 4 * H, N.TG_DW_HX: 2 * H + 64, N.TG_DW_HR: 2 * H + 64, N.TG_DW_DH: 2 * H + 16,
