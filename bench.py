@@ -220,6 +220,45 @@ def dynamics_kernel_probe(tg, dev, n, launches=64):
             "traffic_source": f"profiles/{pmc[0]} (2 x FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None}
 
 
+def forced_rollout_probe(tg, dev, n, T=256):
+    """The dynamics kernel in its one-launch form (tg_rollout_forced: every time step of a teacher-forced replay in one launch, the
+    state in registers between steps) at `n` QuadPole envs x `T` steps with nobody terminating.  Against the HBM roofline twice: with
+    SURVEY 8(d)'s algorithmic bytes (189 B / env-step: the per-step kernel's state read + write) and with the bytes this form really
+    moves (the action read, the next observation, reward and mask byte written: 101 B) -- the second is the honest fraction."""
+    import ctypes as C
+    import torch
+    N_ = tg._native
+    env = tg.QuadPole(max_steps=T)
+    env.spatial_bounds = tuple((-1e9, 1e9) for _ in env.spatial_bounds)
+    pol = tg.GaussianActor_NeuralNetwork(20, 4, (8,), cov=0.3, device=dev)
+    eng = tg.DeviceRollout(env, pol, n // 256, 256, seed=1, fused=False)
+    eng._seed_host, eng._stream_host = 1, 0
+    eng.params = env.native_params()
+    lib, st = N_.load(), N_.stream_ptr(dev)
+    best = None
+    for _ in range(4):
+        eng._enqueue_prepare(None)                       # zeroed trajectory (actions 0 = hover thrust), fresh initial states
+        tr = eng.traj.native()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        N_.check(lib.tg_rollout_forced(C.byref(eng.params), C.byref(tr), 0, T, st), "tg_rollout_forced")
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        best = ms if best is None else min(best, ms)
+    steps = int(eng.traj.len.sum().item())
+    real = 4 * 20 + 4 * 4 + 4 + 1
+    del eng
+    torch.cuda.empty_cache()
+    return {"kernel": "tg::rollout_forced_kernel<QuadPoleEnv<float>,float>", "bound": "hbm", "n_envs": n, "horizon": T, "ms_per_launch": best,
+            "env_steps": steps, "env_steps_per_s": steps / best * 1e3,
+            "achieved": ALGO_BYTES["QuadPole"] * steps / best / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": ALGO_BYTES["QuadPole"] * steps / best / 1e6 / HBM_PEAK_GBS, "bytes_per_env_step": ALGO_BYTES["QuadPole"],
+            "real_bytes_per_env_step": real, "real_GBps": real * steps / best / 1e6, "frac_of_real_traffic": real * steps / best / 1e6 / HBM_PEAK_GBS,
+            "note": "`frac` prices the launch with SURVEY 8(d)'s 189 B / env-step, which this form does not move (the state stays in registers: "
+                    "it can exceed 1); `frac_of_real_traffic` with the 101 B it does move"}
+
+
 def _pmc_bytes_per_row(family):
     """HBM traffic per row by the PMC counters of this family's 2^22-row probe (profiles/), or None."""
     try:
@@ -667,9 +706,11 @@ def main():
         # bandwidth-bound (a bare device copy of the same bytes takes 3.7-4.0 us); at 4,194,304 envs the same kernel streams.
         big = dynamics_kernel_probe(tg, dev, 4194304, launches=16)
         dyn["at_4194304_envs"] = big
+        dyn["one_launch_form"] = forced_rollout_probe(tg, dev, envs_local * agents, T)
         dyn["note"] = ("65,536 envs = 12.4 MB per launch: one wave per SIMD and a kernel boundary per step, latency-bound (a bare copy of "
-                       "the same bytes: same_bytes_device_copy_us); the same kernel at 4,194,304 envs (at_4194304_envs) is HBM-resident "
-                       "and is the figure north_star's 60 % applies to")
+                       "the same bytes: same_bytes_device_copy_us); the same kernel at 4,194,304 envs (at_4194304_envs) is HBM-resident; "
+                       "one_launch_form = the same dynamics with the time loop INSIDE the launch (tg_rollout_forced, the teacher-forced "
+                       "replay path): at 65,536 envs a plain write stream of the trajectory")
     fused_all_alive = None
     if rank == 0 and mgr.engine.fused and agents == 1 and not cartpole:
         # the fused kernel with nobody terminating (bounds opened): its matrix-core rate without idle lanes

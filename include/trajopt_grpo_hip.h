@@ -137,6 +137,11 @@ int  tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const
                      int64_t mean_row_stride, const float* sigma, const uint64_t* d_rng,
                      int64_t env_offset, void* stream);
 
+/* Teacher-forced steps [t_begin, t_end) in ONE launch: tg_rollout_step(d_mean = NULL) for every t of the range, the state kept in
+ * registers between steps (a wavefront owns 64 envs for the whole range) -- per env-step the recorded action is read and the next
+ * observation, reward and mask byte are written, nothing else.  Bit-identical to the per-step launches. */
+int  tg_rollout_forced(const tg_env_params* p, const tg_traj* tr, int32_t t_begin, int32_t t_end, void* stream);
+
 /* counters[0] = sum of episode lengths (= env-steps executed = sum of mask),
  * counters[1] = episodes ended.  rollout/rollout_worker.py:67-68 */
 int  tg_rollout_finish(const tg_traj* tr, void* stream);

@@ -1199,6 +1199,58 @@ def test_grpo_on_a_swarm_buffer_uses_group_statistics_across_bodies(tg, dev):
     assert any(not torch.equal(x, y) for x, y in zip(before, pol.parameters()))
 
 
+@pytest.mark.parametrize("env_name,kw,dtype", [("CartPole", dict(max_steps=300), torch.float32), ("QuadPole", dict(max_steps=120), torch.float32),
+                                               ("QuadPole", dict(max_steps=40), torch.float64), ("QuadPole2D", dict(max_steps=50), torch.float32),
+                                               ("Pendulum", dict(max_steps=130), torch.float64), ("QuadPoleSwarm", dict(n_agents=4, max_steps=64), torch.float32)])
+def test_forced_rollout_in_one_launch_is_bit_identical_to_the_per_step_launches(tg, dev, env_name, kw, dtype):
+    """tg_rollout_forced (every time step of a teacher-forced replay in one launch, the state in registers) against T launches of
+    tg_rollout_step on the same recorded actions: every tensor of the trajectory bit for bit -- ragged episode ends, the swarm's
+    segmented termination, Pendulum's balanced-step count carried in `len`, f32 and f64 -- also when the range is split in two."""
+    from trajopt_grpo_amd import rollout as RO
+    Nn = tg._native
+    env_cls = getattr(tg, env_name)
+    torch.manual_seed(2)
+    if env_name == "Pendulum":
+        kw = dict(kw, gravity=0.0)                               # (no gravity: a near-silent policy balances and TERMINATES)
+    env = env_cls(**kw)
+    pol = tg.GaussianActor_NeuralNetwork(env.obs_dim, env.act_dim, (32, 32), cov=1.5 if env_name != "Pendulum" else 1e-4, device=dev)
+    G, E = 5, 52                                                 # 260 envs: not a multiple of 64
+    src = tg.DeviceRollout(env, pol, G, E, dtype=dtype, seed=11, fused=False)
+    rec = src.run()
+    init = rec.obs[:, 0, :].t().cpu().numpy()
+    acts = rec.act.permute(2, 1, 0).cpu().numpy()                # (n, T, A)
+    if env_name.startswith("QuadPole") and dtype == torch.float32:
+        assert int(rec.len.min()) < env.max_steps, "the policy is meant to end some episodes early"
+
+    def replay(per_step, split=False):
+        RO._FORCED_PER_STEP = per_step
+        try:
+            eng = tg.DeviceRollout(env, pol, G, E, dtype=dtype, seed=11, fused=False)
+            if not split:
+                tr = eng.run(initial_states=init, forced_actions=acts)
+            else:                                                # two launches: [0, T/2) then [T/2, T)
+                eng.params = env.native_params()
+                eng._seed_host, eng._stream_host = 11, 0
+                with torch.cuda.device(dev):
+                    eng._enqueue_prepare(init)
+                    eng.traj.act.copy_(torch.as_tensor(acts, dtype=torch.float32).permute(2, 1, 0).to(dev))
+                    st, nat = Nn.stream_ptr(dev), eng.traj.native()
+                    half = eng.T // 2
+                    Nn.check(Nn.load().tg_rollout_forced(C.byref(eng.params), C.byref(nat), 0, half, st))
+                    Nn.check(Nn.load().tg_rollout_forced(C.byref(eng.params), C.byref(nat), half, eng.T, st))
+                tr = eng.traj
+            torch.cuda.synchronize()
+            return [t.clone() for t in (tr.obs, tr.rew, tr.mask, tr.len)]
+        finally:
+            RO._FORCED_PER_STEP = False
+
+    a, b, c2 = replay(True), replay(False), replay(False, split=True)
+    for x, y, z, name in zip(a, b, c2, ("obs", "rew", "mask", "len")):
+        assert torch.equal(x, y), f"{name}: one launch differs from the per-step launches"
+        assert torch.equal(x, z), f"{name}: a split range differs"
+    assert torch.equal(a[2], rec.mask) and torch.equal(a[3], rec.len)      # (and both replay the sampled rollout's lengths)
+
+
 # --------------------------------------------------------------------------------------------
 # the learner's prologue as native launches (csrc/learn_kernels.hip)
 # --------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in rows))
 starts = [i for i, e in enumerate(ev) if "fused_rollout_kernel" in e[1]]
 # the last full step of the timed region: from one fused rollout launch to the next
-a, b = starts[-3], starts[-2]
+a, b = starts[-4], starts[-3]
 seg = [n for _, n in ev[a:b]]
 c = collections.Counter("at::native" if "at::native" in n else ("rocclr" if "rocclr" in n else ("tg::" if "tg::" in n else "other")) for n in seg)
 print("one C3 step (rollout launch to rollout launch):", len(seg), "launches:", dict(c))

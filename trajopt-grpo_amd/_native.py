@@ -107,6 +107,7 @@ SIGNATURES = {
     "tg_quadrotor12_dynamics": (C.c_int, [_P(EnvParams), C.c_int, _VP, _I64, _VP, _I64, _VP, _I64, _I64, _VP]),
     "tg_rollout_begin": (C.c_int, [_P(Traj), C.c_int, C.c_int, _VP]),
     "tg_rollout_step": (C.c_int, [_P(EnvParams), _P(Traj), _I32, _VP, _I64, _P(_F), _VP, _I64, _VP]),
+    "tg_rollout_forced": (C.c_int, [_P(EnvParams), _P(Traj), _I32, _I32, _VP]),
     "tg_rollout_finish": (C.c_int, [_P(Traj), _VP]),
     "tg_rollout_finish_stats_workspace": (C.c_int, []),
     "tg_rollout_finish_stats": (C.c_int, [_P(Traj), _VP, _VP, _VP, _VP]),

@@ -152,6 +152,77 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(typename Env::C c, R*
     }
 }
 
+// ---------------------------------------------------------------------------
+// teacher-forced rollout, all time steps in ONE launch (tg_rollout_forced)
+// ---------------------------------------------------------------------------
+// `Env.step` over recorded actions for steps [t_begin, t_end): what `rollout_step_kernel<..., kSample = false>` does one launch per
+// time step (replays of recorded trajectories, rollout/rollout_worker.py:51-68 with the action given), with the state kept in
+// REGISTERS between steps.  One wavefront owns 64 envs for the whole range: per env-step it reads the action (A floats, prefetched
+// kAhead steps ahead from clamped addresses -- no load sits under a branch) and writes the next observation, reward and mask byte;
+// the state is never re-read.  At 65,536 envs the per-step launch moves 12 MB in ~5 us (one wave per SIMD and a kernel boundary per
+// step: latency-bound, 0.3 of the HBM roofline); this form is a plain write stream of the trajectory.  Same step function, same
+// contraction-off arithmetic, same "every lane of a live wave stores, zeros for ended envs" rule: bit-identical to the per-step path.
+constexpr int kForcedAhead = 8;
+template <typename Env, typename R>
+__global__ __launch_bounds__(64) void rollout_forced_kernel(typename Env::C c, R* __restrict__ obs, const float* __restrict__ act,
+                                                            R* __restrict__ rew, uint8_t* __restrict__ mask, int32_t* __restrict__ len,
+                                                            int64_t n, int32_t T, int32_t t_begin, int32_t t_end, int32_t agents) {
+    constexpr int S = Env::S, A = Env::A;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = i < n;
+    const int64_t ic = in_range ? i : n - 1;
+    const int64_t T1 = (int64_t)T + 1;
+    int32_t my_len = len[ic];
+    bool alive = in_range && (Env::kBalanceTerminates ? my_len <= 0 : my_len == 0);
+    R s[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const R v = obs[(k * T1 + t_begin) * n + ic];
+        s[k] = alive ? v : (R)0;
+    }
+    float ab[kForcedAhead][A];
+    auto load_actions = [&](int t, float (&dst)[A]) {
+        const int tc = t < T ? t : T - 1;
+#pragma unroll
+        for (int k = 0; k < A; ++k) dst[k] = act[((int64_t)k * T + tc) * n + ic];
+    };
+#pragma unroll
+    for (int q = 0; q < kForcedAhead; ++q) load_actions(t_begin + q, ab[q]);
+    for (int tb = t_begin; tb < t_end; tb += kForcedAhead) {
+#pragma unroll
+        for (int q = 0; q < kForcedAhead; ++q) {
+            const int t = tb + q;
+            if (t >= t_end || __ballot(alive) == 0ull) { tb = t_end; break; }      // (wave-uniform)
+            float a[A];
+#pragma unroll
+            for (int k = 0; k < A; ++k) a[k] = ab[q][k];
+            load_actions(t + kForcedAhead, ab[q]);
+            R o[S], r;
+            const StepOut out = Env::step(s, a, c, t + 1, o, r);
+            bool ended = out.truncated;
+            int balanced_steps = 0;
+            if constexpr (Env::kBalanceTerminates) {
+                balanced_steps = out.balanced ? 1 - my_len : 0;
+                ended = ended || (balanced_steps >= c.term_steps);
+            }
+            const bool done = any_in_segment(alive && ended, agents) || (t + 1 >= T);
+            const bool carry = alive && !done;
+            if (in_range) {
+                rew[(int64_t)t * n + i] = alive ? r : (R)0;
+                mask[(int64_t)t * n + i] = alive ? 1 : 0;
+#pragma unroll
+                for (int k = 0; k < S; ++k) obs[(k * T1 + t + 1) * n + i] = carry ? o[k] : (R)0;
+            }
+            if (alive && done) my_len = t + 1;
+            else if (Env::kBalanceTerminates && alive) my_len = -balanced_steps;
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[k] = carry ? o[k] : (R)0;
+            alive = carry;
+        }
+    }
+    if (in_range) len[i] = my_len;
+}
+
 // sum of episode lengths (= env-steps executed = sum of mask) and #episodes ended
 __global__ __launch_bounds__(256) void rollout_finish_kernel(const int32_t* __restrict__ len, int64_t n,
                                                              uint64_t* __restrict__ counters) {
@@ -338,6 +409,15 @@ static int rollout_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t
     }
 #undef TG_RS
     TG_LAUNCH_CHECK("tg_rollout_step");
+    return TG_OK;
+}
+
+template <template <typename> class EnvT, typename R>
+static int forced_dispatch(const tg_env_params* p, const tg_traj* tr, int32_t t_begin, int32_t t_end, hipStream_t st) {
+    auto c = EnvT<R>::C::make(*p);
+    hipLaunchKernelGGL((rollout_forced_kernel<EnvT<R>, R>), dim3((unsigned)ceil_div(tr->n, 64)), dim3(64), 0, st, c, (R*)tr->d_obs,
+                       (const float*)tr->d_act, (R*)tr->d_rew, tr->d_mask, tr->d_len, tr->n, tr->horizon, t_begin, t_end, p->agents);
+    TG_LAUNCH_CHECK("tg_rollout_forced");
     return TG_OK;
 }
 
@@ -529,6 +609,19 @@ int tg_rollout_step(const tg_env_params* p, const tg_traj* tr, int32_t t, const 
         TG_REQUIRE(mean_row_stride >= A, "tg_rollout_step: mean_row_stride %lld < act_dim %d", (long long)mean_row_stride, A);
     }
 #define CALL(E, R) rollout_dispatch<E, R>(p, tr, t, d_mean, mean_row_stride, sigma, d_rng, env_offset, (hipStream_t)stream)
+    TG_ENV_SWITCH(p->env_id, tr->dtype, CALL)
+#undef CALL
+}
+
+int tg_rollout_forced(const tg_env_params* p, const tg_traj* tr, int32_t t_begin, int32_t t_end, void* stream) {
+    TG_REQUIRE(p && tr && tr->d_obs && tr->d_act && tr->d_rew && tr->d_mask && tr->d_len, "tg_rollout_forced: null pointer");
+    TG_REQUIRE(tr->n > 0 && tr->horizon > 0 && t_begin >= 0 && t_begin <= t_end && t_end <= tr->horizon,
+               "tg_rollout_forced: steps [%d, %d) outside horizon %d", t_begin, t_end, tr->horizon);
+    TG_REQUIRE(tr->horizon == p->max_steps, "tg_rollout_forced: trajectory horizon %d != env.max_steps %d", tr->horizon, p->max_steps);
+    TG_REQUIRE(p->agents <= 1 || (p->agents <= 64 && (p->agents & (p->agents - 1)) == 0 && tr->n % p->agents == 0),
+               "tg_rollout_forced: agents=%d must be a power of two <= 64 dividing n", p->agents);
+    if (t_begin == t_end) return TG_OK;
+#define CALL(E, R) forced_dispatch<E, R>(p, tr, t_begin, t_end, (hipStream_t)stream)
     TG_ENV_SWITCH(p->env_id, tr->dtype, CALL)
 #undef CALL
 }

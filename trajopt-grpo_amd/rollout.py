@@ -26,6 +26,10 @@ from . import distributed as D
 from . import mlp as M
 
 
+import os as _os
+_FORCED_PER_STEP = _os.environ.get("TG_FORCED_PER_STEP", "0") == "1"     # 1: teacher-forced replays as T launches of tg_rollout_step (A/B, tests)
+
+
 class DeviceTrajectory:
     """The tensors of one rollout, on the device, plus views the learner consumes."""
 
@@ -277,6 +281,19 @@ class DeviceRollout:
         p = C.byref(self.params)
         if sample:
             self._refresh_weights()
+        elif not _FORCED_PER_STEP:
+            # teacher-forced replay: every time step in ONE launch, the state in registers between steps (tg_rollout_forced;
+            # bit-identical to T launches of tg_rollout_step)
+            ev = None
+            if self.step_events is not None:
+                ev = N.event_pair()
+                ev[0].record()
+            N.check(lib.tg_rollout_forced(p, C.byref(tr), 0, self.T, st), "tg_rollout_forced")
+            if ev is not None:
+                ev[1].record()
+                self.step_events.append((None, ev[0], ev[1]))
+            self._enqueue_finish(tr, st)
+            return
         env_offset = self.group_offset * self.E
         for t in range(self.T):
             ev = None
