@@ -1327,6 +1327,34 @@ def test_learn_prepare_matches_the_torch_prologue(tg, dev, env_name, S, A, hidde
         algo._check_row_count()
 
 
+def test_learn_compaction_at_c3_size(tg, dev):
+    """tg_learn_count + tg_learn_compact on a full BASELINE configs[2] rollout (65,536 QuadPole envs x 256 steps, ~6 M valid rows of
+    16.8 M entries) through properties that do not need a second copy of the gather: the row indices are strictly increasing, all
+    valid, as many as the mask holds (hence exactly `mask.nonzero()`); sampled input rows are the bf16 observation with the ones
+    column and zero padding; sampled action rows are the recorded actions; the count agrees with the rollout's statistic."""
+    T, G, Eps = 256, 256, 256
+    torch.manual_seed(3)
+    pol = tg.GaussianActorCritic_NeuralNetwork(20, 4, (256,) * 5, cov=0.3, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.QuadPole(max_steps=T), pol, num_workers=G, num_episodes_per_worker=Eps, seed=5, compute_dtype=torch.bfloat16)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    tr = buf.device_traj
+    algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=torch.optim.Adam(pol.parameters(), lr=3e-4), ref_model=None, updates_per_iter=1, gamma=0.999,
+                  batch_size=None, autocast_dtype=torch.bfloat16)
+    idx, xin, act, _, _ = algo._prepare(tr, algo._mlp(pol.actor))
+    algo._check_row_count()                                     # (the mask's own count equals the rollout's statistic)
+    rows = int(tr.mask.sum())
+    assert idx.numel() == rows == buf.valid_rows() and 0 < rows < T * G * Eps
+    assert bool((idx[1:] > idx[:-1]).all()) and int(idx[0]) >= 0 and int(idx[-1]) < T * G * Eps
+    assert bool(tr.mask.reshape(-1)[idx].all())
+    pick = torch.randint(0, rows, (200000,), device=dev)
+    want = tr.obs_rows().index_select(0, idx[pick]).to(torch.bfloat16)
+    got = xin[pick]
+    assert torch.equal(got[:, :20].view(torch.int16), want.view(torch.int16))
+    assert bool((got[:, 20:31] == 0).all()) and bool((got[:, 31] == 1).all())
+    assert torch.equal(act[pick], tr.act_rows().index_select(0, idx[pick]))
+
+
 @pytest.mark.parametrize("kind,cdt,hidden", [("grpo", None, (128, 128)), ("grpo", torch.bfloat16, (128, 128, 128)), ("ppo", torch.bfloat16, (256, 256, 256)),
                                              ("ppo", None, (64, 64)), ("ppo", None, (40, 40))])
 def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, kind, cdt, hidden):
@@ -1699,10 +1727,17 @@ def test_fused_rollouts_at_baseline_sizes(tg, dev, name, hidden, G, Eps, T, cdt)
     m = mask.bool()
     assert torch.all(rew[~m] == 0) and torch.all(act[:, ~m] == 0) and torch.all(obs[:, :T][:, ~m] == 0)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    from trajopt_grpo_amd import rollout as RO
     plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt, fused=False)
-    replay = plain.run(initial_states=obs[:, 0, :].t().cpu().numpy(), forced_actions=act.permute(2, 1, 0).cpu().numpy())
-    assert torch.equal(replay.len, ln) and torch.equal(replay.mask, mask)
-    assert torch.equal(replay.rew, rew) and torch.equal(replay.obs, obs)
+    init, forced = obs[:, 0, :].t().cpu().numpy(), act.permute(2, 1, 0).cpu().numpy()
+    for per_step in (True, False):              # T launches of the golden-pinned step kernel, then the one-launch form (tg_rollout_forced)
+        RO._FORCED_PER_STEP = per_step
+        try:
+            replay = plain.run(initial_states=init, forced_actions=forced)
+        finally:
+            RO._FORCED_PER_STEP = False
+        assert torch.equal(replay.len, ln) and torch.equal(replay.mask, mask), per_step
+        assert torch.equal(replay.rew, rew) and torch.equal(replay.obs, obs), per_step
     again = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt).run()
     assert torch.equal(again.obs, obs) and torch.equal(again.act, act) and torch.equal(again.len, ln)
 
