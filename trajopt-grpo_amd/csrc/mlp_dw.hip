@@ -548,31 +548,36 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(DwArgs args, int64_t rows, f
     TG_CLOCK_PROBE_END(g_probe_weight_grad)
 }
 
-// grad[m][n] += sum over the job's slabs, in slab order.  One thread per output element; consecutive threads read
-// consecutive floats of a slab row.
+// grad[m][n] += sum over the job's slabs, in a fixed order.  A region whose slabs are few (the jobs' own: one per workgroup of the
+// job, 40-75) takes one thread per output element -- consecutive threads read consecutive floats of a slab row; a region with many
+// slabs (the chain kernels' riders: up to 4 per workgroup of a 256-workgroup launch) takes `lanes` consecutive lanes per element,
+// lane `sub` adding slabs sub, sub + lanes, ... and a fixed shuffle tree adding the lanes: one thread walking 1,024 slabs was a
+// 150-us chain of load latencies (C4: 6 % of an update).  Regions start on a multiple of 64 units, so a wavefront never straddles two.
 struct DwFinishDesc {
     const float* slab;        // slab 0, already offset to the region ([M][N] gradient or [1][M] bias sums)
     float* grad;
     int64_t grad_ld;
-    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;
+    int32_t slab_len, n_slabs, N, m_out, n_out, first_elem, lanes;     // first_elem: in UNITS (an element = `lanes` units)
 };
 constexpr int kDwMaxExtra = 4;          // the chain kernels' own partial gradients riding on this launch (tg_mlp_weight_grad_ex)
 constexpr int kDwMaxFinish = 2 * kDwMaxJobs + kDwMaxExtra;
 struct DwFinishArgs {
     DwFinishDesc d[kDwMaxFinish]; int32_t n; int32_t total;
-    // optional rider: loss_sums[k] += sum over rows [0, n_loss_rows) of loss_work[row][k], k < 4, rows in order (the forward chain's
-    // per-workgroup f64 loss sums: this launch follows it in stream order)
+    // optional rider: loss_sums[k] += sum over rows [0, n_loss_rows) of loss_work[row][k], k < 4 (the forward chain's per-workgroup
+    // f64 loss sums: this launch follows it in stream order): the workgroup behind the last region, one wavefront per k
     const double* loss_work; double* loss_sums; int32_t n_loss_rows;
 };
 
 __global__ __launch_bounds__(256) void dw_finish_all_kernel(DwFinishArgs fa) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= fa.total) {
-        if (e < fa.total + 4 && fa.loss_work != nullptr) {
-            const int k = e - fa.total;
+    if (e >= fa.total) {                                    // (fa.total is a multiple of 256: this is a whole workgroup)
+        if (fa.loss_work != nullptr && e < fa.total + 256) {
+            const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
             double t = 0.0;
-            for (int r = 0; r < fa.n_loss_rows; ++r) t += fa.loss_work[(int64_t)r * 4 + k];
-            fa.loss_sums[k] += t;
+            for (int r = lane; r < fa.n_loss_rows; r += 64) t += fa.loss_work[(int64_t)r * 4 + k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) fa.loss_sums[k] += t;
         }
         return;
     }
@@ -580,19 +585,26 @@ __global__ __launch_bounds__(256) void dw_finish_all_kernel(DwFinishArgs fa) {
 #pragma unroll
     for (int t = 1; t < kDwMaxFinish; ++t)
         if (t < fa.n && e >= fa.d[t].first_elem) k = t;
-    const DwFinishDesc d = fa.d[k];
-    const int le = e - d.first_elem;
-    const int m = le / d.n_out, n = le - m * d.n_out;
+    const DwFinishDesc d = fa.d[k];                         // (wave-uniform: regions are 64-aligned)
+    const int unit = e - d.first_elem;
+    const int le = unit / d.lanes, sub = unit - le * d.lanes;
+    const bool live = le < d.m_out * d.n_out;
+    const int m = live ? le / d.n_out : 0, n = live ? le - m * d.n_out : 0;
     const float* src = d.slab + (int64_t)m * d.N + n;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= d.n_slabs; b += 4) {                    // 4 loads in flight; the sum order stays fixed
-        const float v0 = src[(int64_t)b * d.slab_len], v1 = src[(int64_t)(b + 1) * d.slab_len];
-        const float v2 = src[(int64_t)(b + 2) * d.slab_len], v3 = src[(int64_t)(b + 3) * d.slab_len];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    int b = sub;
+    const int step = d.lanes;
+    if (live) {
+        for (; b + 3 * step < d.n_slabs; b += 4 * step) {   // 4 loads in flight; the sum order stays fixed
+            const float v0 = src[(int64_t)b * d.slab_len], v1 = src[(int64_t)(b + step) * d.slab_len];
+            const float v2 = src[(int64_t)(b + 2 * step) * d.slab_len], v3 = src[(int64_t)(b + 3 * step) * d.slab_len];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; b < d.n_slabs; b += step) s0 += src[(int64_t)b * d.slab_len];
     }
-    for (; b < d.n_slabs; ++b) s0 += src[(int64_t)b * d.slab_len];
-    d.grad[(int64_t)m * d.grad_ld + n] += (s0 + s1) + (s2 + s3);
+    float t = (s0 + s1) + (s2 + s3);
+    for (int off = d.lanes >> 1; off > 0; off >>= 1) t += __shfl_down(t, off, 64);    // (lanes = 1: no iteration)
+    if (live && sub == 0) d.grad[(int64_t)m * d.grad_ld + n] += t;
 }
 
 static int dw_cus() { return device_cus(); }
@@ -727,29 +739,37 @@ int tg_mlp_weight_grad_ex(int32_t hidden, const tg_dw_job* jobs, int32_t n_jobs,
         grid += dj.n_blocks;
         const int N = (jb.kind == TG_DW_HX) ? 32 : H;
         DwFinishDesc& fd = fa.d[fa.n++];
-        fd = DwFinishDesc{(const float*)d_workspace + off, jb.d_wgrad, jb.wgrad_ld, dj.slab_len, dj.n_blocks, N, jb.m_out, jb.n_out, elems};
-        elems += jb.m_out * jb.n_out;
+        auto region = [&](DwFinishDesc& d) {                 // units of the region, rounded up to whole wavefronts
+            d.lanes = d.n_slabs > 96 ? 32 : 1;
+            d.first_elem = elems;
+            elems += (d.m_out * d.n_out * d.lanes + 63) / 64 * 64;
+        };
+        fd = DwFinishDesc{(const float*)d_workspace + off, jb.d_wgrad, jb.wgrad_ld, dj.slab_len, dj.n_blocks, N, jb.m_out, jb.n_out, 0, 1};
+        region(fd);
         if (jb.d_bgrad) {
             const int boff = jb.kind == TG_DW_HX ? H * 32 : H * H;
             DwFinishDesc& fb = fa.d[fa.n++];
-            fb = DwFinishDesc{(const float*)d_workspace + off + boff, jb.d_bgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.m_out, elems};
-            elems += jb.m_out;
+            fb = DwFinishDesc{(const float*)d_workspace + off + boff, jb.d_bgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.m_out, 0, 1};
+            region(fb);
         }
         off += (int64_t)dj.n_blocks * dj.slab_len;
     }
     for (int x = 0; x < n_extra; ++x) {
         DwFinishDesc& fd = fa.d[fa.n++];
         fd = DwFinishDesc{extra[x].d_slab, extra[x].d_grad, extra[x].grad_ld, (int32_t)extra[x].slab_stride, extra[x].n_slabs, extra[x].row_pitch,
-                          extra[x].m_out, extra[x].n_out, elems};
-        elems += extra[x].m_out * extra[x].n_out;
+                          extra[x].m_out, extra[x].n_out, 0, 1};
+        fd.lanes = fd.n_slabs > 96 ? 32 : 1;
+        fd.first_elem = elems;
+        elems += (fd.m_out * fd.n_out * fd.lanes + 63) / 64 * 64;
     }
     fa.loss_work = d_loss_work; fa.loss_sums = d_loss_sums; fa.n_loss_rows = n_loss_rows;
+    elems = (elems + 255) / 256 * 256;                      // (the loss rider is the workgroup behind the regions)
     fa.total = elems;
     TG_REQUIRE(grid <= cus, "tg_mlp_weight_grad: %d workgroups for %d CUs (the workspace holds one slab per CU)", grid, cus);
     hipStream_t st = (hipStream_t)stream;
     int rc = hidden == 256 ? launch_dw<256>(args, grid, rows, (float*)d_workspace, st) : launch_dw<128>(args, grid, rows, (float*)d_workspace, st);
     if (rc != TG_OK) return rc;
-    hipLaunchKernelGGL(dw_finish_all_kernel, dim3((unsigned)ceil_div(elems + 4, 256)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(dw_finish_all_kernel, dim3((unsigned)(elems / 256 + (d_loss_work ? 1 : 0))), dim3(256), 0, st, fa);
     TG_LAUNCH_CHECK("tg_mlp_weight_grad (finish)");
     return TG_OK;
 }
