@@ -426,7 +426,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="per-step launches (actor GEMMs + tg_rollout_step) instead of the fused persistent rollout kernel")
     ap.add_argument("--event-every", type=int, default=0,
-                    help="time the hot kernels' launches on every N-th step of the timed region (0: every step when a step takes >= 20 ms, else every 4th)")
+                    help="time the hot kernels' launches on every N-th step of the timed region (0: every step when a step takes >= 20 ms, else every 8th)")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="do not bracket the rollout / learner launches with HIP events (A/B of the measurement's own cost; no roofline objects)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -589,8 +589,9 @@ def main():
     learner_mlps = [m for m in (algo._mlp(n_) for n_ in nets) if m is not None]
     # HIP-event pairs around every hot-kernel launch.  An event is a packet on the queue (~6 us between two kernels): on a step
     # of a few milliseconds (C2: ~45 timed launches in 3.5 ms) timing EVERY launch of EVERY step slows the step by 8 %, so such
-    # steps are timed on every `event_every`-th step of the timed region; steps >= 20 ms (C3) time all of them.
-    event_every = args.event_every if args.event_every > 0 else (1 if warm_ms >= 20.0 else 4)
+    # steps are timed on every `event_every`-th step of the timed region (8th: a timed C2 step is ~15 % longer, so the line loses ~2 %;
+    # `--no-launch-events` gives the undisturbed figure); steps >= 20 ms (C3) time all of them.
+    event_every = args.event_every if args.event_every > 0 else (1 if warm_ms >= 20.0 else 8)
     event_lists = {id(m): ([], [], []) for m in learner_mlps}
     timed_steps = 0
 

@@ -336,7 +336,7 @@ typedef struct tg_chain_loss {
     float        var[4];
     float        epsilon, surr_coef, critic_coef, kl_coef;
     void*        d_dout8; float* d_head_slabs; double* d_work; float* d_bias_partial;
-    /* kind 0, tg_mlp_f32_forward_backward only (NULL elsewhere): the old policy IS the current one (ppo.py:142-143 always; GRPO when
+    /* kind 0 (tg_mlp_forward_chain_loss, tg_mlp_f32_forward_backward; NULL otherwise): the old policy IS the current one (ppo.py:142-143 always; GRPO when
      * nothing has touched either net since `old_policy.load_state_dict(policy.state_dict())`, grpo.py:148): the row's log-probability
      * is written here and used as its own old log-probability (ratio exactly 1, as in the reference, whose two forward passes are
      * the same arithmetic) -- d_logp_old is not read, and the caller needs no no-grad pass of the old policy. */

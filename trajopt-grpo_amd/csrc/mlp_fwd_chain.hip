@@ -43,6 +43,8 @@ struct ChainActs { uint16_t* p[kChainMaxHidden]; uint32_t* m[kChainMaxHidden]; }
 // first layer): the top activation is never written (-512 B per row) and tg_mlp_weight_grad has no DH job (-528 B per row).
 struct ChainLoss {                          // (kept small: every field is a scalar register for the whole kernel)
     int32_t kind, A;                        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error); A <= 4 outputs
+                                            // 2: actor whose old policy is the current one: `logp_old` is WRITTEN (the row's own
+                                            //    log-probability, which is then also its old one: ratio exactly 1), not read
     const float* act;                       // actor: [rows][A] contiguous;  critic: the returns [rows]
     const float* logp_old; const float* adv;
     float n_m, n_i;                         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
@@ -262,10 +264,11 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
         if (lane < 32) {
             int64_t r = round * (32 * WPW) + wave * 32 + lane;
             r = r < rows ? r : rows - 1; r = mem_row(r);
-            if (L.kind == 0) {
+            if (L.kind != 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < L.A) __builtin_amdgcn_global_load_lds(L.act + r * L.A + k, (lds_void*)(lin + 32 * k), 4, 0, 0);
+                // (kind 2 loads the slot it is about to write: never used, but every round issues the same number of DMAs)
                 __builtin_amdgcn_global_load_lds(L.logp_old + r, (lds_void*)(lin + 32 * 4), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(L.adv + r, (lds_void*)(lin + 32 * 5), 4, 0, 0);
             } else {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                         const bool valid = row0 + rl < rows;              // clamped duplicates of the last row contribute nothing
                         float g[4] = {0.f, 0.f, 0.f, 0.f};
                         if (valid) {
-                            if (L.kind == 0) {
+                            if (L.kind != 1) {
                                 float quad = 0.f, dmu[4];
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {              // (inv_var is 0 beyond the net's outputs; the tile slots hold zeros)
@@ -427,7 +430,11 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                                     quad += d * d * L.inv_var[k];
                                 }
                                 const float lp = -0.5f * quad + L.logp_const;
-                                const float lpo = lds_loadf(lin + 32 * 4 + rl);
+                                float lpo = lds_loadf(lin + 32 * 4 + rl);
+                                if (L.kind == 2) {
+                                    lpo = lp;
+                                    const_cast<float*>(L.logp_old)[rowc[c]] = lp;      // (valid rows only: inside `if (valid)`)
+                                }
                                 const float adv = (lds_loadf(lin + 32 * 5 + rl) - L.n_m) * L.n_i;
                                 const float rho = expf(lp - lpo);
                                 const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
@@ -615,11 +622,11 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
     TG_REQUIRE(loss->kind == 0 || loss->kind == 1, "tg_mlp_forward_chain_loss: kind %d", loss->kind);
     TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_forward_chain_loss: %d outputs unsupported (1..4)", loss->act_dim);
     TG_REQUIRE(loss->d_dout8 && loss->d_head_slabs && loss->d_work && loss->d_bias_partial, "tg_mlp_forward_chain_loss: null output");
-    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && loss->d_logp_old && loss->d_adv),
+    TG_REQUIRE(loss->kind == 1 ? loss->d_ret != nullptr : (loss->d_act && (loss->d_logp_old || loss->d_logp_old_out) && loss->d_adv),
                "tg_mlp_forward_chain_loss: missing per-row input");
     TG_REQUIRE(loss->kind == 1 || (loss->act_col_stride == 1 && loss->act_row_stride == loss->act_dim),
                "tg_mlp_forward_chain_loss: the actions must be contiguous [rows][act_dim]");
-    TG_REQUIRE(loss->d_logp_old_out == nullptr, "tg_mlp_forward_chain_loss: d_logp_old_out is tg_mlp_f32_forward_backward's (this kernel reads d_logp_old)");
+
     TG_REQUIRE(rows > 0, "tg_mlp_forward_chain_loss: no rows");
     ChainActs acts{};
     for (int l = 0; l < n_hidden_layers; ++l) {
@@ -632,6 +639,10 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
     L.kind = loss->kind; L.A = loss->act_dim;
     L.act = loss->kind == 0 ? loss->d_act : loss->d_ret;
     L.logp_old = loss->d_logp_old; L.adv = loss->d_adv;
+    if (loss->kind == 0 && loss->d_logp_old_out != nullptr) {      // the old policy is the current one: this pass writes the old log-probabilities
+        L.kind = 2;
+        L.logp_old = loss->d_logp_old_out;
+    }
     L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
     float logdet = 0.f;
     for (int k = 0; k < 4; ++k) {

@@ -412,7 +412,6 @@ class GemmMLP:
         if self._f32 is not None:
             return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out,
                                           logp_old_out)
-        assert logp_old_out is None, "logp_old_out: the fp32 chain learner's loss head only (can_write_old_logp())"
         self._flush_riders()                 # (a forward_loss() that was never followed by backward_fused(): its head gradient is due)
         self._fresh("chain")
         L = len(self.linears)
@@ -426,25 +425,9 @@ class GemmMLP:
                              torch.empty(nblk * 4, dtype=torch.float64, device=dev),
                              torch.empty(nblk * 4, dtype=torch.float32, device=dev))
         slabs, work, bpart = self._head_ws
-        a = N.ChainLoss()
-        a.kind, a.act_dim = kind, self.out_dim
-        if kind == 0:
-            N.require_cuda(act, logp_old, adv)
-            assert act.dtype == torch.float32 and logp_old.dtype == torch.float32 and adv.dtype == torch.float32
-            assert logp_old.is_contiguous() and adv.is_contiguous() and act.shape == (rows, self.out_dim) and act.is_contiguous()
-            a.d_act, a.act_row_stride, a.act_col_stride = act.data_ptr(), act.stride(0), act.stride(1)
-            a.d_logp_old, a.d_adv = logp_old.data_ptr(), adv.data_ptr()
-            va = [float(v) for v in (var.tolist() if isinstance(var, torch.Tensor) else var)]
-            for i in range(self.out_dim):
-                a.var[i] = va[i]
-        else:
-            N.require_cuda(ret)
-            assert ret.dtype == torch.float32 and ret.is_contiguous() and self.out_dim == 1
-            a.d_ret = ret.data_ptr()
-            a.var[0] = 1.0
-        # (norm = host pair (mean, 1 / (std + eps)) of the advantage / return, or None)
-        a.norm_mean, a.norm_inv = (0.0, 1.0) if norm is None else (float(norm[0]), float(norm[1]))
-        a.epsilon, a.surr_coef, a.critic_coef, a.kl_coef = float(epsilon), float(surr_coef), float(critic_coef), float(kl_coef)
+        # (norm = host pair (mean, 1 / (std + eps)) of the advantage / return, or None; logp_old_out: the old policy is the current
+        # one -- this pass writes the old log-probabilities instead of reading them)
+        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out)
         a.d_dout8, a.d_head_slabs, a.d_work, a.d_bias_partial = dz_head.data_ptr(), slabs.data_ptr(), work.data_ptr(), bpart.data_ptr()
         ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid])
         mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits])
@@ -514,8 +497,8 @@ class GemmMLP:
         return a
 
     def can_write_old_logp(self) -> bool:
-        """forward_loss(logp_old_out=...) is available: the fp32 chain learner's loss head."""
-        return self._f32 is not None and self.can_fuse_head()
+        """forward_loss(logp_old_out=...) is available: the loss head runs inside the forward chain (bf16 or fp32)."""
+        return self.can_fuse_head()
 
     def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out=None,
                           logp_old_out=None):
