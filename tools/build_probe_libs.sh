@@ -10,3 +10,4 @@ build w64k_nt     "-DTG_PROBE_ROW_WINDOW=65536"                                 
 build nowin_plain "-DTG_ACT_STORE_NT=0 -DTG_DW_LOAD_AUX=0"                                 # default cache policies, no window
 build dwstamps    "-DTG_F32DW_STAMPS=1"                                                    # fp32 weight-gradient kernel with s_memtime stamps
 build fusedbound  "-DTG_ABLATE_FUSED_CHAIN=1"                                            # upper bound of a fused bf16 forward + loss + backward chain kernel
+build tiledstore  "-DTG_TILED_STORE=1"                                                   # chain kernels store their tiles untransposed into a tiled layout (timing only)

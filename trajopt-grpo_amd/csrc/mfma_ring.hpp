@@ -47,6 +47,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 // the memory traffic a single forward + loss + backward kernel would not have -- the forward chain's mask-bit and d loss / d output
 // stores, the backward chain's loads of them and its second read of the input row.  Results are meaningless; the timing is an
 // upper bound on what that fusion could gain, before its own costs.
+#ifndef TG_TILED_STORE
+#define TG_TILED_STORE 0
+#endif
 #ifndef TG_ABLATE_FUSED_CHAIN
 #define TG_ABLATE_FUSED_CHAIN 0
 #endif

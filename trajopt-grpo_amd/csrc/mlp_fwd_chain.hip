@@ -85,6 +85,28 @@ __device__ static inline float4 lds_float4(const float* __restrict__ p) { return
 // with identical bytes.
 __device__ static inline void store_pair(uint4* __restrict__ st, uint16_t* __restrict__ g, int64_t row0, int64_t rows, int ld,
                                          int lane, const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+#if TG_TILED_STORE
+    // Probe build (-DTG_TILED_STORE=1): the registers go out as they stand into a TILED layout [32-row tile][16-B feature chunk]
+    // [row][16 B] -- every instruction writes four 256-B runs (whole 128-B lines), no LDS transpose.  Consumers do not read this
+    // layout: timing only (what the epilogue's transpose costs).
+    {
+        const int col = lane & 15, grp = lane >> 4;
+        const int64_t tile = row0 >> 5;
+        // (g = buffer + first column of the block pair; buffers are 512-B aligned, ld a power of two: recover both)
+        const int colofs = (int)(((uintptr_t)g >> 1) & (uintptr_t)(ld - 1));
+        uint16_t* base = g - colofs;
+        const int chunk0 = colofs / 8;                                                     // 16-B chunk of the pair's first block
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int row = 16 * c + col;
+            uint16_t* ta = base + ((tile * (ld / 8) + chunk0 + grp) * 32 + row) * 8;
+            uint16_t* tb = base + ((tile * (ld / 8) + chunk0 + 4 + grp) * 32 + row) * 8;
+            act_store16(__builtin_bit_cast(act_u32x4, a[c]), reinterpret_cast<act_u32x4*>(ta));
+            act_store16(__builtin_bit_cast(act_u32x4, b[c]), reinterpret_cast<act_u32x4*>(tb));
+        }
+        return;
+    }
+#endif
     const int col = lane & 15, grp = lane >> 4;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
