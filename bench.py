@@ -48,8 +48,8 @@ sys.path.insert(0, REPO)
 HIDDEN = (256, 256, 256, 256, 256)
 ALGO_BYTES = {"CartPole": 57, "QuadPole2D": 101, "QuadPole": 189}    # SURVEY 8(d), compact variant
 HBM_PEAK_GBS = 8000.0                                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
-# PMC traffic per row of the three learner kernels at 2^22 rows (profiles/r03_*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE)
-PMC_JSON = {"dw": "r03_dw_probe_pmc.json", "bwd": "r03_bwd_chain_probe_pmc.json", "fwd": "r03_fwd_chain_probe_pmc.json"}
+# PMC traffic per row of the three learner kernels at 2^22 rows (profiles/r04_*_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE)
+PMC_JSON = {"dw": "r04_dw_probe_pmc.json", "bwd": "r04_bwd_chain_probe_pmc.json", "fwd": "r04_fwd_chain_probe_pmc.json"}
 CONFIGS = {
     #        env           algo    groups/GPU  episodes  agents  restart  total envs (strong scaling)
     "c2": ("CartPole",      "grpo", 64,         64,       1,      False,   4096),
