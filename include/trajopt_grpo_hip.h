@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 10
+#define TG_ABI_VERSION 11
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -517,6 +517,28 @@ int  tg_params_differ(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t 
 int  tg_adam_step_push(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total, double lr, double beta1, double beta2, double eps,
                        int64_t step, int32_t zero_grads, const tg_gather_segment* d_segments, int32_t n_segments,
                        const int32_t* d_inv_start, const int32_t* d_inv_dst, void* stream);
+/* tg_mlp_f32_weight_grad with the optimizer step RIDING on its reduction launch: the thread that completes a gradient element applies
+ * tg_adam_step's update to its parameter and (push tables given) tg_adam_step_push's layout writes, then leaves the gradient zeroed
+ * (zero_grads) or holding the accumulated value -- what `loss.backward(); optimizer.step()` (algorithms/grpo.py:144-145) leaves, bit
+ * for bit, in the launches of the backward pass alone.  h_table: a HOST copy of the optimizer's tensor table; every tensor of it must
+ * be exactly one gradient window of `jobs`, whole and contiguous (else an error: a parameter without a window would miss its step).
+ * Only where nothing stands between the gradients and the step: one rank (no all-reduce), one chunk of rows per update. */
+typedef struct tg_adam_rider {
+    const tg_adam_tensor*    h_table;
+    int32_t                  n_tensors;
+    int32_t                  zero_grads;
+    int64_t                  total;
+    double                   lr, beta1, beta2, eps;
+    int64_t                  step;          /* 1-based, after the increment */
+    const tg_gather_segment* d_segments;    /* optional (all three or none): tg_adam_step_push's tables */
+    int32_t                  n_segments;
+    int32_t                  pad;
+    const int32_t*           d_inv_start;
+    const int32_t*           d_inv_dst;
+} tg_adam_rider;
+int  tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
+                                 int64_t workspace_bytes, const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums,
+                                 const tg_adam_rider* adam, void* stream);
 
 /* ---- The learner's prologue (algorithms/grpo.py:66-115, algorithms/ppo.py:126-139: returns, group statistics, `x[mask]`) ----
  * tg_returns_moments: tg_rtg_scan + tg_masked_moments of the returns in two launches instead of three, in the form for rollouts of

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TG_NATIVE_LIB: another build of the same library (probe builds with different compile-time flags, tools/mall_probe.py)
 LIB_PATH = os.environ.get("TG_NATIVE_LIB") or os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 10                     # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 11                     # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -74,6 +74,19 @@ class F32DwJob(C.Structure):
 
 
 TG_F32DW_MM, TG_F32DW_HEAD = 0, 1
+
+
+class AdamTensor(C.Structure):
+    """tg_adam_tensor (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("first", C.c_int64)]
+
+
+class AdamRider(C.Structure):
+    """tg_adam_rider (include/trajopt_grpo_hip.h)."""
+    _fields_ = [("h_table", C.POINTER(AdamTensor)), ("n_tensors", C.c_int32), ("zero_grads", C.c_int32), ("total", C.c_int64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int64),
+                ("d_segments", C.c_void_p), ("n_segments", C.c_int32), ("pad", C.c_int32), ("d_inv_start", C.c_void_p),
+                ("d_inv_dst", C.c_void_p)]
 
 
 class ChainLoss(C.Structure):
@@ -152,6 +165,7 @@ SIGNATURES = {
                                               C.POINTER(ChainLoss), _VP]),
     "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
+    "tg_mlp_f32_weight_grad_adam": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, C.POINTER(AdamRider), _VP]),
     "tg_adam_step": (C.c_int, [_VP, _I32, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _I32, _VP]),
     "tg_gather_streams": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
     "tg_params_differ": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),

@@ -35,6 +35,7 @@ _NONZERO_STATIC = os.environ.get("TG_NONZERO_STATIC", "1") == "1"  # 0: torch.no
 _FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
 _NATIVE_PREPARE = os.environ.get("TG_NATIVE_PREPARE", "1") == "1"  # 0: the prologue as torch launches (nonzero, index_selects, pads: A/B runs)
 _FOLD_OLD_LOGP = os.environ.get("TG_FOLD_OLD_LOGP", "1") == "1"    # 0: always a no-grad pass of the old policy for the old log-probabilities (A/B runs)
+_ADAM_RIDER = os.environ.get("TG_ADAM_RIDER", "1") == "1"          # 0: the optimizer step as a launch of its own after the fp32 backward pass (A/B runs)
 _SMALL_N_RETURNS = 16384                                           # envs up to which tg_returns_moments replaces tg_rtg_scan + tg_masked_moments
 
 
@@ -288,27 +289,46 @@ class _GpuLearner(Algorithm):
         rebuilds all layouts; anything else -- hooks, a patched step, another optimizer -- runs as written, layouts refreshed lazily.
         last=False: another update of this learn() follows -- the Adam launch also zeroes the gradients it consumed (the final
         update's gradients stay in .grad, as after the reference's learn())."""
-        if self._fused_adam is None:
-            self._fused_adam = O.FusedAdam(self.optimizer) if _FUSED_ADAM else False
-            if self._fused_adam:
-                owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
-                self._adam_covers_bucket = all(id(p) in owned for p in self.bucket.params)
-        refresher = None
-        if self._fused_adam:
-            extra = [x for x in (getattr(self, "_rollout_stream", None),) if x is not None]
-            key = tuple(id(n) for n in nets) + tuple(id(x) for x in extra)
-            if self._refresher is None or self._refresher[0] != key:
-                self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets], extra))
-                eng = getattr(self, "_rollout_engine", None)
-                if extra and eng is not None:
-                    eng.entry_refresh = self._refresher[1].run          # the rollout's own entry rebuild: this one gather
-            refresher = self._refresher[1]
+        refresher = self._optimizer_setup(*nets)
         stepped = bool(self._fused_adam) and self._fused_adam.step(zero_grads=not last and self._adam_covers_bucket, refresher=refresher)
         if not stepped:
             self.optimizer.step()
         self._refresh(*nets)
         if stepped and not self._fused_adam.pushed:
             refresher.run()
+
+    def _optimizer_setup(self, *nets):
+        """The fused optimizer step and the refresher of `nets`' derived layouts (None without a fused step), created on first use."""
+        if self._fused_adam is None:
+            self._fused_adam = O.FusedAdam(self.optimizer) if _FUSED_ADAM else False
+            if self._fused_adam:
+                owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+                self._adam_covers_bucket = all(id(p) in owned for p in self.bucket.params)
+        if not self._fused_adam:
+            return None
+        extra = [x for x in (getattr(self, "_rollout_stream", None),) if x is not None]
+        key = tuple(id(n) for n in nets) + tuple(id(x) for x in extra)
+        if self._refresher is None or self._refresher[0] != key:
+            self._refresher = (key, O.StreamRefresher(self._fused_adam, [self._mlp(n) for n in nets], extra))
+            eng = getattr(self, "_rollout_engine", None)
+            if extra and eng is not None:
+                eng.entry_refresh = self._refresher[1].run          # the rollout's own entry rebuild: this one gather
+        return self._refresher[1]
+
+    def _adam_rider(self, net, last, whole_update):
+        """`optimizer.step()` (grpo.py:145) as a rider of the backward pass's last launch, where nothing stands between the gradients
+        and the step: the fp32 chain learner, one rank (no all-reduce), the update's rows in ONE chunk, and an optimizer that holds
+        exactly this net's parameters.  None otherwise -- the caller then all-reduces and calls _optimizer_step() as before."""
+        m = self._mlp(net)
+        if not (_ADAM_RIDER and whole_update and m is not None and m._f32 is not None) or D.rank_world(self.process_group)[1] != 1:
+            return None
+        refresher = self._optimizer_setup(net)
+        if refresher is None or not self._adam_covers_bucket:
+            return None
+        owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
+        if owned != {id(p) for p in net.parameters()}:
+            return None
+        return self._fused_adam.rider(zero_grads=not last, refresher=refresher)
 
     def _prep(self, net, X, cap_rows=0):
         m = self._mlp(net)
@@ -497,13 +517,17 @@ class GRPO(_GpuLearner):
                 self._zero_grads()
             sums = all_sums[u]
             fuse = m_actor is not None and m_actor.can_fuse_head()
+            last = u == self.updates_per_iter - 1
+            rider = None
             for lo in range(0, X.shape[0], self.chunk_rows):
                 hi = min(lo + self.chunk_rows, X.shape[0])
                 if fuse:        # loss head + head gradient inside the forward chain (tg_mlp_forward_chain_loss)
                     m_actor.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], var=var,
                                          epsilon=self.epsilon, surr_coef=coef, sums_out=sums,
                                          logp_old_out=old_logp[lo:hi] if (fold_old and u == 0) else None)
-                    m_actor.backward_fused()
+                    # (asked for right before the launch it rides on: it marks the weight layouts as current)
+                    rider = self._adam_rider(actor, last, whole_update=lo == 0 and hi == X.shape[0])
+                    m_actor.backward_fused(adam=rider)
                     continue
                 else:
                     mean = self._forward(actor, xin[lo:hi], train=True, view=True)     # the loss kernel takes a row stride
@@ -511,8 +535,10 @@ class GRPO(_GpuLearner):
                                                        None, None, var, self.epsilon, coef, 0.0, 0.0, want_total=False)
                     self._backward(actor, mean, g_mean)
                 sums += s
+            if rider is not None:                                            # (one rank: no all-reduce; the step rode on the reduction)
+                continue
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
-            self._optimizer_step(actor, last=u == self.updates_per_iter - 1)
+            self._optimizer_step(actor, last=last)
         self._copy_policy_to_old()                                          # grpo.py:148
         if self.updates_per_iter > 0:
             allJ = all_sums

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "tg_common.hpp"
+#include "adam_update.hpp"
 
 #ifndef TG_F32DW_STAMPS
 #define TG_F32DW_STAMPS 0          /* diagnostic build: s_memtime stamps around the phases of the wide job's stage loop (never in the product) */
@@ -1133,12 +1134,17 @@ struct F32FinishDesc {
     const float* slab; float* grad; int64_t grad_ld;
     int32_t slab_len, n_slabs, N, m_out, n_out, first_elem;     // first_elem: in UNITS (below) once the launcher has laid them out
     int32_t vec;                                                // a unit = 4 consecutive floats of a row (else 1 float)
+    // the optimizer step riding on the reduction (tg_mlp_f32_weight_grad_adam): the window IS a whole parameter tensor, p / m / v its
+    // master, exp_avg and exp_avg_sq, adam_first the tensor's first element in the optimizer's index space; p == nullptr: none
+    float* p; float* m; float* v; int64_t adam_first;
 };
 struct F32FinishArgs {
     F32FinishDesc d[2 * kF32DwMaxJobs]; int32_t n; int32_t total;
     // optional rider of the launch: sums[k] += sum over rows [0, n_loss_rows) of loss_work[row][k], in a fixed order (the chain
     // kernel's per-workgroup loss sums: this launch follows it in stream order, so no device-scope hand-off is needed)
     const double* loss_work; double* loss_sums; int32_t n_loss_rows; int32_t n_blocks;
+    AdamScalars adam; int32_t adam_zero_grads;
+    const GatherSegment* seg; const int32_t* inv_start; const int32_t* inv_dst;      // (seg == nullptr: no derived layouts pushed)
 };
 
 // A workgroup = 32 consecutive output units x 8 slab chunks: thread (el, c) adds slabs c, c + 8, ... of its unit (8 loads in
@@ -1162,6 +1168,8 @@ __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa
     const int e = blockIdx.x * 32 + el;
     float4 sum = float4{0.f, 0.f, 0.f, 0.f};
     float* dst = nullptr;
+    float *ap = nullptr, *am = nullptr, *av = nullptr;
+    int64_t ae = 0;
     bool vec = false;
     if (e < fa.total) {
         int k = 0;
@@ -1174,6 +1182,7 @@ __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa
         const int m = le / d.n_out, n = le - m * d.n_out;
         const float* src = d.slab + (int64_t)m * d.N + n;
         dst = d.grad + (int64_t)m * d.grad_ld + n;
+        if (d.p) { ap = d.p + le; am = d.m + le; av = d.v + le; ae = d.adam_first + le; }
         int b = c;
         if (vec) {
             float4 s[8];
@@ -1213,13 +1222,39 @@ __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa
         float4 t = part[0][el];
 #pragma unroll
         for (int u = 1; u < 8; ++u) { t.x += part[u][el].x; t.y += part[u][el].y; t.z += part[u][el].z; t.w += part[u][el].w; }
+        // With the optimizer step riding (ap): the element's gradient is complete here, so the thread that holds it applies Adam
+        // to its parameter (adam_update: the operation sequence of tg_adam_step), writes the new value into the derived weight
+        // layouts (adam_push) and leaves the gradient as the optimizer launch would have (zeroed, or the accumulated value).
         if (vec) {
             float4* d4 = reinterpret_cast<float4*>(dst);
             float4 g = *d4;
             g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            if (ap) {
+                float4 P = *reinterpret_cast<const float4*>(ap), Mv = *reinterpret_cast<const float4*>(am), Vv = *reinterpret_cast<const float4*>(av);
+                P.x = adam_update(g.x, Mv.x, Vv.x, P.x, fa.adam);
+                P.y = adam_update(g.y, Mv.y, Vv.y, P.y, fa.adam);
+                P.z = adam_update(g.z, Mv.z, Vv.z, P.z, fa.adam);
+                P.w = adam_update(g.w, Mv.w, Vv.w, P.w, fa.adam);
+                *reinterpret_cast<float4*>(ap) = P; *reinterpret_cast<float4*>(am) = Mv; *reinterpret_cast<float4*>(av) = Vv;
+                if (fa.seg) {
+                    adam_push(ae, P.x, fa.seg, fa.inv_start, fa.inv_dst);
+                    adam_push(ae + 1, P.y, fa.seg, fa.inv_start, fa.inv_dst);
+                    adam_push(ae + 2, P.z, fa.seg, fa.inv_start, fa.inv_dst);
+                    adam_push(ae + 3, P.w, fa.seg, fa.inv_start, fa.inv_dst);
+                }
+                if (fa.adam_zero_grads) g = float4{0.f, 0.f, 0.f, 0.f};
+            }
             *d4 = g;
         } else {
-            *dst += t.x;
+            float g = *dst + t.x;
+            if (ap) {
+                float Mv = *am, Vv = *av;
+                const float P = adam_update(g, Mv, Vv, *ap, fa.adam);
+                *ap = P; *am = Mv; *av = Vv;
+                if (fa.seg) adam_push(ae, P, fa.seg, fa.inv_start, fa.inv_dst);
+                if (fa.adam_zero_grads) g = 0.f;
+            }
+            *dst = g;
         }
     }
 }
@@ -1335,7 +1370,26 @@ int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
 
 int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
                            int64_t workspace_bytes, const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums, void* stream) {
+    return tg_mlp_f32_weight_grad_adam(hidden, jobs, n_jobs, rows, d_workspace, workspace_bytes, d_loss_work, n_loss_rows, d_loss_sums,
+                                       nullptr, stream);
+}
+
+int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
+                                int64_t workspace_bytes, const double* d_loss_work, int32_t n_loss_rows, double* d_loss_sums,
+                                const tg_adam_rider* adam, void* stream) {
     TG_REQUIRE(jobs && d_workspace, "tg_mlp_f32_weight_grad: null pointer");
+    if (adam) {
+        TG_REQUIRE(adam->h_table && adam->n_tensors >= 1 && adam->n_tensors <= kAdamMaxTensors && adam->total >= 0 && adam->step >= 1,
+                   "tg_mlp_f32_weight_grad_adam: bad optimizer table (%d tensors, %lld elements, step %lld)", adam->n_tensors,
+                   (long long)adam->total, (long long)adam->step);
+        TG_REQUIRE(1.0 - adam->beta1 < 0.5, "tg_mlp_f32_weight_grad_adam: beta1 = %g: lerp's other branch (weight >= 0.5) is not implemented", adam->beta1);
+        TG_REQUIRE((adam->d_segments == nullptr) == (adam->d_inv_start == nullptr) && (adam->d_segments == nullptr) == (adam->d_inv_dst == nullptr) &&
+                   (adam->d_segments == nullptr || (adam->n_segments >= 1 && adam->n_segments <= kGatherMaxSegments)),
+                   "tg_mlp_f32_weight_grad_adam: the push tables come as all three or none, with 1..%d segments", kGatherMaxSegments);
+        // (a launch of zero rows forms no gradient and must not step the optimizer either: the caller's optimizer.step() would
+        // still have run -- refuse, so that the caller takes the separate launch)
+        TG_REQUIRE(rows > 0, "tg_mlp_f32_weight_grad_adam: no rows: run the optimizer step as its own launch");
+    }
     TG_REQUIRE(hidden == 64 || hidden == 128, "tg_mlp_f32_weight_grad: hidden width %d unsupported (64, 128)", hidden);
     TG_REQUIRE(n_jobs >= 1 && n_jobs <= kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d jobs outside 1..%d", n_jobs, kF32DwMaxJobs);
     TG_REQUIRE(rows >= 0, "tg_mlp_f32_weight_grad: negative row count");
@@ -1484,6 +1538,40 @@ int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_
         units += d.vec ? cnt / 4 : cnt;
     }
     fa.total = units;
+    if (adam) {
+        // every tensor of the optimizer's table must be exactly one of this launch's gradient windows, whole and contiguous
+        // (a parameter this launch does not produce a gradient for would silently miss its step)
+        uint64_t seen = 0;
+        for (int k = 0; k < fa.n; ++k) {
+            F32FinishDesc& d = fa.d[k];
+            int t = -1;
+            for (int q = 0; q < adam->n_tensors; ++q)
+                if (adam->h_table[q].g == d.grad) t = q;
+            TG_REQUIRE(t >= 0, "tg_mlp_f32_weight_grad_adam: gradient window %d is not a tensor of the optimizer's table", k);
+            TG_REQUIRE(!(seen >> t & 1), "tg_mlp_f32_weight_grad_adam: tensor %d is the window of two jobs", t);
+            seen |= 1ull << t;
+            const int64_t numel = (t + 1 < adam->n_tensors ? adam->h_table[t + 1].first : adam->total) - adam->h_table[t].first;
+            TG_REQUIRE((int64_t)d.m_out * d.n_out == numel && (d.m_out == 1 || d.grad_ld == d.n_out),
+                       "tg_mlp_f32_weight_grad_adam: window %d (%d x %d, ld %lld) is not the whole contiguous tensor %d (%lld elements)", k,
+                       d.m_out, d.n_out, (long long)d.grad_ld, t, (long long)numel);
+            d.p = adam->h_table[t].p; d.m = adam->h_table[t].m; d.v = adam->h_table[t].v; d.adam_first = adam->h_table[t].first;
+            TG_REQUIRE(d.p && d.m && d.v, "tg_mlp_f32_weight_grad_adam: tensor %d has a null pointer", t);
+            if (d.vec && ((((uintptr_t)d.p | (uintptr_t)d.m | (uintptr_t)d.v) & 15) != 0)) d.vec = 0;
+        }
+        TG_REQUIRE(fa.n == adam->n_tensors, "tg_mlp_f32_weight_grad_adam: the launch produces %d gradient windows, the optimizer holds %d tensors",
+                   fa.n, adam->n_tensors);
+        // (units were laid out with the windows' own vec flags: lay them out again with the final ones)
+        units = 0;
+        for (int k = 0; k < fa.n; ++k) {
+            F32FinishDesc& d = fa.d[k];
+            d.first_elem = units;
+            units += d.vec ? d.m_out * d.n_out / 4 : d.m_out * d.n_out;
+        }
+        fa.total = units;
+        fa.adam = adam_scalars(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step);
+        fa.adam_zero_grads = adam->zero_grads;
+        fa.seg = reinterpret_cast<const GatherSegment*>(adam->d_segments); fa.inv_start = adam->d_inv_start; fa.inv_dst = adam->d_inv_dst;
+    }
     TG_REQUIRE((d_loss_work == nullptr) == (d_loss_sums == nullptr) && n_loss_rows >= 0 && n_loss_rows <= 65536,
                "tg_mlp_f32_weight_grad: loss-sum rider needs both pointers and 0..65536 rows");
     fa.n_blocks = (int32_t)ceil_div(units, 32);

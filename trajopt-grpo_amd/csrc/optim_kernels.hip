@@ -10,25 +10,16 @@
 //   tg_gather_streams every derived layout of the weights (the chain kernels' bf16 fragment streams and f32 bias tables, the fp32
 //                     chain stream) rebuilt from the fp32 masters by one gather: element j of segment s = master
 //                     tensor (code >> 24), offset (code & 0xFFFFFF), or zero.
-#include "tg_common.hpp"
+#include "adam_update.hpp"
 
 namespace tg {
 
-struct AdamTensor { float* p; float* g; float* m; float* v; int64_t first; };   // first = index of element 0 in the launch
-constexpr int kAdamMaxTensors = 64;
-
-struct GatherSegment { void* dst; const int32_t* code; int64_t first; int32_t is_bf16; int32_t pad; };
-constexpr int kGatherMaxSegments = 32;
-constexpr int kPushSegShift = 26;          // a push destination = segment << 26 | element of the segment
-
-// kPush: the thread that has just updated a parameter also writes it into every derived layout it appears in (inv_start / inv_dst:
-// the gather's codes inverted, CSR over the launch's element index) -- tg_gather_streams folded into the optimizer step.
+// kPush: the thread that has just updated a parameter also writes it into every derived layout it appears in (adam_push) --
+// tg_gather_streams folded into the optimizer step.
 template <bool kPush>
-__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total,
-                                                   float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size,
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, int32_t n_tensors, int64_t total, AdamScalars a,
                                                    int32_t zero_grads, const GatherSegment* __restrict__ seg,
                                                    const int32_t* __restrict__ inv_start, const int32_t* __restrict__ inv_dst) {
-#pragma clang fp contract(off)
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     int k = 0;
@@ -37,31 +28,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
     const AdamTensor d = table[k];
     const int64_t i = e - d.first;
     const float g = d.g[i];
-    float m = d.m[i], v = d.v[i], p = d.p[i];
-    // torch._foreach_lerp_(exp_avg, grad, 1 - beta1): weight < 0.5 -> self + weight * (end - self), the product fused into the sum
-    m = fmaf(w1, g - m, m);
-    // torch._foreach_mul_(exp_avg_sq, beta2); torch._foreach_addcmul_(exp_avg_sq, grad, grad, 1 - beta2): self + value * t1 * t2
-    // (measured against torch 2.10's kernels on gfx950: the square is rounded, then value * square is fused into the sum)
-    v = v * beta2;
-    v = fmaf(w2, g * g, v);
-    // sqrt -> / sqrt(bias_correction2) -> + eps: three kernels in torch, three roundings here.  The divisor comes in as a LIST of
-    // scalars (one per tensor): that overload divides (a / float(b)); the single-scalar overload would multiply by float(1 / b)
-    float s = sqrtf(v);
-    s = s / bc2_sqrt;
-    s = s + eps;
-    // torch._foreach_addcdiv_(param, exp_avg, denom, step_size): self + value * (t1 / t2)
-    p = fmaf(step_size, m / s, p);
+    float m = d.m[i], v = d.v[i];
+    const float p = adam_update(g, m, v, d.p[i], a);
     d.m[i] = m; d.v[i] = v; d.p[i] = p;
     if (zero_grads) d.g[i] = 0.0f;          // the next step's optimizer.zero_grad(set_to_none=False), while the line is here
-    if constexpr (kPush) {
-        for (int32_t q = inv_start[e]; q < inv_start[e + 1]; ++q) {
-            const int32_t dd = inv_dst[q];
-            const GatherSegment s_ = seg[dd >> kPushSegShift];
-            const int32_t j = dd & ((1 << kPushSegShift) - 1);
-            if (s_.is_bf16) reinterpret_cast<__bf16*>(s_.dst)[j] = (__bf16)p;        // (the conversion tg_gather_streams applies)
-            else reinterpret_cast<float*>(s_.dst)[j] = p;
-        }
-    }
+    if constexpr (kPush) adam_push(e, p, seg, inv_start, inv_dst);
 }
 
 // flag[0] |= 1 when any element of tensor pair (p, g) of the table differs bitwise (the learner's check that "old_policy is the
@@ -106,13 +77,10 @@ int tg_adam_step(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t total
     TG_REQUIRE(total >= 0 && step >= 1, "tg_adam_step: bad sizes (total %lld, step %lld)", (long long)total, (long long)step);
     TG_REQUIRE(1.0 - beta1 < 0.5, "tg_adam_step: beta1 = %g: lerp's other branch (weight >= 0.5) is not implemented", beta1);
     if (total == 0) return TG_OK;
-    // the scalars exactly as torch/optim/adam.py::_multi_tensor_adam forms them (Python doubles, cast to float by the kernels)
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const double step_size = (lr / bc1) * -1.0, bc2_sqrt = pow(bc2, 0.5);
     static_assert(sizeof(tg_adam_tensor) == sizeof(AdamTensor), "ABI struct and kernel struct must agree");
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads, nullptr, nullptr, nullptr);
+                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, adam_scalars(lr, beta1, beta2, eps, step), zero_grads,
+                       nullptr, nullptr, nullptr);
     TG_LAUNCH_CHECK("tg_adam_step");
     return TG_OK;
 }
@@ -126,12 +94,9 @@ int tg_adam_step_push(const tg_adam_tensor* d_table, int32_t n_tensors, int64_t 
     TG_REQUIRE(total >= 0 && step >= 1, "tg_adam_step_push: bad sizes (total %lld, step %lld)", (long long)total, (long long)step);
     TG_REQUIRE(1.0 - beta1 < 0.5, "tg_adam_step_push: beta1 = %g: lerp's other branch (weight >= 0.5) is not implemented", beta1);
     if (total == 0) return TG_OK;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const double step_size = (lr / bc1) * -1.0, bc2_sqrt = pow(bc2, 0.5);
     hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)bc2_sqrt, (float)eps, (float)step_size, zero_grads, reinterpret_cast<const GatherSegment*>(d_segments),
-                       d_inv_start, d_inv_dst);
+                       reinterpret_cast<const AdamTensor*>(d_table), n_tensors, total, adam_scalars(lr, beta1, beta2, eps, step), zero_grads,
+                       reinterpret_cast<const GatherSegment*>(d_segments), d_inv_start, d_inv_dst);
     TG_LAUNCH_CHECK("tg_adam_step_push");
     return TG_OK;
 }

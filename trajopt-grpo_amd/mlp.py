@@ -23,6 +23,7 @@ Only ReLU hidden activations take this path; anything else stays on torch autogr
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 import os
 
@@ -542,7 +543,7 @@ class GemmMLP:
             return None
         return self._head_ws[:grid * 4].view(grid, 4).sum(0)
 
-    def _backward_fused_f32(self):
+    def _backward_fused_f32(self, adam=None):
         f = self._f32
         xp, acts, dzs, dout = self._acts[0], self._acts[1:], self._bits, self._dz_head
         rows, H, nh, lin = xp.shape[0], f.H, f.n_hidden, self.linears
@@ -583,20 +584,23 @@ class GemmMLP:
             ev[0].record()
         rider = getattr(self, "_loss_rider", None)
         self._loss_rider = None
-        N.check(N.load().tg_mlp_f32_weight_grad(H, arr, len(specs), rows, self._dw_ws.data_ptr(), self._dw_ws.numel() * 4,
-                                                self._head_ws.data_ptr() if rider else None, rider[0] if rider else 0,
-                                                rider[1].data_ptr() if rider else None, N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
+        N.check(N.load().tg_mlp_f32_weight_grad_adam(H, arr, len(specs), rows, self._dw_ws.data_ptr(), self._dw_ws.numel() * 4,
+                                                     self._head_ws.data_ptr() if rider else None, rider[0] if rider else 0,
+                                                     rider[1].data_ptr() if rider else None, C.byref(adam) if adam is not None else None,
+                                                     N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
         if ev is not None:
             ev[1].record()
             self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * 32, f"tg::mlp_f32_dw_kernel<{H}>"))
         self._acts = self._bits = self._dz_head = self._tmask = None
 
     @torch.no_grad()
-    def backward_fused(self):
-        """The rest of the backward pass after forward_loss(): the backward chain and the weight gradients (no head job)."""
+    def backward_fused(self, adam=None):
+        """The rest of the backward pass after forward_loss(): the backward chain and the weight gradients (no head job).
+        adam (fp32 chain learner only): an optim.FusedAdam.rider() -- the optimizer step rides on the gradient reduction."""
         if self._f32 is not None:
             assert self._acts is not None and self._dz_head is not None, "backward_fused() needs forward_loss()"
-            return self._backward_fused_f32()
+            return self._backward_fused_f32(adam)
+        assert adam is None, "the optimizer step rides only on the fp32 chain learner's reduction"
         acts, bits = self._acts, self._bits
         assert acts is not None and self._dz_head is not None, "backward_fused() needs forward_loss()"
         self._backward_chain(self._dz_head, acts, bits, acts[0].shape[0], acts[0].device)

@@ -77,7 +77,7 @@ class FusedAdam:
                     for g in self.opt.param_groups for p in g["params"])
         if sig == self._sig:
             return
-        self._sig, self._tables, self.tensor_ids = sig, [], {}
+        self._sig, self._tables, self.tensor_ids, self._host_tables = sig, [], {}, []
         for gi, g in enumerate(self.opt.param_groups):
             rows, first = [], 0
             for ti, p in enumerate(g["params"]):
@@ -88,9 +88,53 @@ class FusedAdam:
                 first += p.numel()
             dev = g["params"][0].device
             self._tables.append((torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first))
+            host = (N.AdamTensor * len(rows))()
+            for slot, r in zip(host, rows):
+                slot.p, slot.g, slot.m, slot.v, slot.first = r
+            self._host_tables.append(host)
 
     def table(self, group: int = 0):
         return self._tables[group]
+
+    def _steps_uniform(self) -> bool:
+        for g in self.opt.param_groups:
+            steps = {float(self.opt.state[p]["step"]) for p in g["params"]}
+            if len(steps) != 1 or not isinstance(self.opt.state[g["params"][0]]["step"], torch.Tensor) or self.opt.state[g["params"][0]]["step"].is_cuda:
+                return False
+        return True
+
+    @torch.no_grad()
+    def rider(self, zero_grads: bool, refresher: "StreamRefresher") -> "N.AdamRider | None":
+        """This optimizer step as a RIDER of the fp32 learner's gradient-reduction launch (tg_mlp_f32_weight_grad_adam: the thread that
+        completes a gradient element steps its parameter and writes the derived layouts) -- no launch of its own.  Returns the
+        filled struct, having done step()'s host-side bookkeeping (step counters, freshness marks): the caller passes it to the launch
+        that follows immediately.  None when this form does not apply (more than one parameter group, layouts not yet gathered
+        once, anything step() itself would refuse): the caller then calls step() after its backward pass as before."""
+        if len(self.opt.param_groups) != 1 or refresher is None or not _PUSH or not self.usable():
+            return None
+        self._init_state()
+        if not self._steps_uniform():
+            return None
+        self._build()
+        push = refresher.push_tables()
+        if push is None:
+            return None
+        g = self.opt.param_groups[0]
+        for p in g["params"]:
+            self.opt.state[p]["step"] += 1
+        tab, n, total = self._tables[0]
+        seg, n_seg, inv_start, inv_dst = push
+        r = N.AdamRider()
+        r.h_table, r.n_tensors, r.zero_grads, r.total = self._host_tables[0], n, 1 if zero_grads else 0, total
+        r.lr, r.beta1, r.beta2, r.eps = g["lr"], g["betas"][0], g["betas"][1], g["eps"]
+        r.step = int(self.opt.state[g["params"][0]]["step"])
+        r.d_segments, r.n_segments, r.d_inv_start, r.d_inv_dst = seg.data_ptr(), n_seg, inv_start.data_ptr(), inv_dst.data_ptr()
+        r._keep = (self._host_tables[0], seg, inv_start, inv_dst)
+        N.RAW_PARAM_WRITES[0] += 1
+        self.grads_zeroed = bool(zero_grads)
+        refresher.mark_all()
+        self.pushed = True
+        return r
 
     @torch.no_grad()
     def step(self, zero_grads: bool = False, refresher: "StreamRefresher" = None) -> bool:
@@ -105,10 +149,8 @@ class FusedAdam:
         if not self.usable():
             return False
         self._init_state()
-        for g in self.opt.param_groups:
-            steps = {float(self.opt.state[p]["step"]) for p in g["params"]}
-            if len(steps) != 1 or not isinstance(self.opt.state[g["params"][0]]["step"], torch.Tensor) or self.opt.state[g["params"][0]]["step"].is_cuda:
-                return False
+        if not self._steps_uniform():
+            return False
         self._build()
         lib = N.load()
         push = refresher.push_tables() if (refresher is not None and _PUSH) else None
