@@ -38,8 +38,9 @@ if os.environ.get("STAMPS"):
     per = a[:, :6] / a[:, 6:7]
     print("waves", len(a), "stages/wave %.1f" % a[:, 6].mean())
     print("cycles per stage: wait+barrier %.0f  issue %.0f  phase1 %.0f  barrier %.0f  operand reads %.0f  products %.0f  | sum %.0f" % (*per.mean(0), per.mean(0).sum()))
-    for w in range(4):
-        print(" wave", w, np.round(per[w::4].mean(0)))
+    nw = int(os.environ.get("WAVES", 8))                        # waves per workgroup of the kernel that ran (8: the 8-wave fused job)
+    for w in range(nw):
+        print(" wave", w, np.round(per[w::nw].mean(0)))
     t0 = a[:, 7].min()
     print("memtime: entry spread %.0f, entry->loop %.0f, loop %.0f, loop end->exit %.0f, last exit - first entry %.0f cycles" % (
         a[:, 7].max() - t0, (a[:, 8] - a[:, 7]).mean(), (a[:, 9] - a[:, 8]).mean(), (a[:, 10] - a[:, 9]).mean(), a[:, 10].max() - t0))

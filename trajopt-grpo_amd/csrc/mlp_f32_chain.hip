@@ -1129,6 +1129,283 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 #endif
 }
 
+// The fused job (both operands rebuilt, both riders) as ONE 8-wave workgroup per slot, for nets whose only H x H layer is this job
+// (C2's 5-128-128-1: pipelines/cartpole_pipeline_grpo.py:54-76).  f32_dw_fused's 4-wave workgroup keeps the layer's 128 x 128
+// gradient in 64 accumulator registers per thread and a stage costs each wave a ~4,500-cycle chain of LDS round trips (DMA landed ->
+// small rows read -> FMAs -> panel written -> barrier -> operands read) in front of 2,560 cycles of products; with two such waves per
+// SIMD the chains overlap the CU-mate's products by a third only (profiles/r03_f32_dw_fused_job.md).  Here the same stage is spread
+// over 512 threads: a thread rebuilds 4 rows of its feature instead of 8, a wave owns a 32 x 64 strip of the gradient (32
+// accumulator registers, 16 + 4 products per stage), and a SIMD holds FOUR waves (two workgroups per CU as before) whose chains and
+// products interleave.  Same slab layout as f32_dw_fused<H, true, true> (the reduction launch does not know which kernel ran).
+template <int H, int IN_PAD>
+__global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job, int64_t rows, float* __restrict__ ws) {
+    static_assert(H == 128, "one wave per 32 x 64 strip of a 128 x 128 gradient");
+    static_assert(IN_PAD % 8 == 0 && IN_PAD >= 8 && IN_PAD <= 32, "padded input width");
+    using F = F32FusedGeom<H, true, true>;
+    constexpr int SR = F::SR, NW = 8, NG = 3;                           // DMA instructions per wave and stage: one piece of each wide panel + one small piece
+    constexpr int RG = 512 / H, RPT = SR / RG;                          // row groups of the rebuild (4), rows per thread (4)
+    constexpr int MT = H / 32, KS = NW / MT;                            // the first layer's 4 tiles: k-steps split over KS = 2 waves
+    static_assert(SR == 16 && RPT == 4 && F::N_SMALL == 3, "stage geometry");
+    extern __shared__ uint4 lds[];
+    char* lds_c = reinterpret_cast<char*>(lds);
+    TG_CLOCK_PROBE_BEGIN(g_probe_f32_dw)
+#if TG_F32DW_STAMPS
+    const unsigned long long fs_entry = __builtin_amdgcn_s_memtime(), fs_rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long fs_loop0 = 0, fs_loop1 = 0, st[7] = {0, 0, 0, 0, 0, 0, 0};
+#define TG_FSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - st_t; st_t = now_; }
+#else
+#define TG_FSTAMP(k)
+#endif
+    const int D = job.ring_slots;                                       // 2 or 3 (host: what fits 79 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;                            // strip: P features [32 wm, +32) x Q features [64 wn, +64)
+    const int my = (int)blockIdx.x, nb = (int)gridDim.x;
+    const int64_t n_st = (rows + SR - 1) / SR;
+    const int f = tid % H;                                              // this thread's feature ...
+    const int rb = (wave >> 1) * RPT;                                   // ... and first row of the stage (wave-uniform)
+    float* Pp = reinterpret_cast<float*>(lds_c + D * F::SLOT);          // rebuilt panels [SR][H], behind the ring
+    float* Qp = Pp + SR * H;
+    float* w0_s = Qp + SR * H;                                          // [H][in_pad + 4]
+    constexpr int wstride = IN_PAD + 4, thin_f4 = IN_PAD / 4;
+    for (int q = tid; q < H * IN_PAD; q += 512) {
+        const int ff = q / IN_PAD, k = q - ff * IN_PAD;
+        w0_s[ff * wstride + k] = k < job.in_dim ? job.w0[ff * job.in_dim + k] : 0.f;
+    }
+    const float b0v = job.b0[f];
+    float whv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) whv[a] = a < job.act_dim ? job.wh[a * H + f] : 0.f;
+    // feature f = 32 mt + 8 q + 4 hh + low is bit low + 4 q + 16 (mt & 1) of word hh * (MT / 2) + (mt >> 1) of its row's mask
+    const int m_word = ((f >> 2) & 1) * (MT / 2) + (f >> 6), m_shift = (f & 3) + 4 * ((f & 31) >> 3) + 16 * ((f >> 5) & 1);
+
+    // Source addresses as a wave-uniform 64-bit base (the stage's first row, clamped into the buffer) + a 32-bit lane offset: what
+    // a lane keeps across stages is two small integers, not five 64-bit pointers (at 128 registers per wave those were spilled, and
+    // a scratch reload inside the loop is a vector-memory operation in front of which the ring's counted waits would drain).
+    const int lane_hi = lane >> 5, lane_c16 = (lane & 31) * 16;
+    auto issue = [&](int64_t sg, int slot) {
+        char* sb = lds_c + slot * F::SLOT;
+        const int64_t r0 = sg * SR;
+        const int64_t rbase = r0 < rows ? r0 : rows - 1;                // (stages past the end re-read the last row)
+        const int64_t left = rows - 1 - rbase;                          // rows of the buffer beyond rbase
+        const int lim = left < SR ? (int)left : SR;                     // a lane's row offset is clamped to [0, lim]
+        const int n_valid = r0 < rows ? (rows - r0 < SR ? (int)(rows - r0) : SR) : 0;      // rows of this stage that exist
+        // a wide panel = 8 pieces of 2 rows: wave w brings piece w of each (the bottom dZ arrives as zeros past the last row: no
+        // product or sum needs masking)
+        const int rr = 2 * wave + lane_hi;
+        const uint32_t ow = (uint32_t)(rr < lim ? rr : lim) * (H * 4) + lane_c16;
+        const char* at_b = reinterpret_cast<const char*>(job.a_top + rbase * H);
+        const char* z0_b = reinterpret_cast<const char*>(job.dz0 + rbase * H);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(at_b + ow), (f32_lds_void*)(sb + F::OFF_AT + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(rr < n_valid ? reinterpret_cast<const uint4*>(z0_b + ow) : &g_f32_zero16,
+                                         (f32_lds_void*)(sb + F::OFF_Z0 + wave * 1024), 16, 0, 0);
+        const int pc = wave % F::N_SMALL;                               // (waves 3..7 repeat a piece: every wave issues NG instructions)
+        if (pc < SR / 8) {
+            // the input rows as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece
+            const int rx = pc * 8 + (lane >> 3), c4 = lane & 7;
+            const char* x_b = reinterpret_cast<const char*>(job.q + rbase * IN_PAD);
+            const uint32_t ox = (uint32_t)(rx < lim ? rx : lim) * (IN_PAD * 4) + c4 * 16;
+            __builtin_amdgcn_global_load_lds(c4 < thin_f4 ? reinterpret_cast<const uint4*>(x_b + ox) : &g_f32_zero16,
+                                             (f32_lds_void*)(sb + F::OFF_X + pc * 1024), 16, 0, 0);
+        } else {
+            // lanes [0, 32): the stage's g rows (16 B each; zeros past the last row); lanes [32, 64): its mask rows
+            const int rg_ = (lane & 31) < SR ? (lane & 31) : SR - 1;
+            const uint32_t og = (uint32_t)(rg_ < lim ? rg_ : lim) * 16;
+            const char* g_b = reinterpret_cast<const char*>(job.p + rbase * 4);
+            const char* m_b = reinterpret_cast<const char*>(job.mask + rbase * 4);
+            const uint4* src = lane < 32 ? (rg_ < n_valid ? reinterpret_cast<const uint4*>(g_b + og) : &g_f32_zero16)
+                                         : reinterpret_cast<const uint4*>(m_b + og);
+            __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_G), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2] = {f32x16{}, f32x16{}}, acc0 = f32x16{};
+    float bsum = 0.f, b0sum = 0.f, hacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float gsum = 0.f;                                                   // component (f & 3) of the row group's sum of g rows
+    const bool gc1 = (f & 1) != 0, gc2 = (f & 2) != 0;
+    int64_t sg_issue = my;
+    int slot_issue = 0, slot = 0;
+    __syncthreads();                                                    // the table is in place (ordinary stores: before any DMA)
+#pragma unroll 1
+    for (int t = 0; t < D - 1; ++t) {
+        issue(sg_issue, slot_issue);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+    }
+    const int tile0 = wave % MT, ks0 = wave / MT;                       // first-layer rider: this wave's tile and k-step phase
+#if TG_F32DW_STAMPS
+    fs_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int64_t sg = my; sg < n_st; sg += nb) {
+#if TG_F32DW_STAMPS
+        unsigned long long st_t = __builtin_amdgcn_s_memtime();
+        st[6] += 1;
+#endif
+        if (D == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // the stage has landed for every wave; every wave is done with the previous stage's slot and panels
+        asm volatile("" ::: "memory");
+        TG_FSTAMP(0)
+        issue(sg_issue, slot_issue);
+        sg_issue += nb;
+        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        char* sb = lds_c + slot * F::SLOT;
+        slot = slot + 1 == D ? 0 : slot + 1;
+        const float* X = reinterpret_cast<const float*>(sb + F::OFF_X);
+        const float* Gm = reinterpret_cast<const float*>(sb + F::OFF_G);
+        const uint32_t* Mm = reinterpret_cast<const uint32_t*>(sb + F::OFF_G + 512);
+        const float* AT = reinterpret_cast<const float*>(sb + F::OFF_AT);
+        const float* Z0 = reinterpret_cast<const float*>(sb + F::OFF_Z0);
+        TG_FSTAMP(1)
+        // ---- phase 1: rebuild (k ascending, as the chain kernel forms the values), and the riders' vector work ----
+        {
+            // a0[row][f] = relu(b0[f] + sum_k W0[f][k] x[row][k])
+            float z[RPT], o[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) { z[r] = lds_f(Z0 + (rb + r) * H + f); o[r] = b0v; }
+#pragma unroll
+            for (int k4 = 0; k4 < thin_f4; ++k4) {
+                const float4 w = lds_f4(w0_s + f * wstride + 4 * k4);
+                float4 xv[RPT];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) xv[r] = lds_f4(X + (rb + r) * 32 + 4 * k4);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) lds_st(Qp + (rb + r) * H + f, fmaxf(o[r], 0.f));
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) b0sum += z[r];
+        }
+        {
+            // dZ_top[row][f] = (sum_a g[row][a] W_head[a][f]) * bit(row, f)
+            float at[RPT];
+            float4 g4[RPT];
+            uint32_t mw[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                at[r] = lds_f(AT + (rb + r) * H + f);
+                g4[r] = lds_f4(Gm + 4 * (rb + r));
+                mw[r] = lds_u(Mm + 4 * (rb + r) + m_word);
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                float v = whv[0] * g4[r].x;
+                v = fmaf(whv[1], g4[r].y, v); v = fmaf(whv[2], g4[r].z, v); v = fmaf(whv[3], g4[r].w, v);
+                const float pv = ((mw[r] >> m_shift) & 1u) != 0u ? v : 0.f;
+                lds_st(Pp + (rb + r) * H + f, pv);
+                bsum += pv;
+                hacc[0] = fmaf(g4[r].x, at[r], hacc[0]); hacc[1] = fmaf(g4[r].y, at[r], hacc[1]);
+                hacc[2] = fmaf(g4[r].z, at[r], hacc[2]); hacc[3] = fmaf(g4[r].w, at[r], hacc[3]);
+                const float g_lo = gc1 ? g4[r].y : g4[r].x, g_hi = gc1 ? g4[r].w : g4[r].z;
+                gsum += gc2 ? g_hi : g_lo;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this thread's panel writes have landed ...
+        TG_FSTAMP(2)
+        __builtin_amdgcn_s_barrier();                               // ... and everyone's
+        asm volatile("" ::: "memory");
+        TG_FSTAMP(3)
+        // ---- phase 2: products, in two halves of 4 k-steps (a half's operands in registers first: 16 registers, and the
+        // second half's reads go out while the first half's products run) ----
+        const float* Pa = Pp + kk * H + 32 * wm + i;
+        const float* Qa = Qp + kk * H + 64 * wn + i;
+        const float* Za = Z0 + (2 * ks0 + kk) * H + 32 * tile0 + i;
+        const float* Xa = X + (2 * ks0 + kk) * 32 + i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float av[4], bv[4][2], za[2], xb[2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                av[s] = lds_f(Pa + 2 * (4 * h + s) * H);
+                bv[s][0] = lds_f(Qa + 2 * (4 * h + s) * H);
+                bv[s][1] = lds_f(Qa + 2 * (4 * h + s) * H + 32);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                           // the rider's k-steps of this half: KS (2 h + s) + ks0
+                za[s] = lds_f(Za + 2 * KS * (2 * h + s) * H);
+                xb[s] = lds_f(Xa + 2 * KS * (2 * h + s) * 32);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(av[s]), "+v"(bv[s][0]), "+v"(bv[s][1]));     // (the products stay behind the wait)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][1], acc[1], 0, 0, 0);
+                if (s % KS == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s / KS], xb[s / KS], acc0, 0, 0, 0);
+            }
+        }
+        TG_FSTAMP(5)
+    }
+#if TG_F32DW_STAMPS
+    fs_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+#undef TG_FSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no LDS-DMA may outlive the workgroup's LDS allocation
+    __syncthreads();
+    // ---- the row groups' partial sums and the k-step phases' partial tiles meet in LDS, added in a fixed order ----
+    float* red = reinterpret_cast<float*>(lds_c);                       // [7][512] floats, then [MT][16][64]
+    red[tid] = bsum;
+    red[512 + tid] = b0sum;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) red[(2 + a) * 512 + tid] = hacc[a];
+    red[6 * 512 + tid] = gsum;
+    float* tiles = red + 7 * 512;
+    if (ks0 > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tiles[(tile0 * 16 + r) * 64 + lane] = acc0[r];
+    }
+    __syncthreads();
+    float* slab = ws + job.slab_off + (int64_t)my * job.slab_len;
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int m0 = 32 * wm, n0 = 64 * wn + 32 * y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[y][r];
+    }
+    float* s1 = slab + H * H + H;                                       // first-layer rider: [H][32] + [H]
+    float* s2 = s1 + H * 32 + H;                                        // head rider: [4][H] + [4]
+    if (tid < H) {
+        float t[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            t[q] = red[q * 512 + tid];
+#pragma unroll
+            for (int g = 1; g < RG; ++g) t[q] += red[q * 512 + g * H + tid];
+        }
+        slab[H * H + tid] = t[0];
+        s1[H * 32 + tid] = t[1];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s2[a * H + tid] = t[2 + a];
+        if (tid < 4) {
+            float gs = 0.f;                                             // (thread f < 4 of a row group holds component f), groups in order
+#pragma unroll
+            for (int g = 0; g < RG; ++g) gs += red[6 * 512 + g * H + tid];
+            s2[4 * H + tid] = gs;
+        }
+    }
+    if (ks0 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc0[r] + tiles[(tile0 * 16 + r) * 64 + lane];
+            s1[(32 * tile0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = v;
+        }
+    }
+    TG_CLOCK_PROBE_END(g_probe_f32_dw)
+#if TG_F32DW_STAMPS
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* o = g_f32_stamps3 + ((size_t)blockIdx.x * 8 + wave) * 12;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = st[k];
+        o[7] = fs_entry; o[8] = fs_loop0; o[9] = fs_loop1; o[10] = __builtin_amdgcn_s_memtime(); o[11] = __builtin_amdgcn_s_memrealtime() - fs_rt0;
+    }
+#endif
+}
+
 // grad[m][n] += sum over the job's slabs, in a fixed order.
 struct F32FinishDesc {
     const float* slab; float* grad; int64_t grad_ld;
@@ -1577,7 +1854,22 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     fa.n_blocks = (int32_t)ceil_div(units, 32);
     fa.loss_work = d_loss_work; fa.loss_sums = d_loss_sums; fa.n_loss_rows = n_loss_rows;
     hipStream_t st = (hipStream_t)stream;
-    if (hidden == 128) {
+    // a net whose only H x H layer carries everything (two hidden layers, H = 128): the 8-wave form of that job
+    // (TG_F32DW_FUSED8=0: the 4-wave form, for A/B runs)
+    static const bool fused8 = [] { const char* e = getenv("TG_F32DW_FUSED8"); return !e || atoi(e) != 0; }();
+    if (hidden == 128 && n_jobs == 1 && jobs[0].recompute == 3 && fused8 &&
+        jobs[0].in_pad % 8 == 0 && jobs[0].in_pad >= 8 && jobs[0].in_pad <= 32) {
+        auto launch8 = [&](auto kern) -> int {
+            static LdsOptIn opt_in;
+            if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_weight_grad")) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), shmem, st, args.job[0], rows, (float*)d_workspace);
+            return TG_OK;
+        };
+        const int rc = jobs[0].in_pad == 8 ? launch8(mlp_f32_dw_fused8_kernel<128, 8>)
+                     : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16>)
+                     : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24>) : launch8(mlp_f32_dw_fused8_kernel<128, 32>);
+        if (rc) return rc;
+    } else if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
         static LdsOptIn opt_in;
         if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_weight_grad")) return rc;
