@@ -1137,7 +1137,11 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 // over 512 threads: a thread rebuilds 4 rows of its feature instead of 8, a wave owns a 32 x 64 strip of the gradient (32
 // accumulator registers, 16 + 4 products per stage), and a SIMD holds FOUR waves (two workgroups per CU as before) whose chains and
 // products interleave.  Same slab layout as f32_dw_fused<H, true, true> (the reduction launch does not know which kernel ran).
-template <int H, int IN_PAD>
+//   kPipe: one barrier per stage instead of two.  Two ring slots and TWO sets of rebuilt panels: an iteration rebuilds stage t + 1
+// (and does its riders) in the same instruction stream as the products of stage t, whose panels the previous iteration wrote -- the
+// barrier at the top of the iteration (the next stage's DMA has landed) is also the one that publishes them.  The last iteration
+// rebuilds a stage past the end: its P-side operands arrive as zeros, so every sum it touches gets zeros.
+template <int H, int IN_PAD, bool kPipe>
 __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job, int64_t rows, float* __restrict__ ws) {
     static_assert(H == 128, "one wave per 32 x 64 strip of a 128 x 128 gradient");
     static_assert(IN_PAD % 8 == 0 && IN_PAD >= 8 && IN_PAD <= 32, "padded input width");
@@ -1156,7 +1160,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
 #else
 #define TG_FSTAMP(k)
 #endif
-    const int D = job.ring_slots;                                       // 2 or 3 (host: what fits 79 KiB)
+    const int D = kPipe ? 2 : job.ring_slots;                           // 2 or 3 (host: what fits 79 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;                            // strip: P features [32 wm, +32) x Q features [64 wn, +64)
@@ -1164,18 +1168,21 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
     const int64_t n_st = (rows + SR - 1) / SR;
     const int f = tid % H;                                              // this thread's feature ...
     const int rb = (wave >> 1) * RPT;                                   // ... and first row of the stage (wave-uniform)
-    float* Pp = reinterpret_cast<float*>(lds_c + D * F::SLOT);          // rebuilt panels [SR][H], behind the ring
+    float* Pp = reinterpret_cast<float*>(lds_c + D * F::SLOT);          // rebuilt panels [SR][H] (kPipe: two sets of P | Q), behind the ring
     float* Qp = Pp + SR * H;
-    float* w0_s = Qp + SR * H;                                          // [H][in_pad + 4]
+    float* w0_s = Pp + (kPipe ? 4 : 2) * SR * H;                        // [H][in_pad + 4]
     constexpr int wstride = IN_PAD + 4, thin_f4 = IN_PAD / 4;
-    for (int q = tid; q < H * IN_PAD; q += 512) {
-        const int ff = q / IN_PAD, k = q - ff * IN_PAD;
-        w0_s[ff * wstride + k] = k < job.in_dim ? job.w0[ff * job.in_dim + k] : 0.f;
-    }
-    const float b0v = job.b0[f];
-    float whv[4];
+    float b0v, whv[4];
+    auto load_weights = [&]() {                                         // the first layer's table into LDS, this thread's bias and head weights
+        for (int q = tid; q < H * IN_PAD; q += 512) {
+            const int ff = q / IN_PAD, k = q - ff * IN_PAD;
+            w0_s[ff * wstride + k] = k < job.in_dim ? job.w0[ff * job.in_dim + k] : 0.f;
+        }
+        b0v = job.b0[f];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) whv[a] = a < job.act_dim ? job.wh[a * H + f] : 0.f;
+        for (int a = 0; a < 4; ++a) whv[a] = a < job.act_dim ? job.wh[a * H + f] : 0.f;
+    };
+    if constexpr (!kPipe) load_weights();
     // feature f = 32 mt + 8 q + 4 hh + low is bit low + 4 q + 16 (mt & 1) of word hh * (MT / 2) + (mt >> 1) of its row's mask
     const int m_word = ((f >> 2) & 1) * (MT / 2) + (f >> 6), m_shift = (f & 3) + 4 * ((f & 31) >> 3) + 16 * ((f >> 5) & 1);
 
@@ -1222,7 +1229,120 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
     float bsum = 0.f, b0sum = 0.f, hacc[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;                                                   // component (f & 3) of the row group's sum of g rows
     const bool gc1 = (f & 1) != 0, gc2 = (f & 2) != 0;
+    const int tile0 = wave % MT, ks0 = wave / MT;                       // first-layer rider: this wave's tile and k-step phase
+    // ---- phase 1 of a stage: rebuild into the panels Pw | Qw (k ascending, as the chain kernel forms the values), and the riders'
+    // vector work ----
+    auto rebuild_q = [&](const char* sb, float* __restrict__ Qw) {
+        // a0[row][f] = relu(b0[f] + sum_k W0[f][k] x[row][k])
+        const float* X = reinterpret_cast<const float*>(sb + F::OFF_X);
+        const float* Z0 = reinterpret_cast<const float*>(sb + F::OFF_Z0);
+        float z[RPT], o[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { z[r] = lds_f(Z0 + (rb + r) * H + f); o[r] = b0v; }
+#pragma unroll
+        for (int k4 = 0; k4 < thin_f4; ++k4) {
+            const float4 w = lds_f4(w0_s + f * wstride + 4 * k4);
+            float4 xv[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) xv[r] = lds_f4(X + (rb + r) * 32 + 4 * k4);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lds_st(Qw + (rb + r) * H + f, fmaxf(o[r], 0.f));
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) b0sum += z[r];
+    };
+    auto rebuild_p = [&](const char* sb, float* __restrict__ Pw) {
+        // dZ_top[row][f] = (sum_a g[row][a] W_head[a][f]) * bit(row, f)
+        const float* Gm = reinterpret_cast<const float*>(sb + F::OFF_G);
+        const uint32_t* Mm = reinterpret_cast<const uint32_t*>(sb + F::OFF_G + 512);
+        const float* AT = reinterpret_cast<const float*>(sb + F::OFF_AT);
+        float at[RPT];
+        float4 g4[RPT];
+        uint32_t mw[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            at[r] = lds_f(AT + (rb + r) * H + f);
+            g4[r] = lds_f4(Gm + 4 * (rb + r));
+            mw[r] = lds_u(Mm + 4 * (rb + r) + m_word);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float v = whv[0] * g4[r].x;
+            v = fmaf(whv[1], g4[r].y, v); v = fmaf(whv[2], g4[r].z, v); v = fmaf(whv[3], g4[r].w, v);
+            const float pv = ((mw[r] >> m_shift) & 1u) != 0u ? v : 0.f;
+            lds_st(Pw + (rb + r) * H + f, pv);
+            bsum += pv;
+            hacc[0] = fmaf(g4[r].x, at[r], hacc[0]); hacc[1] = fmaf(g4[r].y, at[r], hacc[1]);
+            hacc[2] = fmaf(g4[r].z, at[r], hacc[2]); hacc[3] = fmaf(g4[r].w, at[r], hacc[3]);
+            const float g_lo = gc1 ? g4[r].y : g4[r].x, g_hi = gc1 ? g4[r].w : g4[r].z;
+            gsum += gc2 ? g_hi : g_lo;
+        }
+    };
+    // ---- the first layer's rider of a stage: this wave's tile, its k-steps KS s + ks0, operands straight from the ring slot ----
+    auto rider_half = [&](const char* sb, int h) {
+        const float* Za = reinterpret_cast<const float*>(sb + F::OFF_Z0) + (2 * ks0 + kk) * H + 32 * tile0 + i;
+        const float* Xa = reinterpret_cast<const float*>(sb + F::OFF_X) + (2 * ks0 + kk) * 32 + i;
+        float za[2], xb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            za[s] = lds_f(Za + 2 * KS * (2 * h + s) * H);
+            xb[s] = lds_f(Xa + 2 * KS * (2 * h + s) * 32);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s], xb[s], acc0, 0, 0, 0);
+    };
     int64_t sg_issue = my;
+    if constexpr (kPipe) {
+        const int n_my = my < n_st ? (int)((n_st - 1 - my) / nb) + 1 : 0;
+        float* pan = Pp;                                                // set u: P at pan + 2 u SR H, Q behind it
+        issue(sg_issue, 0);                                             // the first stage is on its way while the weights are fetched
+        sg_issue += nb;
+        load_weights();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                // the table is in place and the first stage has landed
+        asm volatile("" ::: "memory");
+        issue(sg_issue, 1);
+        sg_issue += nb;
+        rebuild_q(lds_c, pan + SR * H);
+        rebuild_p(lds_c, pan);
+        rider_half(lds_c, 0);
+        rider_half(lds_c, 1);
+#pragma unroll 1
+        for (int k = 0; k < n_my; ++k) {
+            const int cur = k & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // stage k + 1 has landed; stage k's panels are complete; slot and panel set of stage k - 1 are free
+            asm volatile("" ::: "memory");
+            issue(sg_issue, cur);                                       // stage k + 2 into the slot stage k was rebuilt from
+            sg_issue += nb;
+            const char* sn = lds_c + (cur ^ 1) * F::SLOT;               // stage k + 1's slot
+            float* Pn = pan + (cur ^ 1) * 2 * SR * H;
+            const float* Pa = pan + cur * 2 * SR * H + kk * H + 32 * wm + i;
+            const float* Qa = Pa + SR * H - 32 * wm + 64 * wn;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float av[4], bv[4][2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    av[s] = lds_f(Pa + 2 * (4 * h + s) * H);
+                    bv[s][0] = lds_f(Qa + 2 * (4 * h + s) * H);
+                    bv[s][1] = lds_f(Qa + 2 * (4 * h + s) * H + 32);
+                }
+                if (h == 0) rebuild_q(sn, Pn + SR * H);
+                else rebuild_p(sn, Pn);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][1], acc[1], 0, 0, 0);
+                }
+                rider_half(sn, h);
+            }
+        }
+    } else {
     int slot_issue = 0, slot = 0;
     __syncthreads();                                                    // the table is in place (ordinary stores: before any DMA)
 #pragma unroll 1
@@ -1231,7 +1351,6 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         sg_issue += nb;
         slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
     }
-    const int tile0 = wave % MT, ks0 = wave / MT;                       // first-layer rider: this wave's tile and k-step phase
 #if TG_F32DW_STAMPS
     fs_loop0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1252,57 +1371,10 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         char* sb = lds_c + slot * F::SLOT;
         slot = slot + 1 == D ? 0 : slot + 1;
         const float* X = reinterpret_cast<const float*>(sb + F::OFF_X);
-        const float* Gm = reinterpret_cast<const float*>(sb + F::OFF_G);
-        const uint32_t* Mm = reinterpret_cast<const uint32_t*>(sb + F::OFF_G + 512);
-        const float* AT = reinterpret_cast<const float*>(sb + F::OFF_AT);
         const float* Z0 = reinterpret_cast<const float*>(sb + F::OFF_Z0);
         TG_FSTAMP(1)
-        // ---- phase 1: rebuild (k ascending, as the chain kernel forms the values), and the riders' vector work ----
-        {
-            // a0[row][f] = relu(b0[f] + sum_k W0[f][k] x[row][k])
-            float z[RPT], o[RPT];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) { z[r] = lds_f(Z0 + (rb + r) * H + f); o[r] = b0v; }
-#pragma unroll
-            for (int k4 = 0; k4 < thin_f4; ++k4) {
-                const float4 w = lds_f4(w0_s + f * wstride + 4 * k4);
-                float4 xv[RPT];
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) xv[r] = lds_f4(X + (rb + r) * 32 + 4 * k4);
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) lds_st(Qp + (rb + r) * H + f, fmaxf(o[r], 0.f));
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) b0sum += z[r];
-        }
-        {
-            // dZ_top[row][f] = (sum_a g[row][a] W_head[a][f]) * bit(row, f)
-            float at[RPT];
-            float4 g4[RPT];
-            uint32_t mw[RPT];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                at[r] = lds_f(AT + (rb + r) * H + f);
-                g4[r] = lds_f4(Gm + 4 * (rb + r));
-                mw[r] = lds_u(Mm + 4 * (rb + r) + m_word);
-            }
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                float v = whv[0] * g4[r].x;
-                v = fmaf(whv[1], g4[r].y, v); v = fmaf(whv[2], g4[r].z, v); v = fmaf(whv[3], g4[r].w, v);
-                const float pv = ((mw[r] >> m_shift) & 1u) != 0u ? v : 0.f;
-                lds_st(Pp + (rb + r) * H + f, pv);
-                bsum += pv;
-                hacc[0] = fmaf(g4[r].x, at[r], hacc[0]); hacc[1] = fmaf(g4[r].y, at[r], hacc[1]);
-                hacc[2] = fmaf(g4[r].z, at[r], hacc[2]); hacc[3] = fmaf(g4[r].w, at[r], hacc[3]);
-                const float g_lo = gc1 ? g4[r].y : g4[r].x, g_hi = gc1 ? g4[r].w : g4[r].z;
-                gsum += gc2 ? g_hi : g_lo;
-            }
-        }
+        rebuild_q(sb, Qp);
+        rebuild_p(sb, Pp);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this thread's panel writes have landed ...
         TG_FSTAMP(2)
         __builtin_amdgcn_s_barrier();                               // ... and everyone's
@@ -1343,6 +1415,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
 #if TG_F32DW_STAMPS
     fs_loop1 = __builtin_amdgcn_s_memtime();
 #endif
+    }
 #undef TG_FSTAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no LDS-DMA may outlive the workgroup's LDS allocation
     __syncthreads();
@@ -1865,9 +1938,13 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), shmem, st, args.job[0], rows, (float*)d_workspace);
             return TG_OK;
         };
-        const int rc = jobs[0].in_pad == 8 ? launch8(mlp_f32_dw_fused8_kernel<128, 8>)
-                     : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16>)
-                     : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24>) : launch8(mlp_f32_dw_fused8_kernel<128, 32>);
+        // (in_pad 8: the one-barrier form with two panel sets -- 76 KiB; TG_F32DW_PIPE=0: the two-barrier form, for A/B runs)
+        static const bool pipe = [] { const char* e = getenv("TG_F32DW_PIPE"); return !e || atoi(e) != 0; }();
+        if (jobs[0].in_pad == 8 && pipe)
+            shmem = 2 * (size_t)F32FusedGeom<128, true, true>::SLOT + 4 * 16 * 128 * 4 + 128 * (8 + 4) * 4;
+        const int rc = jobs[0].in_pad == 8 ? (pipe ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, false>))
+                     : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16, false>)
+                     : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24, false>) : launch8(mlp_f32_dw_fused8_kernel<128, 32, false>);
         if (rc) return rc;
     } else if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
