@@ -29,7 +29,8 @@
 #define TG_F32DW_STAMPS 0          /* diagnostic build: s_memtime stamps around the phases of the wide job's stage loop (never in the product) */
 #endif
 #ifndef TG_F32DW_ABLATE
-#define TG_F32DW_ABLATE 0          /* timing-only probe builds of the wide weight-gradient job: 1 = no products, 2 = no stream */
+#define TG_F32DW_ABLATE 0          /* timing-only probe builds of the wide weight-gradient job: 1 = no products, 2 = no stream;
+                                      of the one-barrier 8-wave job: 3 = no rebuild inside the loop, 4 = no products, 5 = no DMA inside the loop */
 #endif
 
 namespace tg {
@@ -1150,6 +1151,10 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
     constexpr int RG = 512 / H, RPT = SR / RG;                          // row groups of the rebuild (4), rows per thread (4)
     constexpr int MT = H / 32, KS = NW / MT;                            // the first layer's 4 tiles: k-steps split over KS = 2 waves
     static_assert(SR == 16 && RPT == 4 && F::N_SMALL == 3, "stage geometry");
+    // The first layer's gradient dW_0 = dZ_0^T x.  As a product it is one more 32 x 32 tile per wave and k-step pair -- a fifth of the
+    // matrix pipe's time for a tile of which in_dim of 32 columns are real.  At padded width 8 the rebuild's thread (feature f, 4
+    // rows) already holds dZ_0[row][f] and x[row][0..8) in registers: 8 FMAs per row into 8 accumulators instead (kVecRider).
+    constexpr bool kVecRider = kPipe && IN_PAD == 8;
     extern __shared__ uint4 lds[];
     char* lds_c = reinterpret_cast<char*>(lds);
     TG_CLOCK_PROBE_BEGIN(g_probe_f32_dw)
@@ -1226,6 +1231,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         }
     };
     f32x16 acc[2] = {f32x16{}, f32x16{}}, acc0 = f32x16{};
+    float w0acc[kVecRider ? IN_PAD : 1] = {};                          // kVecRider: dW_0[f][0..IN_PAD) of this thread's row group
     float bsum = 0.f, b0sum = 0.f, hacc[4] = {0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;                                                   // component (f & 3) of the row group's sum of g rows
     const bool gc1 = (f & 1) != 0, gc2 = (f & 2) != 0;
@@ -1248,6 +1254,13 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
+            }
+            if constexpr (kVecRider) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {                     // rows ascending
+                    w0acc[4 * k4 + 0] = fmaf(z[r], xv[r].x, w0acc[4 * k4 + 0]); w0acc[4 * k4 + 1] = fmaf(z[r], xv[r].y, w0acc[4 * k4 + 1]);
+                    w0acc[4 * k4 + 2] = fmaf(z[r], xv[r].z, w0acc[4 * k4 + 2]); w0acc[4 * k4 + 3] = fmaf(z[r], xv[r].w, w0acc[4 * k4 + 3]);
+                }
             }
         }
 #pragma unroll
@@ -1284,6 +1297,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
     };
     // ---- the first layer's rider of a stage: this wave's tile, its k-steps KS s + ks0, operands straight from the ring slot ----
     auto rider_half = [&](const char* sb, int h) {
+        if constexpr (kVecRider) return;
         const float* Za = reinterpret_cast<const float*>(sb + F::OFF_Z0) + (2 * ks0 + kk) * H + 32 * tile0 + i;
         const float* Xa = reinterpret_cast<const float*>(sb + F::OFF_X) + (2 * ks0 + kk) * 32 + i;
         float za[2], xb[2];
@@ -1317,7 +1331,9 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // stage k + 1 has landed; stage k's panels are complete; slot and panel set of stage k - 1 are free
             asm volatile("" ::: "memory");
+#if TG_F32DW_ABLATE != 5
             issue(sg_issue, cur);                                       // stage k + 2 into the slot stage k was rebuilt from
+#endif
             sg_issue += nb;
             const char* sn = lds_c + (cur ^ 1) * F::SLOT;               // stage k + 1's slot
             float* Pn = pan + (cur ^ 1) * 2 * SR * H;
@@ -1332,14 +1348,21 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
                     bv[s][0] = lds_f(Qa + 2 * (4 * h + s) * H);
                     bv[s][1] = lds_f(Qa + 2 * (4 * h + s) * H + 32);
                 }
+#if TG_F32DW_ABLATE != 3
                 if (h == 0) rebuild_q(sn, Pn + SR * H);
                 else rebuild_p(sn, Pn);
+#endif
+#if TG_F32DW_ABLATE == 4
+#pragma unroll
+                for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(av[s]), "v"(bv[s][0]), "v"(bv[s][1]));
+#else
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][0], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s][1], acc[1], 0, 0, 0);
                 }
                 rider_half(sn, h);
+#endif
             }
         }
     } else {
@@ -1426,8 +1449,11 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
 #pragma unroll
     for (int a = 0; a < 4; ++a) red[(2 + a) * 512 + tid] = hacc[a];
     red[6 * 512 + tid] = gsum;
-    float* tiles = red + 7 * 512;
-    if (ks0 > 0) {
+    float* tiles = red + 7 * 512;                                       // (kVecRider: the row groups' dW_0 rows, [RG][H][IN_PAD])
+    if constexpr (kVecRider) {
+#pragma unroll
+        for (int k = 0; k < IN_PAD; ++k) tiles[tid * IN_PAD + k] = w0acc[k];
+    } else if (ks0 > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tiles[(tile0 * 16 + r) * 64 + lane] = acc0[r];
     }
@@ -1452,6 +1478,15 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         }
         slab[H * H + tid] = t[0];
         s1[H * 32 + tid] = t[1];
+        if constexpr (kVecRider) {
+#pragma unroll
+            for (int k = 0; k < IN_PAD; ++k) {                          // (the reduction reads in_dim <= IN_PAD columns of each 32-float row)
+                float v = tiles[tid * IN_PAD + k];
+#pragma unroll
+                for (int g = 1; g < RG; ++g) v += tiles[(g * H + tid) * IN_PAD + k];
+                s1[tid * 32 + k] = v;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) s2[a * H + tid] = t[2 + a];
         if (tid < 4) {
@@ -1461,7 +1496,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             s2[4 * H + tid] = gs;
         }
     }
-    if (ks0 == 0) {
+    if (!kVecRider && ks0 == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = acc0[r] + tiles[(tile0 * 16 + r) * 64 + lane];
