@@ -2120,7 +2120,7 @@ def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden):
 # the fp32 chain learner (csrc/mlp_f32_chain.hip): the reference's own precision and net sizes
 # --------------------------------------------------------------------------------------------
 F32_SHAPES = [(5, 1, (128, 128)), (20, 4, (128,) * 4), (10, 2, (64,)), (5, 1, (64, 64, 64)), (32, 4, (128, 128, 128)), (3, 1, (128,)),
-              (12, 3, (128, 128)), (20, 4, (128, 128)), (32, 2, (128, 128))]       # (two 128-wide layers: the 8-wave weight-gradient job at every padded input width)
+              (12, 3, (128, 128)), (20, 4, (128, 128)), (32, 2, (128, 128)), (7, 2, (128, 128))]       # (two 128-wide layers: the 8-wave weight-gradient job at every padded input width)
 
 
 @pytest.mark.parametrize("dims", F32_SHAPES)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Timing-only ablations of the one-barrier 8-wave weight-gradient job (probe builds -DTG_F32DW_ABLATE=3/4/5 in scratch/, results
-# meaningless): what the stage loop costs without the rebuild, without the products, without the DMA.
+# meaningless): what the stage loop costs without the rebuild, without the products, without the DMA, with a third of the rebuild's vector instructions gone (6).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-for v in product:"" norebuild:$R/scratch/libtg_p8abl3.so noproducts:$R/scratch/libtg_p8abl4.so nodma:$R/scratch/libtg_p8abl5.so; do
+for v in product:"" norebuild:$R/scratch/libtg_p8abl3.so noproducts:$R/scratch/libtg_p8abl4.so nodma:$R/scratch/libtg_p8abl5.so lessvalu:$R/scratch/libtg_p8abl6.so; do
   name=${v%%:*}; lib=${v#*:}
   rm -rf /tmp/dwa_$name
   if [ -n "$lib" ]; then export TG_NATIVE_LIB=$lib; else unset TG_NATIVE_LIB; fi

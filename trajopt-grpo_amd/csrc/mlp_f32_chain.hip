@@ -1142,8 +1142,12 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 // (and does its riders) in the same instruction stream as the products of stage t, whose panels the previous iteration wrote -- the
 // barrier at the top of the iteration (the next stage's DMA has landed) is also the one that publishes them.  The last iteration
 // rebuilds a stage past the end: its P-side operands arrive as zeros, so every sum it touches gets zeros.
-template <int H, int IN_PAD, bool kPipe>
+//   kLean (with kPipe, padded width 8): the net has at most 5 inputs and ONE output (CartPole, Pendulum: C2) -- the terms that are
+// identically zero (input columns 5..7, head rows 1..3) are not computed: a third of the rebuild's vector instructions, which is
+// what the stage's time follows (tools/f32_dw_pipe_ablation.sh).  Same bits: fma(0, x, o) == o.
+template <int H, int IN_PAD, bool kPipe, bool kLean = false>
 __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job, int64_t rows, float* __restrict__ ws) {
+    static_assert(!kLean || (kPipe && IN_PAD == 8), "the lean form is a specialisation of the one-barrier job at padded width 8");
     static_assert(H == 128, "one wave per 32 x 64 strip of a 128 x 128 gradient");
     static_assert(IN_PAD % 8 == 0 && IN_PAD >= 8 && IN_PAD <= 32, "padded input width");
     using F = F32FusedGeom<H, true, true>;
@@ -1245,6 +1249,25 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         float z[RPT], o[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) { z[r] = lds_f(Z0 + (rb + r) * H + f); o[r] = b0v; }
+        if constexpr (kLean) {
+            const float4 w = lds_f4(w0_s + f * wstride);
+            const float w4 = lds_f(w0_s + f * wstride + 4);
+            float4 xv[RPT];
+            float x4[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) { xv[r] = lds_f4(X + (rb + r) * 32); x4[r] = lds_f(X + (rb + r) * 32 + 4); }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
+                o[r] = fmaf(w4, x4[r], o[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {                         // rows ascending
+                w0acc[0] = fmaf(z[r], xv[r].x, w0acc[0]); w0acc[1] = fmaf(z[r], xv[r].y, w0acc[1]);
+                w0acc[2] = fmaf(z[r], xv[r].z, w0acc[2]); w0acc[3] = fmaf(z[r], xv[r].w, w0acc[3]);
+                w0acc[4] = fmaf(z[r], x4[r], w0acc[4]);
+            }
+        } else
 #pragma unroll
         for (int k4 = 0; k4 < thin_f4; ++k4) {
             const float4 w = lds_f4(w0_s + f * wstride + 4 * k4);
@@ -1255,7 +1278,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             for (int r = 0; r < RPT; ++r) {
                 o[r] = fmaf(w.x, xv[r].x, o[r]); o[r] = fmaf(w.y, xv[r].y, o[r]); o[r] = fmaf(w.z, xv[r].z, o[r]); o[r] = fmaf(w.w, xv[r].w, o[r]);
             }
-            if constexpr (kVecRider) {
+            if constexpr (kVecRider && TG_F32DW_ABLATE != 6) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {                     // rows ascending
                     w0acc[4 * k4 + 0] = fmaf(z[r], xv[r].x, w0acc[4 * k4 + 0]); w0acc[4 * k4 + 1] = fmaf(z[r], xv[r].y, w0acc[4 * k4 + 1]);
@@ -1274,8 +1297,27 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         const uint32_t* Mm = reinterpret_cast<const uint32_t*>(sb + F::OFF_G + 512);
         const float* AT = reinterpret_cast<const float*>(sb + F::OFF_AT);
         float at[RPT];
-        float4 g4[RPT];
         uint32_t mw[RPT];
+        if constexpr (kLean) {
+            float g1[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                at[r] = lds_f(AT + (rb + r) * H + f);
+                g1[r] = lds_f(Gm + 4 * (rb + r));
+                mw[r] = lds_u(Mm + 4 * (rb + r) + m_word);
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float v = whv[0] * g1[r];
+                const float pv = ((mw[r] >> m_shift) & 1u) != 0u ? v : 0.f;
+                lds_st(Pw + (rb + r) * H + f, pv);
+                bsum += pv;
+                hacc[0] = fmaf(g1[r], at[r], hacc[0]);
+                gsum += g1[r];                                      // (threads f = 1..3 of a row group carry a copy nobody reads)
+            }
+            return;
+        }
+        float4 g4[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             at[r] = lds_f(AT + (rb + r) * H + f);
@@ -1289,10 +1331,12 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             const float pv = ((mw[r] >> m_shift) & 1u) != 0u ? v : 0.f;
             lds_st(Pw + (rb + r) * H + f, pv);
             bsum += pv;
+#if TG_F32DW_ABLATE != 6                                    /* probe build 6: 56 of the rebuild's ~165 vector instructions gone */
             hacc[0] = fmaf(g4[r].x, at[r], hacc[0]); hacc[1] = fmaf(g4[r].y, at[r], hacc[1]);
             hacc[2] = fmaf(g4[r].z, at[r], hacc[2]); hacc[3] = fmaf(g4[r].w, at[r], hacc[3]);
             const float g_lo = gc1 ? g4[r].y : g4[r].x, g_hi = gc1 ? g4[r].w : g4[r].z;
             gsum += gc2 ? g_hi : g_lo;
+#endif
         }
     };
     // ---- the first layer's rider of a stage: this wave's tile, its k-steps KS s + ks0, operands straight from the ring slot ----
@@ -1977,7 +2021,9 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         static const bool pipe = [] { const char* e = getenv("TG_F32DW_PIPE"); return !e || atoi(e) != 0; }();
         if (jobs[0].in_pad == 8 && pipe)
             shmem = 2 * (size_t)F32FusedGeom<128, true, true>::SLOT + 4 * 16 * 128 * 4 + 128 * (8 + 4) * 4;
-        const int rc = jobs[0].in_pad == 8 ? (pipe ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, false>))
+        const bool lean = jobs[0].in_dim <= 5 && jobs[0].act_dim == 1;
+        const int rc = jobs[0].in_pad == 8 ? (pipe ? (lean ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, true>))
+                                                   : launch8(mlp_f32_dw_fused8_kernel<128, 8, false>))
                      : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16, false>)
                      : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24, false>) : launch8(mlp_f32_dw_fused8_kernel<128, 32, false>);
         if (rc) return rc;
