@@ -864,9 +864,12 @@ def main():
                                 "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
                                 "total_ms_per_step": 1e3 * dur / max(timed_steps, 1),
                                 "note": {"fwd": "tg_mlp_f32_forward_backward: forward + loss head + backward-data pass of every row in one launch; "
-                                                "flops = matrix-core products only (first layer + 2 x the H x H layers; the <= 4-output head runs on the vector unit)",
-                                         "dw": "tg_mlp_f32_weight_grad: every weight / bias gradient of the net in one launch; flops = the H x H layers' "
-                                               "and the first layer's (padded to 32 columns) products; head and bias sums on the vector unit"}.get(fam)}
+                                                "flops = the algorithmic count, un-padded (2 H in + 4 (L - 1) H^2 + 4 H out per row; rounds 2-3 "
+                                                "counted the first layer padded to 8 columns and no head: +0.4 % at C2)",
+                                         "dw": "tg_mlp_f32_weight_grad: every weight / bias gradient of the net in one launch + the fixed-order slab "
+                                               "reduction launch (which also carries the optimizer step); flops = the algorithmic count, un-padded "
+                                               "(2 (L - 1) H^2 + 2 H in + 2 H out per row; rounds 2-3 counted the first layer padded to 32 columns: "
+                                               "x 1.19 at C2 -- their 0.39 is 0.33 in this convention)"}.get(fam)}
                 continue
             dur = sum(d for d, _, _, _ in ls) * 1e-3
             nbytes = sum(b for _, b, _, _ in ls)

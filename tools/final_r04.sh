@@ -17,7 +17,8 @@ done
 timeout -k 10 400 python3 bench.py --policy-dtype fp32 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/r04_bench_fp32_policy.json 2> $OUT/r04_bench_fp32_policy.err || exit 1
 echo "configs done"
 # same-box A/Bs of the round's switches on C2
-for v in "TG_NATIVE_PREPARE=0" "TG_FOLD_OLD_LOGP=0" "TG_ADAM_PUSH=0" "TG_TRUST_VERSION_KEYS=1" "TG_NATIVE_PREPARE=0 TG_FOLD_OLD_LOGP=0 TG_ADAM_PUSH=0 TG_TRUST_VERSION_KEYS=1"; do
+for v in "TG_NATIVE_PREPARE=0" "TG_FOLD_OLD_LOGP=0" "TG_ADAM_PUSH=0" "TG_TRUST_VERSION_KEYS=1" "TG_ADAM_RIDER=0" "TG_F32DW_PIPE=0" "TG_F32DW_FUSED8=0" \
+         "TG_NATIVE_PREPARE=0 TG_FOLD_OLD_LOGP=0 TG_ADAM_PUSH=0 TG_TRUST_VERSION_KEYS=1 TG_ADAM_RIDER=0 TG_F32DW_FUSED8=0"; do
   env $v timeout -k 10 200 python3 bench.py --config c2 --steps 60 --warmup 10 --no-launch-events --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('c2 [$v]', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms')"
 done | tee $OUT/r04_c2_switches_same_box.txt
 timeout -k 10 200 python3 bench.py --config c2 --steps 60 --warmup 10 --no-launch-events --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('c2 [product]', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms')" | tee -a $OUT/r04_c2_switches_same_box.txt

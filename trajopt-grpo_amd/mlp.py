@@ -533,7 +533,9 @@ class GemmMLP:
         if ev is not None:
             ev[1].record()
             # matrix-core flops per row: first layer + forward and backward products of the H x H layers (head: vector unit)
-            self.fwd_events.append((ev[0], ev[1], rows, 2 * H * f.in_pad + 4 * (nh - 1) * H * H, f"tg::mlp_f32_chain_kernel<{H},true>"))
+            # algorithmic flops per row (un-padded): forward first layer + H x H layers + head, backward head + H x H layers
+            self.fwd_events.append((ev[0], ev[1], rows, 2 * H * self.in_dim + 4 * (nh - 1) * H * H + 4 * H * self.out_dim,
+                                    f"tg::mlp_f32_chain_kernel<{H},true>"))
         grid = min(nblk, -(-rows // 256))
         self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
         assert getattr(self, "_loss_rider", None) is None, "forward_loss(sums_out=...) must be followed by backward_fused()"
@@ -590,7 +592,10 @@ class GemmMLP:
                                                      N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
         if ev is not None:
             ev[1].record()
-            self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * 32, f"tg::mlp_f32_dw_kernel<{H}>"))
+            # algorithmic flops per row (un-padded): every layer's dZ^T A
+            one_job = H == 128 and nh == 2
+            self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * self.in_dim + 2 * H * self.out_dim,
+                                   f"tg::mlp_f32_dw_fused8_kernel<{H},...> + finish" if one_job else f"tg::mlp_f32_dw_kernel<{H}> + finish"))
         self._acts = self._bits = self._dz_head = self._tmask = None
 
     @torch.no_grad()
