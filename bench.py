@@ -908,7 +908,7 @@ def main():
         if sustained is not None:
             out["sustained_matrix_rate"] = sustained
             rk = out.get("rollout_kernel")
-            if rk and rk.get("bound") == "mfma" and (args.policy_dtype == "fp32") == ("f32" in sustained["kernel"]):
+            if rk and rk.get("bound") == "mfma" and (args.policy_dtype == "fp32") == ("mfma_loop_f32" in sustained["kernel"]):
                 # the fused rollout kernel against the same ceiling (its all-alive launch: no idle lanes)
                 rk["sustained_peak"] = sustained["TFLOPs"]
                 rk["frac_of_sustained"] = rk["achieved"] / sustained["TFLOPs"]
