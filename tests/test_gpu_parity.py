@@ -2421,6 +2421,54 @@ def test_optimizer_step_riding_on_the_f32_reduction_is_bit_identical(tg, dev, hi
     assert all(float(v) == 6.0 for k, v in a.items() if k.startswith("t."))
 
 
+def test_optimizer_step_does_not_ride_when_the_optimizer_holds_more_than_the_net(tg, dev, monkeypatch):
+    """The riding step is refused -- and the separate launch taken -- when the optimizer owns a tensor the backward pass's launch
+    produces no gradient window for (it would silently miss its step): same result as with the rider switched off, and the
+    C entry point itself refuses such a table."""
+    import ctypes as C
+    import trajopt_grpo_amd.algorithms as A
+    import trajopt_grpo_amd.optim as O
+    from trajopt_grpo_amd import _native as N
+
+    def run(ride):
+        monkeypatch.setattr(A, "_ADAM_RIDER", ride)
+        torch.manual_seed(3)
+        pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
+        extra = torch.nn.Parameter(torch.full((7,), 0.25, device=dev))
+        extra.grad = torch.full((7,), 0.5, device=dev)
+        mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=40), pol, num_workers=8, num_episodes_per_worker=16, seed=5)
+        buf = tg.Rollout_Buffer(mgr)
+        opt = torch.optim.Adam(list(pol.parameters()) + [extra], lr=1e-3)
+        algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.9, policy=pol, optimizer=opt, updates_per_iter=2)
+        for _ in range(2):
+            buf.sample()
+            algo.learn(buf)
+        return [p.detach().clone() for p in pol.parameters()] + [extra.detach().clone()], algo
+
+    calls = []
+    orig = O.FusedAdam.rider
+    monkeypatch.setattr(O.FusedAdam, "rider", lambda self, *a, **k: calls.append(1) or orig(self, *a, **k))
+    (a, algo), (b, _) = run(True), run(False)
+    assert calls == []                                       # the learner never even asks: the parameter sets differ
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[-1], torch.full((7,), 0.25, device=dev))      # the extra tensor was stepped by the separate launch
+    # the C ABI's own check: a table with one tensor more than the launch has windows
+    m = algo._mlp(algo.policy.actor)
+    fa = algo._fused_adam
+    tab, n, total = fa.table(0)
+    r = N.AdamRider()
+    r.h_table, r.n_tensors, r.zero_grads, r.total = fa._host_tables[0], n, 0, total
+    r.lr, r.beta1, r.beta2, r.eps, r.step = 1e-3, 0.9, 0.999, 1e-8, 5
+    xp = m.prepare_input(torch.randn(300, 5, device=dev))
+    m.forward_loss(xp, 0, act=torch.randn(300, 1, device=dev), logp_old=torch.full((300,), -1.0, device=dev), adv=torch.randn(300, device=dev),
+                   var=torch.full((1,), 0.5), epsilon=0.2, surr_coef=-1.0 / 300)
+    before = [p.detach().clone() for p in algo.policy.parameters()]
+    with pytest.raises(RuntimeError, match="gradient windows"):
+        m.backward_fused(adam=r)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(algo.policy.parameters(), before))     # nothing was launched
+
+
 def test_ppo_with_more_than_four_actions_keeps_one_prepared_input(tg, dev):
     """An fp32 actor with > 4 outputs is outside the fp32 chain learner while its 1-output critic is inside: PPO must put both on
     the per-layer path (they share one padded input) instead of feeding one of them a wrongly padded buffer."""
