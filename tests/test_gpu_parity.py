@@ -1256,17 +1256,24 @@ def test_forced_rollout_in_one_launch_is_bit_identical_to_the_per_step_launches(
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,n,E", [(1, 1, 1), (63, 31, 31), (64, 32, 8), (65, 33, 11), (128, 100, 25), (500, 4096, 64), (256, 96, 32), (300, 4100, 4100)])
 @pytest.mark.parametrize("gamma", [0.5, 0.999])
-def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, n, E, gamma):
+@pytest.mark.parametrize("padding", ["garbage", "zeros_short"])
+def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, n, E, gamma, padding):
     """tg_returns_moments (LDS-staged strips, one lane per env on the recurrence: the form for a few thousand envs) against
     tg_rtg_scan + tg_masked_moments, which are pinned to the reference (grpo.py:66-74,110-115): same bits, ragged episode lengths,
-    strips that do not divide the horizon, env counts that do not fill a workgroup, masks with holes."""
+    strips that do not divide the horizon, env counts that do not fill a workgroup, masks with holes.  padding = zeros_short: short
+    episodes with zero rewards behind them, as a rollout writes them -- the kernel's scans then stop at each block's last live
+    step; garbage: non-zero rewards under a zero mask everywhere (every step is live)."""
     K = tg.hip_ops
     g = torch.Generator(device="cpu").manual_seed(T * 1000 + n)
-    rew = torch.randn(T, n, generator=g).to(dev)
-    lens = torch.randint(0, T + 1, (n,), generator=g)
+    rew = torch.randn(T, n, generator=g)
+    lens = torch.randint(0, (T + 1) if padding == "garbage" else max(T // 5, 1) + 1, (n,), generator=g)
     mask = (torch.arange(T).view(T, 1) < lens.view(1, n))
+    if padding == "zeros_short":
+        rew = rew * mask
+        rew[0, ::5] = -0.0 if T > 1 else rew[0, ::5]             # (a negative zero under a set mask bit is live too)
+    rew = rew.to(dev)
     if T > 2:
-        mask[T // 2, ::7] = False                                # a hole: the reference's recurrence cuts the carry there
+        mask[T // 2 if padding == "garbage" else max(T // 10, 1) - 1, ::7] = False     # a hole: the reference's recurrence cuts the carry there
     mask = mask.to(torch.uint8).to(dev)
     rtg0 = K.rtg_scan(rew, mask, gamma)
     mom0 = K.masked_moments(rtg0, mask, E)

@@ -38,6 +38,13 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
     const int64_t e0 = (int64_t)blockIdx.x * kRmEnvs;
     const int le = tid & (kRmEnvs - 1), lt0 = tid / kRmEnvs;            // env column; first row (rows 8 apart)
     const bool env_ok = e0 + le < n;
+    // The scans below are serial in time, and most of the horizon is padding once the block's longest episode has ended (CartPole at
+    // C2: ~100 of 500 steps): the loading threads find the block's last step that is not all zero bits -- beyond it reward * mask
+    // + carry is +0 and the moments add nothing, exactly what the strips already hold -- and the scans stop there.
+    __shared__ int s_last;
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    int my_last = -1;
     // ---- all waves: the block's [T][32] strips of rewards and masks into LDS (coalesced 128-B / 32-B row segments, 8 rows per
     // pass and thread group, every load of a pass in flight together) ----
     // (unconditional loads from clamped addresses: a load under a branch is issued, waited for and only then followed by the next
@@ -56,9 +63,15 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
         for (int k = 0; k < 16; ++k) {
             const int t = t0 + lt0 + 8 * k;
             if (t < T) { s_r[t * kRmEnvs + le] = env_ok ? vr[k] : 0.f; s_m[t * kRmEnvs + le] = env_ok ? vm[k] : (uint8_t)0; }
+            const bool live = env_ok && t < T && (vm[k] != 0 || __float_as_uint(vr[k]) != 0u);
+            my_last = live && t > my_last ? t : my_last;
         }
     }
+    if (my_last >= 0) atomicMax(&s_last, my_last);
     __syncthreads();
+    // steps [0, t_stop) are scanned: t_stop = the first multiple of the chunk length past the last live step (or the horizon)
+    const int t_live = s_last + 1;
+    const int t_stop = (t_live + kRmChunk - 1) / kRmChunk * kRmChunk < T ? (t_live + kRmChunk - 1) / kRmChunk * kRmChunk : T;
     if (tid < kRmEnvs) {
         // ---- one lane per env.  Backward: R = r m + carry; carry = (gamma R) m -- the reference's order (grpo.py:66-74), individually
         // rounded.  A chunk's operands are read into registers first (independent LDS reads), so the dependent chain is three
@@ -67,7 +80,7 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
         // hipcc then waits for each LDS read where it stands -- 105 cycles per step instead of a dozen.  Full chunks run unguarded,
         // the < 32 steps that remain one by one.)
         float carry = 0.0f;
-        int t_hi = T;
+        int t_hi = t_stop;
         for (; t_hi >= kRmChunk; t_hi -= kRmChunk) {
             float r[kRmChunk], m[kRmChunk];
 #pragma unroll
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
             s2 = mk ? q : s2;
         };
         int t0 = 0;
-        for (; t0 + kRmChunk <= T; t0 += kRmChunk) {
+        for (; t0 + kRmChunk <= t_stop; t0 += kRmChunk) {
             float v[kRmChunk]; uint8_t m[kRmChunk];
 #pragma unroll
             for (int k = 0; k < kRmChunk; ++k) {
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < kRmChunk; ++k) add(v[k], m[k]);
         }
-        for (; t0 < T; ++t0) add(s_r[t0 * kRmEnvs + tid], s_m[t0 * kRmEnvs + tid]);
+        for (; t0 < t_stop; ++t0) add(s_r[t0 * kRmEnvs + tid], s_m[t0 * kRmEnvs + tid]);
         if (e0 + tid < n) {
             work[e0 + tid] = cnt;
             work[n + e0 + tid] = s1;
