@@ -2050,11 +2050,12 @@ def test_fused_adam_is_bit_identical_to_torch(tg, dev, lr, betas, eps):
 
 
 @pytest.mark.parametrize("cdt,hidden", [(torch.bfloat16, (256,) * 5), (torch.bfloat16, (128,) * 3), (None, (128, 128)), (None, (64,) * 4)])
-def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden):
+def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden, monkeypatch):
     """optim.StreamRefresher (tg_gather_streams: every derived weight layout of actor and critic in one launch) leaves exactly the
     bytes FragmentStream.refresh() / F32ChainStream.refresh() build, and learn() with the fused optimizer step equals learn() with
     torch's step bit for bit."""
     from trajopt_grpo_amd import mlp as M, optim as O, algorithms as ALG
+    monkeypatch.setattr(O, "_PUSH", True)                    # (the product's default, whatever TG_ADAM_PUSH says in this process)
     torch.manual_seed(11)
     S, A = (20, 4) if cdt is not None else (5, 1)
     pol = tg.GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
@@ -2386,6 +2387,9 @@ def test_optimizer_step_riding_on_the_f32_reduction_is_bit_identical(tg, dev, hi
     layouts and the NEXT rollout's trajectory are bit-identical."""
     import trajopt_grpo_amd.algorithms as A
     import trajopt_grpo_amd.optim as O
+
+    monkeypatch.setattr(O, "_PUSH", True)                    # (the product's defaults, whatever the A/B switches say in this process)
+    monkeypatch.setattr(A, "_FUSED_ADAM", True)
 
     def run(ride):
         monkeypatch.setattr(A, "_ADAM_RIDER", ride)
