@@ -1510,8 +1510,9 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * H + n0 + col] = acc[y][r];
     }
-    float* s1 = slab + H * H + H;                                       // first-layer rider: [H][32] + [H]
-    float* s2 = s1 + H * 32 + H;                                        // head rider: [4][H] + [4]
+    constexpr int W0C = kVecRider ? IN_PAD : 32;                        // columns of the first-layer rider's part of the slab (the host lays
+    float* s1 = slab + H * H + H;                                       // the reduction out to match): [H][W0C] + [H]
+    float* s2 = s1 + H * W0C + H;                                       // head rider: [4][H] + [4]
     if (tid < H) {
         float t[6];
 #pragma unroll
@@ -1521,14 +1522,14 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             for (int g = 1; g < RG; ++g) t[q] += red[q * 512 + g * H + tid];
         }
         slab[H * H + tid] = t[0];
-        s1[H * 32 + tid] = t[1];
+        s1[H * W0C + tid] = t[1];
         if constexpr (kVecRider) {
 #pragma unroll
             for (int k = 0; k < IN_PAD; ++k) {                          // (the reduction reads in_dim <= IN_PAD columns of each 32-float row)
                 float v = tiles[tid * IN_PAD + k];
 #pragma unroll
                 for (int g = 1; g < RG; ++g) v += tiles[(g * H + tid) * IN_PAD + k];
-                s1[tid * 32 + k] = v;
+                s1[tid * W0C + k] = v;
             }
         }
 #pragma unroll
@@ -1836,6 +1837,14 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     int n_wide = 0;
     size_t shmem = H == 128 ? (size_t)F32DwGeom<128>::LDS_PLAIN : (size_t)F32DwGeom<64>::LDS_PLAIN;
     int ring_slots[kF32DwMaxJobs], fused_slab[kF32DwMaxJobs];
+    // a net whose only H x H layer carries everything (two hidden layers, H = 128): the 8-wave form of that job
+    // (TG_F32DW_FUSED8=0: the 4-wave form; TG_F32DW_PIPE=0: the 8-wave form with two barriers per stage -- for A/B runs)
+    static const bool fused8 = [] { const char* e = getenv("TG_F32DW_FUSED8"); return !e || atoi(e) != 0; }();
+    static const bool pipe = [] { const char* e = getenv("TG_F32DW_PIPE"); return !e || atoi(e) != 0; }();
+    const bool use8 = hidden == 128 && n_jobs == 1 && jobs[0].kind == F32DW_MM && jobs[0].recompute == 3 && fused8 &&
+                      jobs[0].in_pad % 8 == 0 && jobs[0].in_pad >= 8 && jobs[0].in_pad <= 32;
+    const bool use8_pipe = use8 && pipe && jobs[0].in_pad == 8;         // (its first-layer rider runs on the vector pipe: 8 slab columns, not 32)
+    const int w0cols = use8_pipe ? 8 : 32;
     for (int j = 0; j < n_jobs; ++j) {
         const tg_f32_dw_job& jb = jobs[j];
         TG_REQUIRE(jb.kind == F32DW_MM || jb.kind == F32DW_HEAD, "tg_mlp_f32_weight_grad: job %d has kind %d", j, jb.kind);
@@ -1865,7 +1874,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
                 auto fit = [&](auto geom) {
                     using F = decltype(geom);
                     ring_slots[j] = F::lds_bytes(3, jb.in_pad) <= F32DwGeom<128>::LDS_MAX ? 3 : 2;
-                    fused_slab[j] = F::SLAB;
+                    fused_slab[j] = F::SLAB - ((jb.recompute & 1) ? H * (32 - w0cols) : 0);
                     return (size_t)F::lds_bytes(ring_slots[j], jb.in_pad);
                 };
                 size_t need = 0;
@@ -1942,11 +1951,11 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         // the riders' parts of a fused job's slab: [H x H][H] | first layer [H x 32][H] | head [4 x H][4]
         int64_t roff = off + H * H + H;
         if (jb.recompute & 1) {
-            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_w0grad, jb.w0grad_ld, dj.slab_len, dj.n_blocks, 32, H, jb.in_dim, elems};
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_w0grad, jb.w0grad_ld, dj.slab_len, dj.n_blocks, w0cols, H, jb.in_dim, elems};
             elems += H * jb.in_dim;
-            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + H * 32, jb.d_b0grad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, H, elems};
+            fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + H * w0cols, jb.d_b0grad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, H, elems};
             elems += H;
-            roff += H * 32 + H;
+            roff += H * w0cols + H;
         }
         if (jb.recompute & 2) {
             fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_whgrad, jb.whgrad_ld, dj.slab_len, dj.n_blocks, H, jb.act_dim, H, elems};
@@ -2006,23 +2015,18 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     fa.n_blocks = (int32_t)ceil_div(units, 32);
     fa.loss_work = d_loss_work; fa.loss_sums = d_loss_sums; fa.n_loss_rows = n_loss_rows;
     hipStream_t st = (hipStream_t)stream;
-    // a net whose only H x H layer carries everything (two hidden layers, H = 128): the 8-wave form of that job
-    // (TG_F32DW_FUSED8=0: the 4-wave form, for A/B runs)
-    static const bool fused8 = [] { const char* e = getenv("TG_F32DW_FUSED8"); return !e || atoi(e) != 0; }();
-    if (hidden == 128 && n_jobs == 1 && jobs[0].recompute == 3 && fused8 &&
-        jobs[0].in_pad % 8 == 0 && jobs[0].in_pad >= 8 && jobs[0].in_pad <= 32) {
+    if (use8) {
         auto launch8 = [&](auto kern) -> int {
             static LdsOptIn opt_in;
             if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_weight_grad")) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), shmem, st, args.job[0], rows, (float*)d_workspace);
             return TG_OK;
         };
-        // (in_pad 8: the one-barrier form with two panel sets -- 76 KiB; TG_F32DW_PIPE=0: the two-barrier form, for A/B runs)
-        static const bool pipe = [] { const char* e = getenv("TG_F32DW_PIPE"); return !e || atoi(e) != 0; }();
-        if (jobs[0].in_pad == 8 && pipe)
+        // (in_pad 8: the one-barrier form with two panel sets -- 76 KiB)
+        if (use8_pipe)
             shmem = 2 * (size_t)F32FusedGeom<128, true, true>::SLOT + 4 * 16 * 128 * 4 + 128 * (8 + 4) * 4;
         const bool lean = jobs[0].in_dim <= 5 && jobs[0].act_dim == 1;
-        const int rc = jobs[0].in_pad == 8 ? (pipe ? (lean ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, true>))
+        const int rc = jobs[0].in_pad == 8 ? (use8_pipe ? (lean ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, true>))
                                                    : launch8(mlp_f32_dw_fused8_kernel<128, 8, false>))
                      : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16, false>)
                      : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24, false>) : launch8(mlp_f32_dw_fused8_kernel<128, 32, false>);
