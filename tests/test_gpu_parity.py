@@ -1223,9 +1223,9 @@ def test_forced_rollout_in_one_launch_is_bit_identical_to_the_per_step_launches(
         assert int(rec.len.min()) < env.max_steps, "the policy is meant to end some episodes early"
 
     def replay(per_step, split=False):
-        RO._FORCED_PER_STEP = per_step
-        try:
+        if True:
             eng = tg.DeviceRollout(env, pol, G, E, dtype=dtype, seed=11, fused=False)
+            eng.forced_per_step = per_step
             if not split:
                 tr = eng.run(initial_states=init, forced_actions=acts)
             else:                                                # two launches: [0, T/2) then [T/2, T)
@@ -1241,8 +1241,6 @@ def test_forced_rollout_in_one_launch_is_bit_identical_to_the_per_step_launches(
                 tr = eng.traj
             torch.cuda.synchronize()
             return [t.clone() for t in (tr.obs, tr.rew, tr.mask, tr.len)]
-        finally:
-            RO._FORCED_PER_STEP = False
 
     a, b, c2 = replay(True), replay(False), replay(False, split=True)
     for x, y, z, name in zip(a, b, c2, ("obs", "rew", "mask", "len")):
@@ -1254,7 +1252,8 @@ def test_forced_rollout_in_one_launch_is_bit_identical_to_the_per_step_launches(
 # --------------------------------------------------------------------------------------------
 # the learner's prologue as native launches (csrc/learn_kernels.hip)
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("T,n,E", [(1, 1, 1), (63, 31, 31), (64, 32, 8), (65, 33, 11), (128, 100, 25), (500, 4096, 64), (256, 96, 32), (300, 4100, 4100)])
+@pytest.mark.parametrize("T,n,E", [(1, 1, 1), (63, 31, 31), (64, 32, 8), (65, 33, 11), (128, 100, 25), (500, 4096, 64), (256, 96, 32), (300, 4100, 4100),
+                                   (1023, 70, 35)])     # 1023 = tg_returns_moments_max_horizon(): the whole 160 KiB of LDS
 @pytest.mark.parametrize("gamma", [0.5, 0.999])
 @pytest.mark.parametrize("padding", ["garbage", "zeros_short"])
 def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, n, E, gamma, padding):
@@ -1281,6 +1280,28 @@ def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, 
     torch.cuda.synchronize()
     assert torch.equal(rtg0, rtg1)
     assert torch.equal(mom0.view(torch.int64), mom1.view(torch.int64))       # bit for bit (NaN-safe)
+
+
+def test_returns_moments_horizon_limit(tg, dev):
+    """The advertised limit launches (the kernel's LDS is dynamic to the last byte), one step more is refused with a message --
+    and GRPO.learn() at that horizon takes tg_rtg_scan + tg_masked_moments instead of raising."""
+    K = tg.hip_ops
+    Tmax = K.returns_moments_max_horizon()
+    assert Tmax == 1023
+    rew = torch.randn(Tmax + 1, 64, device=dev)
+    mask = torch.ones(Tmax + 1, 64, dtype=torch.uint8, device=dev)
+    K.returns_moments(rew[:Tmax].contiguous(), mask[:Tmax].contiguous(), 0.9, 32)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="horizon"):
+        K.returns_moments(rew, mask, 0.9, 32)
+    torch.manual_seed(0)
+    pol = tg.GaussianActor_NeuralNetwork(5, 1, (64, 64), cov=0.5, device=dev)
+    mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=Tmax + 1), pol, num_workers=2, num_episodes_per_worker=8, seed=1)
+    buf = tg.Rollout_Buffer(mgr)
+    buf.sample()
+    algo = tg.GRPO(0.15, 0.5, 0.5, pol, torch.optim.Adam(pol.parameters(), lr=3e-4), updates_per_iter=1)
+    algo.learn(buf)
+    assert all(map(lambda v: v == v, algo.last_stats["J"]))
 
 
 @pytest.mark.parametrize("env_name,S,A,hidden,cdt,dtype", [("CartPole", 5, 1, (128, 128), None, torch.float32),
@@ -1366,11 +1387,14 @@ def test_learn_compaction_at_c3_size(tg, dev):
                                              ("ppo", None, (64, 64)), ("ppo", None, (40, 40))])
 def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, kind, cdt, hidden):
     """learn() on the native prologue (tg_returns_moments / tg_learn_count / tg_learn_compact) against the same learn() on the torch
-    prologue it replaces (TG_NATIVE_PREPARE=0): identical weights, bit for bit, after two updates."""
+    prologue that nets outside its gate take (mask.nonzero(), index_selects, prepare_input; forced here by patching the gate shut):
+    identical weights, bit for bit, after two updates."""
     from trajopt_grpo_amd import algorithms as Alg
+    gate = Alg._GpuLearner._prepare_enqueue
 
     def run(native):
-        Alg._NATIVE_PREPARE = native
+        if not native:
+            Alg._GpuLearner._prepare_enqueue = lambda self, *a, **k: None
         try:
             torch.manual_seed(11)
             cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
@@ -1390,7 +1414,7 @@ def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, ki
             torch.cuda.synchronize()
             return [p.detach().clone() for p in pol.parameters()], algo.last_stats
         finally:
-            Alg._NATIVE_PREPARE = True
+            Alg._GpuLearner._prepare_enqueue = gate
 
     (wa, sa), (wb, sb) = run(True), run(False)
     assert sa["n_valid"] == sb["n_valid"] and sa["n_valid"] < 6 * 40 * 120          # (episodes do end early: ragged rows)
@@ -1494,7 +1518,8 @@ def test_weights_written_through_data_are_seen_by_the_next_rollout_and_learn(tg,
 
 def test_folded_old_policy_pass_notices_weights_changed_behind_the_keys(tg, dev):
     """GRPO lets the first update stand in for the old policy's pass while the version keys say old_policy is the policy.  A write
-    through `.data` breaks that silently: the bitwise comparison enqueued with the fold reports it when the statistics are read."""
+    through `.data` breaks that silently: the bitwise comparison enqueued with the fold reports it at the end of that learn() (the
+    optimizer steps have been applied by then: the error says so; ADVICE r04 asked for it no later than that)."""
     torch.manual_seed(3)
     pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
     mgr = tg.RolloutManager(lambda: tg.CartPole(max_steps=40), pol, num_workers=4, num_episodes_per_worker=32, seed=2)
@@ -1506,9 +1531,9 @@ def test_folded_old_policy_pass_notices_weights_changed_behind_the_keys(tg, dev)
     algo.last_stats
     with torch.no_grad():
         pol.actor.network[0].weight.data.add_(0.25)          # behind the version counters
-    buf.sample(); algo.learn(buf)
+    buf.sample()
     with pytest.raises(RuntimeError, match="different weights"):
-        algo.last_stats
+        algo.learn(buf)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1740,11 +1765,8 @@ def test_fused_rollouts_at_baseline_sizes(tg, dev, name, hidden, G, Eps, T, cdt)
     plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt, fused=False)
     init, forced = obs[:, 0, :].t().cpu().numpy(), act.permute(2, 1, 0).cpu().numpy()
     for per_step in (True, False):              # T launches of the golden-pinned step kernel, then the one-launch form (tg_rollout_forced)
-        RO._FORCED_PER_STEP = per_step
-        try:
-            replay = plain.run(initial_states=init, forced_actions=forced)
-        finally:
-            RO._FORCED_PER_STEP = False
+        plain.forced_per_step = per_step
+        replay = plain.run(initial_states=init, forced_actions=forced)
         assert torch.equal(replay.len, ln) and torch.equal(replay.mask, mask), per_step
         assert torch.equal(replay.rew, rew) and torch.equal(replay.obs, obs), per_step
     again = tg.DeviceRollout(mk(), pol, G, Eps, seed=31, compute_dtype=cdt).run()
@@ -1883,16 +1905,13 @@ def test_backward_chain_forms_the_first_layer_gradient(tg, dev, H, layers, S, A,
         mlp = M.GemmMLP(net, torch.bfloat16)
         for p in net.parameters():
             p.grad = torch.zeros_like(p)
-        old = M._FUSE_W0
-        M._FUSE_W0 = fuse
-        try:
-            xp = mlp.prepare_input(X)
-            assert float(xp[:, 31].float().min()) == 1.0 and float(xp[:, S:31].float().abs().max()) == 0.0
-            mlp.forward(xp, keep=True)
-            mlp.backward(g)
-            torch.cuda.synchronize()
-        finally:
-            M._FUSE_W0 = old
+        xp = mlp.prepare_input(X)
+        assert float(xp[:, 31].float().min()) == 1.0 and float(xp[:, S:31].float().abs().max()) == 0.0
+        if not fuse:
+            M.set_ones_column(xp, False)       # (an input nobody vouches for: the stored form, kind HX job)
+        mlp.forward(xp, keep=True)
+        mlp.backward(g)
+        torch.cuda.synchronize()
         dz_bottom = None if fuse else mlp._ws.get(f"z{layers - 1}", rows, H, torch.bfloat16, dev).clone()
         return [p.grad.clone() for p in net.parameters()], dz_bottom, xp
 
@@ -1980,9 +1999,7 @@ def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind,
     ref = grads()
 
     mlp2 = M.GemmMLP(net, torch.bfloat16)
-    old = M._FUSE_HEAD
-    M._FUSE_HEAD = True
-    try:
+    if True:
         assert mlp2.can_fuse_head()
         for p in net.parameters():
             p.grad = torch.zeros_like(p)
@@ -1994,8 +2011,6 @@ def test_forward_chain_with_the_loss_head_inside(tg, dev, H, layers, S, A, kind,
         dz = mlp2._dz_head.clone()
         mlp2.backward_fused()
         torch.cuda.synchronize()
-    finally:
-        M._FUSE_HEAD = old
     got = grads()
     ddz = (dz.float() - dz_ref.float()).abs()
     assert float((ddz > 2.0 ** -7 * dz_ref.float().abs() + 1e-30).float().mean()) < 1e-3 and float(ddz.max()) <= 2.0 ** -6 * float(dz_ref.float().abs().max())
@@ -2055,7 +2070,6 @@ def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden, mo
     bytes FragmentStream.refresh() / F32ChainStream.refresh() build, and learn() with the fused optimizer step equals learn() with
     torch's step bit for bit."""
     from trajopt_grpo_amd import mlp as M, optim as O, algorithms as ALG
-    monkeypatch.setattr(O, "_PUSH", True)                    # (the product's default, whatever TG_ADAM_PUSH says in this process)
     torch.manual_seed(11)
     S, A = (20, 4) if cdt is not None else (5, 1)
     pol = tg.GaussianActorCritic_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
@@ -2108,15 +2122,13 @@ def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden, mo
         mgr = tg.RolloutManager(env, pol2, num_workers=4, num_episodes_per_worker=32, seed=3, compute_dtype=cdt)
         buf = tg.Rollout_Buffer(mgr)
         buf.sample()
-        old = ALG._FUSED_ADAM
-        ALG._FUSED_ADAM = fused_flag
-        try:
-            algo = tg.PPO(epsilon=0.2, policy=pol2, optimizer=torch.optim.Adam(pol2.parameters(), lr=3e-4), ref_model=None,
-                          updates_per_iter=3, gamma=0.99, batch_size=None, autocast_dtype=cdt)
-            algo.learn(buf)
-            assert bool(algo._fused_adam) == fused_flag
-        finally:
-            ALG._FUSED_ADAM = old
+        opt2 = torch.optim.Adam(pol2.parameters(), lr=3e-4)
+        if not fused_flag:
+            opt2.register_step_post_hook(lambda *a, **k: None)       # (an optimizer with hooks keeps torch's own step())
+        algo = tg.PPO(epsilon=0.2, policy=pol2, optimizer=opt2, ref_model=None,
+                      updates_per_iter=3, gamma=0.99, batch_size=None, autocast_dtype=cdt)
+        algo.learn(buf)
+        assert algo._fused_adam.usable() == fused_flag
         torch.cuda.synchronize()
         return [p.detach().clone() for p in pol2.parameters()], algo.last_stats["total_loss"]
 
@@ -2179,8 +2191,8 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monke
     eps, sc, cc, kc = 0.2, -1.0 / rows, 0.5 / rows, 0.5 / rows
 
     def run(recompute):
-        monkeypatch.setattr(M, "_F32_RECOMPUTE", recompute)
         m = M.GemmMLP(net, torch.float32)
+        m.f32_store_all = not recompute
         for i, p in enumerate(net.parameters()):
             p.grad = torch.full_like(p, 0.25 * (i + 1))                 # the kernels must ADD to what is there
         assert m.can_fuse_head()
@@ -2388,11 +2400,11 @@ def test_optimizer_step_riding_on_the_f32_reduction_is_bit_identical(tg, dev, hi
     import trajopt_grpo_amd.algorithms as A
     import trajopt_grpo_amd.optim as O
 
-    monkeypatch.setattr(O, "_PUSH", True)                    # (the product's defaults, whatever the A/B switches say in this process)
-    monkeypatch.setattr(A, "_FUSED_ADAM", True)
+    ask = A._GpuLearner._adam_rider
 
     def run(ride):
-        monkeypatch.setattr(A, "_ADAM_RIDER", ride)
+        # (the arm without the rider: the learner is never offered one -- what happens on several ranks or several chunks)
+        monkeypatch.setattr(A._GpuLearner, "_adam_rider", ask if ride else (lambda self, *a, **k: None))
         rides = []
         orig = O.FusedAdam.rider
 
@@ -2441,8 +2453,10 @@ def test_optimizer_step_does_not_ride_when_the_optimizer_holds_more_than_the_net
     import trajopt_grpo_amd.optim as O
     from trajopt_grpo_amd import _native as N
 
+    ask = A._GpuLearner._adam_rider
+
     def run(ride):
-        monkeypatch.setattr(A, "_ADAM_RIDER", ride)
+        monkeypatch.setattr(A._GpuLearner, "_adam_rider", ask if ride else (lambda self, *a, **k: None))
         torch.manual_seed(3)
         pol = tg.GaussianActor_NeuralNetwork(5, 1, (128, 128), cov=0.5, device=dev)
         extra = torch.nn.Parameter(torch.full((7,), 0.25, device=dev))

@@ -31,11 +31,9 @@ from . import optim as O
 from .rollout import DeviceTrajectory
 
 
-_NONZERO_STATIC = os.environ.get("TG_NONZERO_STATIC", "1") == "1"  # 0: torch.nonzero (a host round trip for the shape) even when the count is known
-_FUSED_ADAM = os.environ.get("TG_FUSED_ADAM", "1") == "1"          # 0: torch's own optimizer.step() (A/B runs)
-_NATIVE_PREPARE = os.environ.get("TG_NATIVE_PREPARE", "1") == "1"  # 0: the prologue as torch launches (nonzero, index_selects, pads: A/B runs)
-_FOLD_OLD_LOGP = os.environ.get("TG_FOLD_OLD_LOGP", "1") == "1"    # 0: always a no-grad pass of the old policy for the old log-probabilities (A/B runs)
-_ADAM_RIDER = os.environ.get("TG_ADAM_RIDER", "1") == "1"          # 0: the optimizer step as a launch of its own after the fp32 backward pass (A/B runs)
+# 0: always a no-grad pass of the old policy for the old log-probabilities (for callers that write weights through `.data` between
+# learn() calls and do not want the fold's bitwise check to stop them)
+_FOLD_OLD_LOGP = os.environ.get("TG_FOLD_OLD_LOGP", "1") == "1"
 _SMALL_N_RETURNS = 16384                                           # envs up to which tg_returns_moments replaces tg_rtg_scan + tg_masked_moments
 
 
@@ -147,7 +145,11 @@ class _GpuLearner(Algorithm):
                 m.refresh(force=True)
 
     def _check_deferred(self):
-        """Checks whose answers were copied to the host asynchronously during the last learn(): read here, long after they landed."""
+        """Checks whose answers are copied to the host asynchronously: the mask's own row count against the rollout's statistic, the
+        bitwise comparison behind the folded old-policy pass.  Read at the END of the learn() that enqueued them (both were written
+        before its first update ran, so the host does not wait) and again at the next entry / statistics read for a learn() that
+        raised in between.  The optimizer steps of that learn() have been applied by then: the error says the weights are suspect, it
+        does not roll them back."""
         self._check_row_count()
         pend = getattr(self, "_fold_pending", None)
         if pend is not None:
@@ -300,7 +302,7 @@ class _GpuLearner(Algorithm):
     def _optimizer_setup(self, *nets):
         """The fused optimizer step and the refresher of `nets`' derived layouts (None without a fused step), created on first use."""
         if self._fused_adam is None:
-            self._fused_adam = O.FusedAdam(self.optimizer) if _FUSED_ADAM else False
+            self._fused_adam = O.FusedAdam(self.optimizer)
             if self._fused_adam:
                 owned = {id(p) for g in self.optimizer.param_groups for p in g["params"]}
                 self._adam_covers_bucket = all(id(p) in owned for p in self.bucket.params)
@@ -320,8 +322,8 @@ class _GpuLearner(Algorithm):
         and the step: the fp32 chain learner, one rank (no all-reduce), the update's rows in ONE chunk, and an optimizer that holds
         exactly this net's parameters.  None otherwise -- the caller then all-reduces and calls _optimizer_step() as before."""
         m = self._mlp(net)
-        if not (_ADAM_RIDER and whole_update and m is not None and m._f32 is not None) or D.rank_world(self.process_group)[1] != 1:
-            return None
+        if not (whole_update and m is not None and m._f32 is not None) or D.rank_world(self.process_group)[1] != 1 or D._ALWAYS:
+            return None                     # (TG_COLLECTIVES_AT_WORLD_1=1: the gradient all-reduce is wanted even at one rank)
         refresher = self._optimizer_setup(net)
         if refresher is None or not self._adam_covers_bucket:
             return None
@@ -361,7 +363,7 @@ class _GpuLearner(Algorithm):
     def _gather_valid(self, traj):
         """Indices of valid (t, n) rows (time-major) and the gathered observations / actions."""
         flat = traj.mask.reshape(-1)
-        if traj.host_valid_rows is not None and hasattr(torch, "nonzero_static") and _NONZERO_STATIC:
+        if traj.host_valid_rows is not None and hasattr(torch, "nonzero_static"):
             # the count is on the host already (it rode on the rollout's statistics): no host-device round trip for the shape
             idx = torch.nonzero_static(flat, size=int(traj.host_valid_rows())).squeeze(1)
         else:
@@ -400,7 +402,7 @@ class _GpuLearner(Algorithm):
         return self._prepare_finish(self._prepare_enqueue(traj, m, src0, moments, norm_mode, group_size, src1))
 
     def _prepare_enqueue(self, traj, m, src0=None, moments=None, norm_mode=0, group_size=0, src1=None):
-        if m is None or not _NATIVE_PREPARE or traj.obs.dtype not in (torch.float32, torch.float64) or m.in_pad > 64 or traj.S > m.in_pad:
+        if m is None or traj.obs.dtype not in (torch.float32, torch.float64) or m.in_pad > 64 or traj.S > m.in_pad:
             return None
         if m.in_pad % (8 if m.cd == torch.bfloat16 else 4) or m.cd not in (torch.bfloat16, torch.float32):
             return None
@@ -474,7 +476,7 @@ class GRPO(_GpuLearner):
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
-        if traj.n <= _SMALL_N_RETURNS and traj.T <= K.returns_moments_max_horizon() and _NATIVE_PREPARE:   # grpo.py:66-74; per group, :110-115
+        if traj.n <= _SMALL_N_RETURNS and traj.T <= K.returns_moments_max_horizon():       # grpo.py:66-74; per group, :110-115
             rtg, moments = K.returns_moments(rew, traj.mask, self.gamma, traj.E)
         else:
             rtg = K.rtg_scan(rew, traj.mask, self.gamma)
@@ -536,9 +538,11 @@ class GRPO(_GpuLearner):
                     self._backward(actor, mean, g_mean)
                 sums += s
             if rider is not None:                                            # (one rank: no all-reduce; the step rode on the reduction)
+                self._refresh(actor)                                         # (what the rider does not write -- "w", "dx" -- is stale now)
                 continue
             self.bucket.allreduce(self.process_group)                        # one RCCL all-reduce / step
             self._optimizer_step(actor, last=last)
+        self._check_deferred()                                              # (this learn()'s own row count / fold flag: landed long ago)
         self._copy_policy_to_old()                                          # grpo.py:148
         if self.updates_per_iter > 0:
             allJ = all_sums
@@ -690,6 +694,7 @@ class PPO(_GpuLearner):
                     self._step(M.inherit_ones_column(xin.index_select(0, b), xin), act.index_select(0, b), adv.index_select(0, b),
                                ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums,
                                last=final and k == n_steps - 1)
+        self._check_deferred()                                              # (this learn()'s own row count: landed long ago)
         self._copy_policy_to_old()                                          # ppo.py:186
         if all_sums:
             S2 = torch.stack(all_sums)                                      # [steps][actor | critic][4]

@@ -27,8 +27,11 @@ namespace tg {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRmEnvs = 32;          // envs per workgroup
 constexpr int kRmChunk = 32;         // time steps a lane takes into registers at a time
+constexpr int kRmMaxHorizon = (160 * 1024 - 16) / (kRmEnvs * 5);      // 1023
 
-// LDS: R[T][32] f32 (rewards in, returns out, in place) + M[T][32] u8.  T * 160 B <= 160 KiB, i.e. T <= 1024 (the host checks).
+// LDS, all of it dynamic: R[T][32] f32 (rewards in, returns out, in place) + M[T][32] u8 + 16 B for the block's last live step.
+// T * 160 + 16 B <= 160 KiB, i.e. T <= 1023 (kRmMaxHorizon; the host checks -- a static __shared__ beside a dynamic allocation of
+// exactly 160 KiB does not launch).
 __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ mask, float gamma,
                                                               float* __restrict__ rtg, int64_t n, int32_t T, double* __restrict__ work) {
     extern __shared__ float s_dyn[];
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
     // The scans below are serial in time, and most of the horizon is padding once the block's longest episode has ended (CartPole at
     // C2: ~100 of 500 steps): the loading threads find the block's last step that is not all zero bits -- beyond it reward * mask
     // + carry is +0 and the moments add nothing, exactly what the strips already hold -- and the scans stop there.
-    __shared__ int s_last;
+    int& s_last = *reinterpret_cast<int*>(s_m + (size_t)T * kRmEnvs);        // (T * 160 B in: 16-B aligned)
     if (tid == 0) s_last = -1;
     __syncthreads();
     int my_last = -1;
@@ -328,7 +331,7 @@ using namespace tg;
 
 extern "C" {
 
-int tg_returns_moments_max_horizon(void) { return 1024; }
+int tg_returns_moments_max_horizon(void) { return kRmMaxHorizon; }
 
 int tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, float* d_rtg, int64_t n, int32_t T, int64_t group_size,
                        double* d_moments, double* d_work, void* stream) {
@@ -338,7 +341,7 @@ int tg_returns_moments(const float* d_rew, const uint8_t* d_mask, float gamma, f
     hipStream_t st = (hipStream_t)stream;
     TG_REQUIRE(T <= tg_returns_moments_max_horizon(), "tg_returns_moments: horizon %d > %d (the block's [T][32] strips live in LDS: use tg_rtg_scan + tg_masked_moments)",
                T, tg_returns_moments_max_horizon());
-    const size_t shmem = (size_t)T * kRmEnvs * 5;
+    const size_t shmem = (size_t)T * kRmEnvs * 5 + 16;
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)returns_moments_kernel, shmem, opt_in, "tg_returns_moments")) return rc;
     hipLaunchKernelGGL(returns_moments_kernel, dim3((unsigned)ceil_div(n, kRmEnvs)), dim3(256), shmem, st, d_rew, d_mask, gamma, d_rtg, n, T, d_work);

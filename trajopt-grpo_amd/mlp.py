@@ -25,18 +25,12 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
-import os
 
 import torch
 
 from . import _native as N
 
 _ROW_BLOCK = 8192
-_STORE_TOP_DZ = os.environ.get("TG_STORE_TOP_DZ", "0") == "1"
-_FUSE_W0 = os.environ.get("TG_FUSE_W0", "1") == "1"
-_FUSE_HEAD = os.environ.get("TG_FUSE_HEAD", "1") == "1"
-_F32_CHAIN = os.environ.get("TG_F32_CHAIN", "1") == "1"       # 0: fp32 nets on the per-layer GEMM path (A/B runs)
-_F32_RECOMPUTE = os.environ.get("TG_F32_RECOMPUTE", "1") == "1"   # 0: store the first activation / top dZ instead of rebuilding them (A/B runs)
 
 
 _LOG = logging.getLogger("trajopt_grpo_amd")
@@ -169,7 +163,10 @@ class GemmMLP:
         self.in_dim, self.out_dim = self.linears[0].in_features, self.linears[-1].out_features
         # fp32 nets of the reference's own shapes: the fp32 chain learner (tg_mlp_f32_forward / _forward_backward / _weight_grad)
         self._f32 = None
-        if compute_dtype == torch.float32 and _F32_CHAIN and f32_chain_supported(net):
+        # (parity tests: every hidden activation and dZ of the fp32 chain learner written to HBM, so that each can be compared with
+        # fp64; the product rebuilds the first activation and the top dZ on chip instead)
+        self.f32_store_all = False
+        if compute_dtype == torch.float32 and f32_chain_supported(net):
             self._f32 = F32ChainStream(net, f32_chain_supported(net))
         self.in_pad = _round_up(self.in_dim, 32) if self._f32 is None else self._f32.in_pad
         self.out_pad = _round_up(self.out_dim, 8)
@@ -397,7 +394,7 @@ class GemmMLP:
         backward chain active, at most 4 outputs, fp32 gradient windows."""
         if self._f32 is not None:
             return all(lin_ok(l) and l.weight.grad.stride(1) == 1 and l.bias.grad.is_contiguous() for l in self.linears)
-        return (_FUSE_HEAD and self._chain is not None and self._bchain is not None and self.cd == torch.bfloat16
+        return (self._chain is not None and self._bchain is not None and self.cd == torch.bfloat16
                 and len(self.linears) - 1 >= 3 and self.out_dim <= 4 and all(lin_ok(l) for l in self.linears)
                 and self.linears[-1].weight.grad.stride(1) == 1)
 
@@ -512,7 +509,7 @@ class GemmMLP:
         assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
         # with >= 2 hidden layers the first activation and the top layer's dZ are neither written nor read: the weight-gradient job
         # that needs them rebuilds them from the input row / from d loss / d output + the top layer's mask bits (16 B per row)
-        rec = _F32_RECOMPUTE and nh >= 2
+        rec = nh >= 2 and not self.f32_store_all
         acts = [None if (rec and i == 0) else self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
         dzs = [None if (rec and i == nh - 1) else self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
         tmask = self._ws.get("fmask", rows, 4, torch.int32, dev) if rec else None
@@ -590,6 +587,8 @@ class GemmMLP:
                                                      self._head_ws.data_ptr() if rider else None, rider[0] if rider else 0,
                                                      rider[1].data_ptr() if rider else None, C.byref(adam) if adam is not None else None,
                                                      N.stream_ptr(xp.device)), "tg_mlp_f32_weight_grad")
+        if adam is not None:
+            adam.commit()                # (the launch was accepted: now the optimizer's step counters and the layouts' marks move)
         if ev is not None:
             ev[1].record()
             # algorithmic flops per row (un-padded): every layer's dZ^T A
@@ -673,15 +672,14 @@ class GemmMLP:
         nh = L - 1                                             # hidden layers; chain order = top (i = L-2) down to i = 0
         H = self._bchain.H
         # the top layer's dZ is neither written nor read: tg_mlp_weight_grad rebuilds it from dz_head and the mask bits (kind RH)
-        # (TG_STORE_TOP_DZ=1 keeps the stored form for A/B runs)
-        store_top = _STORE_TOP_DZ
-        dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) if (j > 0 or store_top) else None for j in range(nh)]
+        dzs = [self._ws.get(f"z{j}", rows, H, self.cd, device) if j > 0 else None for j in range(nh)]
         dz_ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
         m_ptrs = (N.C.c_void_p * nh)(*[bits[L - 1 - j].data_ptr() for j in range(nh)])     # bits[i + 1] masks hidden layer i
         # the first layer's weight (and, through the ones column of the input, bias) gradient is formed inside the backward chain
-        # from the bottom dZ it holds in registers: that dZ is neither written nor read (TG_FUSE_W0=0: the stored form, kind HX)
+        # from the bottom dZ it holds in registers: that dZ is neither written nor read (an input without the ones column -- padded by
+        # the caller, not by prepare_input() / tg_learn_compact -- takes the stored form, kind HX)
         xin = acts[0]
-        fuse0 = (_FUSE_W0 and xin is not None and xin.shape[1] == 32 and self.in_dim < 32 and lin_ok(self.linears[0])
+        fuse0 = (xin is not None and xin.shape[1] == 32 and self.in_dim < 32 and lin_ok(self.linears[0])
                  and self._has_ones_column(xin))
         if fuse0:
             dzs[nh - 1] = None
@@ -702,7 +700,7 @@ class GemmMLP:
                                               None, N.stream_ptr(device)), "tg_mlp_backward_chain")
         if ev is not None:
             ev[1].record()
-            n_stored = nh - (0 if store_top else 1) - (1 if fuse0 else 0)
+            n_stored = nh - 1 - (1 if fuse0 else 0)
             self.dx_events.append((ev[0], ev[1], rows, 16 + nh * (H // 8) + n_stored * 2 * H + (64 if fuse0 else 0),
                                    f"tg::mlp_bwd_chain_kernel<{H},8,{'true' if fuse0 else 'false'}>"))
         riders, loss_rider = getattr(self, "_riders", None) or ([], None)
@@ -719,7 +717,7 @@ class GemmMLP:
         jobs = [(N.TG_DW_DH, dz_head, acts[L - 1], lin[L - 1].weight.grad, None)] if acts[L - 1] is not None else []
         for j in range(nh - 1):
             i = L - 2 - j                                                                      # hidden-to-hidden layer i
-            if j == 0 and not store_top:                                                       # top layer: dZ not stored
+            if j == 0:                                                                         # top layer: dZ not stored
                 assert acts[i] is not None
                 jobs.append((N.TG_DW_RH, dz_head, acts[i], lin[i].weight.grad, lin[i].bias.grad, bits[L - 1]))
             elif acts[i] is None:                                                              # i == 1: input not stored

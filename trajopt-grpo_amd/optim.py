@@ -12,14 +12,9 @@ weight decay, ...) keeps torch's own `optimizer.step()` and the per-stream refre
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import _native as N
-
-
-_PUSH = os.environ.get("TG_ADAM_PUSH", "1") == "1"        # 0: optimizer step and layout gather as two launches (A/B runs)
 
 
 class FusedAdam:
@@ -107,10 +102,12 @@ class FusedAdam:
     def rider(self, zero_grads: bool, refresher: "StreamRefresher") -> "N.AdamRider | None":
         """This optimizer step as a RIDER of the fp32 learner's gradient-reduction launch (tg_mlp_f32_weight_grad_adam: the thread that
         completes a gradient element steps its parameter and writes the derived layouts) -- no launch of its own.  Returns the
-        filled struct, having done step()'s host-side bookkeeping (step counters, freshness marks): the caller passes it to the launch
-        that follows immediately.  None when this form does not apply (more than one parameter group, layouts not yet gathered
-        once, anything step() itself would refuse): the caller then calls step() after its backward pass as before."""
-        if len(self.opt.param_groups) != 1 or refresher is None or not _PUSH or not self.usable():
+        filled struct; NOTHING on the host has changed yet: the caller passes it to the launch that follows immediately and, once that
+        launch has been accepted, calls `r.commit()` -- step()'s host-side bookkeeping (step counters, freshness marks).  A launch
+        that is refused leaves the optimizer where it was.  None when this form does not apply (more than one parameter
+        group, layouts not yet gathered once, anything step() itself would refuse): the caller then calls step() after its backward
+        pass as before."""
+        if len(self.opt.param_groups) != 1 or refresher is None or not self.usable():
             return None
         self._init_state()
         if not self._steps_uniform():
@@ -120,20 +117,23 @@ class FusedAdam:
         if push is None:
             return None
         g = self.opt.param_groups[0]
-        for p in g["params"]:
-            self.opt.state[p]["step"] += 1
         tab, n, total = self._tables[0]
         seg, n_seg, inv_start, inv_dst = push
         r = N.AdamRider()
         r.h_table, r.n_tensors, r.zero_grads, r.total = self._host_tables[0], n, 1 if zero_grads else 0, total
         r.lr, r.beta1, r.beta2, r.eps = g["lr"], g["betas"][0], g["betas"][1], g["eps"]
-        r.step = int(self.opt.state[g["params"][0]]["step"])
+        r.step = int(self.opt.state[g["params"][0]]["step"]) + 1
         r.d_segments, r.n_segments, r.d_inv_start, r.d_inv_dst = seg.data_ptr(), n_seg, inv_start.data_ptr(), inv_dst.data_ptr()
         r._keep = (self._host_tables[0], seg, inv_start, inv_dst)
-        N.RAW_PARAM_WRITES[0] += 1
-        self.grads_zeroed = bool(zero_grads)
-        refresher.mark_all()
-        self.pushed = True
+
+        def commit():
+            for p in g["params"]:
+                self.opt.state[p]["step"] += 1
+            N.RAW_PARAM_WRITES[0] += 1
+            self.grads_zeroed = bool(zero_grads)
+            refresher.mark_all()
+            self.pushed = True
+        r.commit = commit
         return r
 
     @torch.no_grad()
@@ -153,7 +153,7 @@ class FusedAdam:
             return False
         self._build()
         lib = N.load()
-        push = refresher.push_tables() if (refresher is not None and _PUSH) else None
+        push = refresher.push_tables() if refresher is not None else None
         for gi, ((tab, n, total), g) in enumerate(zip(self._tables, self.opt.param_groups)):
             for p in g["params"]:
                 self.opt.state[p]["step"] += 1

@@ -26,10 +26,6 @@ from . import distributed as D
 from . import mlp as M
 
 
-import os as _os
-_FORCED_PER_STEP = _os.environ.get("TG_FORCED_PER_STEP", "0") == "1"     # 1: teacher-forced replays as T launches of tg_rollout_step (A/B, tests)
-
-
 class DeviceTrajectory:
     """The tensors of one rollout, on the device, plus views the learner consumes."""
 
@@ -158,11 +154,16 @@ class DeviceRollout:
         # set by a learner whose fused optimizer step keeps this engine's weight stream current: callable -> True when it has just
         # rebuilt the stream (one gather launch covering every layout of the policy); run() calls it at every entry
         self.entry_refresh = None
+        # True: a teacher-forced replay runs as T launches of the golden-pinned tg_rollout_step instead of one tg_rollout_forced
+        # launch (the parity tests replay both ways and compare bits)
+        self.forced_per_step = False
 
     # ---- policy mean for time step t -------------------------------------------------
-    def _refresh_weights(self):
+    def _refresh_weights(self, entry: bool = False):
+        """entry: called at a rollout's entry -- whoever wrote the weights since the last rollout may have done so through `.data`,
+        which moves no version key: every derived layout counts as stale (TG_TRUST_VERSION_KEYS=1: the keys decide)."""
         if self._mlp is not None:
-            self._mlp.refresh()
+            self._mlp.refresh(force=entry and not N.TRUST_KEYS)
         if self._lowp is not None:
             for (w, b), lin in zip(self._lowp, self._linears):
                 w.copy_(lin.weight)
@@ -225,7 +226,7 @@ class DeviceRollout:
                     self._enqueue_steps(sample=False)
                 else:
                     self._enqueue_prepare(initial_states)
-                    self._enqueue_steps(sample=True)
+                    self._enqueue_steps(sample=True, entry=True)
         self._stream_host += 1
         return self.traj
 
@@ -276,12 +277,12 @@ class DeviceRollout:
                 "tg_rollout_finish_stats")
         self.traj.stats_fresh = True
 
-    def _enqueue_steps(self, sample: bool):
+    def _enqueue_steps(self, sample: bool, entry: bool = False):
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
         p = C.byref(self.params)
         if sample:
-            self._refresh_weights()
-        elif not _FORCED_PER_STEP:
+            self._refresh_weights(entry)
+        elif not self.forced_per_step:
             # teacher-forced replay: every time step in ONE launch, the state in registers between steps (tg_rollout_forced;
             # bit-identical to T launches of tg_rollout_step)
             ev = None
