@@ -6,6 +6,7 @@ fp32 returns within 1e-5 (the north-star bar)."""
 import ctypes as C
 
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -1534,6 +1535,33 @@ def test_folded_old_policy_pass_notices_weights_changed_behind_the_keys(tg, dev)
     buf.sample()
     with pytest.raises(RuntimeError, match="different weights"):
         algo.learn(buf)
+
+
+def test_env_dynamics_members_match_the_reference(tg, dev):
+    """`Env._dynamics(state, control)` / `_propegate*` as callable members (environments/cartpole_env.py:52-100,
+    quadrotor_env.py:417-528, :578-585, :1024-1130; the reference's tests/test_cartpole.py:36-40 calls `env._dynamics`): one f64
+    tg_env_step on temporaries, against inputs / outputs read off the imported reference (oracle/tools/gen_members.py)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_public_members.json")) as f:
+        calls = json.load(f)["calls"]
+    for name in ("CartPole", "QuadPole", "QuadPole2D"):
+        env = getattr(tg, name)(device=dev)
+        env.reset()
+        before = env._get_obs().copy()
+        for c in calls[name]:
+            st, u, want = np.array(c["state"]), np.array(c["wrapped"], dtype=np.float32), np.array(c["next"])
+            got = env._dynamics(st, u)
+            assert isinstance(got, np.ndarray) and got.shape == want.shape
+            np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13, err_msg=name)
+        assert np.array_equal(env._get_obs(), before), "_dynamics must not move the env"
+        # the propagate helper = state_dict <- _dynamics(own state, control)
+        u = env._wrap_action(np.zeros(env.act_dim, dtype=np.float32) + np.float32(0.25))
+        want = env._dynamics(before, u)
+        {"CartPole": lambda: env._propegate_cartpole(env.state_dict["cartpole"], u), "QuadPole": lambda: env._propegate(u),
+         "QuadPole2D": lambda: env._propogate(u)}[name]()
+        np.testing.assert_array_equal(env._get_obs(), want)
+    env = tg.CartPole(device=dev)
+    assert env._dynamics(np.array([0, 0, 0, 1, 0]), 0.0).shape == (5,)         # (a scalar control, as the reference's own test passes it)
 
 
 # --------------------------------------------------------------------------------------------

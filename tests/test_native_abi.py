@@ -282,3 +282,48 @@ def test_register_stream_f32_layout_follows_the_lds_exchange_order():
     old = st[1, K1 // 2 + 64 + 5, 7].item()
     rs.refresh()
     assert rs.stream.view(4, R, 64)[1, K1 // 2 + 64 + 5, 7].item() == 2.0 * old
+
+
+def test_every_public_member_of_the_reference_classes_exists_on_the_drop_in():
+    """tests/golden/reference_public_members.json (oracle/tools/gen_members.py: the member NAMES of the reference's classes, read off the
+    imported reference) against the drop-in: each name is there (`QuadPole2D.out_of_bounds`, `Env._dynamics`,
+    `_wrap_action`, `Buffer.visualize`, ... were missing)."""
+    import json
+    from trajopt_grpo_amd import algorithms, buffers, environments, pipelines, policies
+    with open(os.path.join(REPO, "tests", "golden", "reference_public_members.json")) as f:
+        ref = json.load(f)
+    missing = {}
+    for cls_name, names in ref["classes"].items():
+        cls = next((getattr(m, cls_name) for m in (tg, environments, policies, buffers, algorithms, pipelines) if hasattr(m, cls_name)), None)
+        assert cls is not None, f"class {cls_name} has no drop-in"
+        gone = [n for n in names if not hasattr(cls, n)]
+        if gone:
+            missing[cls_name] = gone
+    assert not missing, missing
+
+
+def test_wrap_action_is_the_reference_line_and_has_an_exact_inverse():
+    """`_wrap_action` (cartpole_env.py:48-49, quadrotor_env.py:409-413, :928) reproduces the reference's float32 controls bit for bit
+    (host arithmetic, no GPU), and `_unwrap_control` -- what lets `_dynamics(state, control)` run on tg_env_step -- finds an action
+    that wraps to exactly that control."""
+    import json
+    with open(os.path.join(REPO, "tests", "golden", "reference_public_members.json")) as f:
+        calls = json.load(f)["calls"]
+    for name in ("CartPole", "QuadPole", "QuadPole2D"):
+        env = getattr(tg, name)()
+        for c in calls[name]:
+            a = np.array(c["action"], dtype=np.float32)
+            u = env._wrap_action(a)
+            assert str(np.asarray(u).dtype) == c["wrapped_dtype"]
+            assert np.array_equal(np.asarray(u, dtype=np.float64), np.array(c["wrapped"]))
+            back = env._unwrap_control(u)
+            assert back.dtype == np.float32 and np.array_equal(np.asarray(env._wrap_action(back), dtype=np.float64), np.array(c["wrapped"]))
+    # the predicates read state_dict on the host, like the reference's
+    e3, e2 = tg.QuadPole(), tg.QuadPole2D()
+    for c in calls["out_of_bounds"]:
+        e3.state_dict["quadrotor"] = np.array(list(c["pos"]) + [0.0] * 10)
+        e2.state_dict["quadrotor"] = np.array([c["pos"][0], c["pos"][2]] + [0.0] * 6)
+        assert e3._out_of_bounds() is c["QuadPole"] and e2.out_of_bounds() is c["QuadPole2D"], c
+    with pytest.raises(AttributeError, match="env"):
+        tg.Quadrotor.__new__(tg.Quadrotor).reset()
+    assert tg.buffers.Buffer().visualize() is None

@@ -44,8 +44,6 @@ def main():
         xp = mlp.prepare_input(torch.randn(rows, 20, device=dev))
         out = {"rows": rows}
         if a.fused_head:
-            from trajopt_grpo_amd import mlp as M
-            M._FUSE_HEAD = True
             for p in net.parameters():
                 p.grad = torch.zeros_like(p)
             act = torch.randn(rows, 4, device=dev)

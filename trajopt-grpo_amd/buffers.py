@@ -24,6 +24,9 @@ class Buffer:
     def __init__(self):
         pass
 
+    def visualize(self):                 # buffers/buffer.py:7-9: an abstract no-op
+        pass
+
 
 class Rollout_Buffer(Buffer):
     _REF_FIELDS = ("group_observations", "group_actions", "group_rewards", "group_lengths", "group_masks")

@@ -361,8 +361,7 @@ __global__ __launch_bounds__(256) void quadrotor12_kernel(const R* __restrict__ 
 // ---------------------------------------------------------------------------
 static inline dim3 env_grid(int64_t n, int& block) {
     // small launches are latency-bound: one wave per workgroup spreads them over all CUs
-    static const int forced = [] { const char* e = getenv("TG_STEP_BLOCK"); return e ? atoi(e) : 0; }();
-    block = forced > 0 ? forced : ((n <= (int64_t)1 << 18) ? 64 : 256);
+    block = (n <= (int64_t)1 << 18) ? 64 : 256;
     return dim3((unsigned)ceil_div(n, block));
 }
 

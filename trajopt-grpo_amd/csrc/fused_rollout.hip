@@ -372,13 +372,11 @@ int tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_wf
     const int n_hh = n_hidden_layers - 1;
     hipStream_t st = (hipStream_t)stream;
     // variant: 0 = NT 1 x 8 waves (default), 1 = NT 1 x 4 waves (two workgroups per CU; default below 32,768 envs, where
-    // it gives twice as many workgroups), 2 = NT 2 x 4 waves.  TG_FUSED_VARIANT overrides.
-    static const int var_env = [] { const char* e = getenv("TG_FUSED_VARIANT"); return e ? atoi(e) : -1; }();
-    const int variant = (var_env >= 0 && var_env <= 2) ? var_env : (tr->n < 32768 ? 1 : 0);
+    // it gives twice as many workgroups).  (NT 2 x 4 waves was measured slower at every size, DESIGN_HISTORY: not instantiated.)
+    const int variant = tr->n < 32768 ? 1 : 0;
 #define CALL(E, HH)                                                                                                       \
-    (variant == 0   ? fused_launch<E, HH, 1, 8>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st) \
-     : variant == 1 ? fused_launch<E, HH, 1, 4>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st) \
-                    : fused_launch<E, HH, 2, 4>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st))
+    (variant == 0 ? fused_launch<E, HH, 1, 8>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st) \
+                  : fused_launch<E, HH, 1, 4>(p, tr, d_wfrag, d_bias, n_hh, sigma, d_rng, env_offset, t_begin, t_end, st))
     switch (p->env_id * 1000 + hidden) {
         case TG_ENV_CARTPOLE * 1000 + 128: return CALL(CartPoleEnv, 128);
         case TG_ENV_CARTPOLE * 1000 + 256: return CALL(CartPoleEnv, 256);

@@ -611,14 +611,8 @@ static int dw_cus() { return device_cus(); }
 
 // Relative cost of a row of each job kind = its bytes, times a per-kind factor for the kinds that are not purely
 // byte-bound (HR recomputes a tile per stage).  The workgroups are split between the jobs in proportion to it.
-// TG_DW_COST="hh,hx,dh,hr,rh" (percent of the byte count) overrides the factors: a tuning knob, read once.
 static int64_t dw_row_cost(int H, int kind) {
-    static int pct[5] = {0, 0, 0, 0, 0};
-    if (pct[0] == 0) {
-        int v[5] = {100, 100, 100, 260, 300};   // HR / RH: measured optimum (tools/dw_probe.py, 2^22 rows, the learner's job set)
-        if (const char* e = getenv("TG_DW_COST")) (void)sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
-        for (int k = 0; k < 5; ++k) pct[k] = v[k] > 0 ? v[k] : 100;
-    }
+    static const int pct[5] = {100, 100, 100, 260, 300};   // HR / RH: measured optimum (tools/dw_probe.py, 2^22 rows, the learner's job set)
     int64_t bytes;
     switch (kind) {
         case DW_HH: bytes = 4 * H; break;

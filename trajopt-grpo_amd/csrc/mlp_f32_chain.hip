@@ -436,8 +436,7 @@ static int launch_f32_chain(const F32ChainArgs& args_in, hipStream_t st) {
     auto kern = mlp_f32_chain_kernel<H, kTrain>;
     F32ChainArgs args = args_in;
     const int n_stream = args.net.n_hh * (H / 32) * (kTrain ? 2 : 1);
-    static const bool no_resident = getenv("TG_F32_NO_RESIDENT") != nullptr;             // A/B runs
-    args.resident = !no_resident && n_stream > 0 && f32_chain_lds<H>(args.net.n_hh, args.net.k2, n_stream) <= 160 * 1024;
+    args.resident = n_stream > 0 && f32_chain_lds<H>(args.net.n_hh, args.net.k2, n_stream) <= 160 * 1024;
     const size_t shmem = f32_chain_lds<H>(args.net.n_hh, args.net.k2, args.resident ? n_stream : 2);
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32_forward")) return rc;
@@ -1689,10 +1688,7 @@ __global__ __launch_bounds__(256) void mlp_f32_dw_finish_kernel(F32FinishArgs fa
     }
 }
 
-static int f32_dw_max_blocks() {
-    static const int forced = [] { const char* e = getenv("TG_F32DW_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning knob (<= 2 per CU)
-    return forced > 0 && forced <= 2 * device_cus() ? forced : 2 * device_cus();
-}
+static int f32_dw_max_blocks() { return 2 * device_cus(); }
 static int f32_dw_slab_len(int H, int kind, int n) { return kind == F32DW_HEAD ? 4 * H + 4 : (n <= 32 ? H * 32 + H : H * H + H); }
 
 }  // namespace tg
@@ -1838,12 +1834,10 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     size_t shmem = H == 128 ? (size_t)F32DwGeom<128>::LDS_PLAIN : (size_t)F32DwGeom<64>::LDS_PLAIN;
     int ring_slots[kF32DwMaxJobs], fused_slab[kF32DwMaxJobs];
     // a net whose only H x H layer carries everything (two hidden layers, H = 128): the 8-wave form of that job
-    // (TG_F32DW_FUSED8=0: the 4-wave form; TG_F32DW_PIPE=0: the 8-wave form with two barriers per stage -- for A/B runs)
-    static const bool fused8 = [] { const char* e = getenv("TG_F32DW_FUSED8"); return !e || atoi(e) != 0; }();
-    static const bool pipe = [] { const char* e = getenv("TG_F32DW_PIPE"); return !e || atoi(e) != 0; }();
-    const bool use8 = hidden == 128 && n_jobs == 1 && jobs[0].kind == F32DW_MM && jobs[0].recompute == 3 && fused8 &&
+    // (padded input width 8: one barrier per stage; wider inputs: two)
+    const bool use8 = hidden == 128 && n_jobs == 1 && jobs[0].kind == F32DW_MM && jobs[0].recompute == 3 &&
                       jobs[0].in_pad % 8 == 0 && jobs[0].in_pad >= 8 && jobs[0].in_pad <= 32;
-    const bool use8_pipe = use8 && pipe && jobs[0].in_pad == 8;         // (its first-layer rider runs on the vector pipe: 8 slab columns, not 32)
+    const bool use8_pipe = use8 && jobs[0].in_pad == 8;         // (its first-layer rider runs on the vector pipe: 8 slab columns, not 32)
     const int w0cols = use8_pipe ? 8 : 32;
     for (int j = 0; j < n_jobs; ++j) {
         const tg_f32_dw_job& jb = jobs[j];
@@ -1889,12 +1883,10 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     const int max_blocks = f32_dw_max_blocks();
     // share of the slots that goes to the wide jobs: in proportion to estimated time per row -- a wide job's products at ~70 % of
     // the fp32 matrix rate of one workgroup per CU against a light job's bytes at the ~12 GB/s one workgroup streams
-    // (TG_F32DW_WIDE_PCT overrides: a tuning knob, read once)
-    static const int forced_pct = [] { const char* e = getenv("TG_F32DW_WIDE_PCT"); return e ? atoi(e) : 0; }();
     const double t_wide = wide_sum * (H == 128 ? 0.085 : 0.085 / 4), t_light = (double)light_sum / 12000.0;
     int wide_slots = 0;
     if (n_wide) {
-        const double share = forced_pct > 0 ? forced_pct / 100.0 : t_wide / (t_wide + t_light);
+        const double share = t_wide / (t_wide + t_light);
         wide_slots = n_wide < n_jobs ? (int)(share * max_blocks + 0.5) : max_blocks;
         if (wide_slots < n_wide) wide_slots = n_wide;
         if (wide_slots > max_blocks - (n_jobs - n_wide)) wide_slots = max_blocks - (n_jobs - n_wide);
@@ -2026,8 +2018,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         if (use8_pipe)
             shmem = 2 * (size_t)F32FusedGeom<128, true, true>::SLOT + 4 * 16 * 128 * 4 + 128 * (8 + 4) * 4;
         const bool lean = jobs[0].in_dim <= 5 && jobs[0].act_dim == 1;
-        const int rc = jobs[0].in_pad == 8 ? (use8_pipe ? (lean ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, true>))
-                                                   : launch8(mlp_f32_dw_fused8_kernel<128, 8, false>))
+        const int rc = jobs[0].in_pad == 8 ? (lean ? launch8(mlp_f32_dw_fused8_kernel<128, 8, true, true>) : launch8(mlp_f32_dw_fused8_kernel<128, 8, true>))
                      : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16, false>)
                      : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24, false>) : launch8(mlp_f32_dw_fused8_kernel<128, 32, false>);
         if (rc) return rc;

@@ -106,6 +106,74 @@ class Env:
     def _get_info(self):
         return {"time_balanced": self._time_balanced}
 
+    def _get_obs(self):
+        """The observation = the full state, as the reference's `_get_obs` (cartpole_env.py:130-131, quadrotor_env.py:600-604)."""
+        return np.hstack([np.asarray(self.state_dict[k]).ravel() for k, _ in self._state_split])[:self.obs_dim]
+
+    # -- the reference's per-step helpers as callable members (environments/cartpole_env.py:48-100, quadrotor_env.py:409-417,
+    #    :578-585, :928, :1024-1042; tests/test_cartpole.py:36-40 calls `env._dynamics`) ---------------------------------------
+    _WRAP = None           # (offset attribute or None, scale attribute or constant): u = offset + scale * clip(a, -1, 1)
+
+    def _wrap_scalars(self):
+        off, scale = self._WRAP
+        return (getattr(self, off) if isinstance(off, str) else off), (getattr(self, scale) if isinstance(scale, str) else scale)
+
+    def _wrap_action(self, action):
+        """The control the dynamics receive: float32 in, float32 out under NumPy's weak-scalar promotion, like the reference's line."""
+        off, scale = self._wrap_scalars()
+        u = scale * np.clip(action, -1, 1)
+        return u if off is None else off + u
+
+    def _unwrap_control(self, control) -> np.ndarray:
+        """A float32 action `a` with `_wrap_action(a) == control` bit for bit when `control` is a value the wrap can produce (every
+        control step() ever passes on), else the nearest one (<= 1 float32 ulp off, and clipped to the wrap's range)."""
+        off, scale = self._wrap_scalars()
+        u = np.asarray(np.atleast_1d(control), dtype=np.float32).reshape(self.act_dim)
+        t = u if off is None else u - np.float32(off)
+        a = np.clip((t.astype(np.float64) / float(np.float32(scale))).astype(np.float32), -1, 1).astype(np.float32)
+        for k in range(a.size):                                  # a few float32 neighbours: the two roundings of the wrap
+            best, cand = None, a[k]
+            lo = hi = cand
+            cands = [cand]
+            for _ in range(4):
+                lo, hi = np.nextafter(lo, np.float32(-2)), np.nextafter(hi, np.float32(2))
+                cands += [lo, hi]
+            for c in cands:
+                c = np.float32(min(max(c, np.float32(-1)), np.float32(1)))
+                w = np.asarray(self._wrap_action(np.array([c], dtype=np.float32)), dtype=np.float32)[0]
+                err = abs(float(w) - float(u[k]))
+                if best is None or err < best[0]:
+                    best = (err, c)
+                if err == 0.0:
+                    break
+            a[k] = best[1]
+        return a
+
+    def _dynamics(self, state, control):
+        """next state = f(state, wrapped control): the reference's pure one-step map (cartpole_env.py:52-92, quadrotor_env.py:417-528,
+        :1044-1130), evaluated by one tg_env_step on temporaries in this env's dtype (float64 by default); the env's own state does
+        not move.  `control` is what `_wrap_action` returns (a scalar is taken as a 1-vector)."""
+        a = self._unwrap_control(control)
+        S = self.obs_dim
+        st = torch.as_tensor(np.asarray(state, dtype=np.float64).reshape(S, 1)).to(self._dtype).to(self._device)
+        act = torch.as_tensor(a.reshape(self.act_dim, 1)).to(self._device)
+        steps = torch.zeros(1, dtype=torch.int32, device=self._device)
+        tb, rew = torch.zeros(1, dtype=self._dtype, device=self._device), torch.zeros(1, dtype=self._dtype, device=self._device)
+        trunc = torch.zeros(1, dtype=torch.uint8, device=self._device)
+        p = self.native_params()
+        with torch.cuda.device(self._device):
+            N.check(N.load().tg_env_step(C.byref(p), N.dtype_code(self._dtype), st.data_ptr(), 1, act.data_ptr(), 1, st.data_ptr(), 1,
+                                         steps.data_ptr(), tb.data_ptr(), rew.data_ptr(), trunc.data_ptr(), 1,
+                                         N.stream_ptr(self._device)), "tg_env_step")
+        return st[:, 0].double().cpu().numpy()
+
+    def _propagate_state(self, control):
+        """state_dict <- _dynamics(state, control): the reference's `_propegate*` helpers (no reward, no step counting)."""
+        nxt = self._dynamics(self._get_obs(), control)
+        self._alloc()
+        self._state.copy_(torch.as_tensor(nxt, dtype=self._dtype).reshape(-1, 1))
+        self._sync_state_dict()
+
     def reset(self):
         self._alloc()
         p = self.native_params()
@@ -190,6 +258,11 @@ class CartPole(Env):
     def _fill_params(self, p):
         p.p[0], p.p[1], p.p[2], p.p[3] = self.masscart, self.masspole, self.length, self.gravity
 
+    _WRAP = (None, 5)                                                          # cartpole_env.py:48-49
+
+    def _propegate_cartpole(self, state, control):                             # cartpole_env.py:94-100 (`state` is the env's own)
+        self._propagate_state(control)
+
 
 class Pendulum(Env):
     """Torque-driven pendulum, upright at theta = pi.  environments/pendulum_env.py:7-158.
@@ -213,6 +286,11 @@ class Pendulum(Env):
 
     def _fill_params(self, p):
         p.p[0], p.p[1], p.p[2], p.p[3] = self.mass, self.length, self.gravity, 1.0 if self.swingup else 0.0
+
+    _WRAP = (None, 1)                                                          # pendulum_env.py:45-46
+
+    def _propegate_pendulum(self, state, control):                             # pendulum_env.py:77-83
+        self._propagate_state(control)
 
     def step(self, action):
         reward, truncated = self._native_step(action)
@@ -245,6 +323,16 @@ class QuadPole2D(Env):
         for i, v in enumerate((self.mq, self.mp, self.I, self.Lq, self.Lp, self.gravity, b[0][1], self.balance_radius)):
             p.p[i] = v
 
+    _WRAP = ("hover_force", "hover_force")                                     # quadrotor_env.py:928
+
+    def out_of_bounds(self):
+        """quadrotor_env.py:1009-1022: x or z outside the bounds (reads `state_dict`, like the reference)."""
+        x, z = self.state_dict["quadrotor"][0:2]
+        return bool(x < self._xbounds[0] or x > self._xbounds[1] or z < self._zbounds[0] or z > self._zbounds[1])
+
+    def _propogate(self, action):                                              # quadrotor_env.py:1024-1042 (sic)
+        self._propagate_state(action)
+
 
 class QuadPole(Env):
     """3-D quadrotor (quaternion attitude) + tethered payload.  environments/quadrotor_env.py:353-713."""
@@ -274,6 +362,17 @@ class QuadPole(Env):
         for i, v in enumerate((self.mass, self.load_mass, self.gravity, self.tether_length, self.Ixx, self.Iyy,
                                self.Izz, self.torque_constant, self.arm_length, hi)):
             p.p[i] = v
+
+    _WRAP = ("hover_force", "hover_force")                                     # quadrotor_env.py:409-413
+
+    def _out_of_bounds(self):
+        """quadrotor_env.py:613-622: any position coordinate outside its bounds (reads `state_dict`, like the reference)."""
+        x, y, z = self.state_dict["quadrotor"][0:3]
+        return bool(x < self._xbounds[0] or x > self._xbounds[1] or y < self._ybounds[0] or y > self._ybounds[1]
+                    or z < self._zbounds[0] or z > self._zbounds[1])
+
+    def _propegate(self, action):                                              # quadrotor_env.py:578-585
+        self._propagate_state(action)
 
 
 class QuadPoleSwarm(QuadPole):
@@ -325,6 +424,35 @@ class Quadrotor:
                                                  o_d.data_ptr(), n, n, N.stream_ptr(self._device)), "tg_quadrotor12_dynamics")
         out = o_d.cpu().numpy().T
         return out[0] if np.ndim(state) == 1 else out
+
+    # The rest of the reference's class is scaffolding (quadrotor_env.py:68-111, :172-182): `_pack_state` / `_unpack_state` /
+    # `_spawn_obstacles` / `_spawn_goal` do nothing, `_spwan_quadrotor` (sic) draws a position, and reset / restart / step / render
+    # forward to a `self.env` that is never set (AttributeError there, and here).
+    spatial_bounds = ((-5, 5), (-5, 5), (-5, 5))
+
+    def _pack_state(self):
+        return None
+
+    def _unpack_state(self, state):
+        pass
+
+    def _spwan_quadrotor(self):
+        b = self.spatial_bounds
+        self.quadrotor = np.array([np.random.uniform(b[0][0], b[0][1]), np.random.uniform(b[1][0], b[1][1]),
+                                   np.random.uniform(b[2][0], b[2][1]), 0, 0, 0, 0, 0, 0, 0, 0, 0])
+        return self.quadrotor
+
+    def _spawn_obstacles(self):
+        pass
+
+    def _spawn_goal(self):
+        pass
+
+    def _no_env(self, *a, **k):
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute 'env' (the reference's Quadrotor forwards reset / restart / "
+                             "step / render to a member it never sets: quadrotor_env.py:172-182; only `_dynamics` is usable)")
+
+    reset = restart = step = render = _no_env
 
 
 class QuadrotorSwarm(Quadrotor):
