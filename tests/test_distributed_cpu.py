@@ -36,10 +36,10 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
-        G, E, T, S, A = 4, 3, 12, 5, 2
+        G, E, T, S, A = max(4, world), 3, 12, 5, 2
         obs, act, rew, mask = _ragged(np.random.default_rng(0), G, E, T, S, A)
         lo, hi = D.shard_groups(G, rank, world)
-        assert (lo, hi) == (rank * 2, rank * 2 + 2) and D.rank_world() == (rank, world)
+        assert (lo, hi) == (rank * G // world, (rank + 1) * G // world) and D.rank_world() == (rank, world)
         sl = slice(lo, hi)
         torch.manual_seed(1)
         pol = L.OraclePolicy(S, A, (16, 16), cov=0.4, critic=True)
@@ -89,18 +89,22 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gradients_equal_single_process():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_two_rank_gradients_equal_single_process(world):
+    """(world 4 and 8: one group per rank.  Eight ranks of the PRODUCT path cannot be rehearsed on a one-GPU box -- the pool admits six
+    GPU processes -- so this is where shard_groups / GradBucket / the sum-based moments first run at the driver's largest rank count.)"""
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-        res = {k: out[k] for k in (0, 1)}
-    # both ranks hold the same reduced gradient
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = {k: out[k] for k in range(world)}
+    # all ranks hold the same reduced gradient
     for key in ("grpo", "ppo", "moments"):
-        np.testing.assert_array_equal(res[0][key], res[1][key])
+        for r in range(1, world):
+            np.testing.assert_array_equal(res[0][key], res[r][key])
     # single-process reference on the full batch
     torch.set_num_threads(1)
-    G, E, T, S, A = 4, 3, 12, 5, 2
+    G, E, T, S, A = max(4, world), 3, 12, 5, 2
     obs, act, rew, mask = _ragged(np.random.default_rng(0), G, E, T, S, A)
     torch.manual_seed(1)
     pol = L.OraclePolicy(S, A, (16, 16), cov=0.4, critic=True)
@@ -125,7 +129,7 @@ def test_two_rank_gradients_equal_single_process():
     adv = (adv_raw - adv_raw.mean()) / (adv_raw.std() + 1e-8)
     ret = (rtg[mb] - rtg[mb].mean()) / (rtg[mb].std() + 1e-8)
     o, a = obs[mb], act[mb]
-    old_lp = torch.from_numpy(np.concatenate([res[0]["old_lp"], res[1]["old_lp"]]))   # rank order == group order
+    old_lp = torch.from_numpy(np.concatenate([res[r]["old_lp"] for r in range(world)]))   # rank order == group order
     for p in pol.parameters():
         p.grad = None
     lp, _ = pol.log_prob(o, a)
