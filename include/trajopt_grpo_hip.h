@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 11
+#define TG_ABI_VERSION 12
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_HIP = -2, TG_ERR_UNSUPPORTED = -3 };
 
@@ -237,6 +237,8 @@ typedef struct tg_loss_args {
     double* d_sums;          /* f64[4]: sum surrogate, sum (V-R)^2, sum exp(lp_old)(lp_old-lp), #valid */
     double* d_work;          /* f64[4*tg_loss_work_blocks()] scratch */
     int64_t M;
+    const float* d_coef;     /* NULL, or device f32[3] {surr_coef, critic_coef, kl_coef}: used INSTEAD of the three host fields
+                                (tg_ppo_norm's output + 4: PPO's 1 / n_valid stays on the device) */
 } tg_loss_args;
 
 int  tg_loss_work_blocks(void);
@@ -341,6 +343,11 @@ typedef struct tg_chain_loss {
      * is written here and used as its own old log-probability (ratio exactly 1, as in the reference, whose two forward passes are
      * the same arithmetic) -- d_logp_old is not read, and the caller needs no no-grad pass of the old policy. */
     float*       d_logp_old_out;
+    /* NULL, or device f32[8] as tg_ppo_norm writes it {adv mean, adv 1/(std+eps), ret mean, ret 1/(std+eps), surr_coef, critic_coef,
+     * kl_coef, n}: the head then takes its normalisation pair (kind 0: [0], [1]; kind 1: [2], [3]) and its coefficients ([4], [5], [6])
+     * from there instead of from norm_mean / norm_inv / *_coef above -- PPO's batch statistics (ppo.py:138-139) and 1 / n_valid
+     * (:165-179) never visit the host. */
+    const float* d_norm8;
 } tg_chain_loss;
 int  tg_mlp_forward_chain_blocks(void);
 int  tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float* d_bias, int32_t hidden, int32_t n_hidden_layers,
@@ -455,6 +462,22 @@ int  tg_mlp_f32_forward(const float* d_x, int32_t in_pad, const float* d_stream,
 int  tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, int32_t hidden, int32_t n_hidden_layers,
                                  int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits,
                                  const tg_chain_loss* loss, void* stream);
+/* The same passes at H = 256 (the reference's QuadPole factory at its own precision: pipelines/quadpole_pipeline_ppo.py:54-58,
+ * 20-256x5-{4,1} fp32), csrc/mlp_f32_wide.hip: a wave owns 16 rows on v_mfma_f32_16x16x4_f32, two 4-wave workgroups per CU.
+ *   d_stream  f32, tg_mlp_f32w_stream_floats(n_hidden_layers) floats, in 16-KiB blocks of 16 pieces x 64 lanes x 16 B, lane = (i = lane & 15,
+ *             g = lane >> 4) (trajopt-grpo_amd/mlp.py `F32WideStream`):
+ *               first layer, 2 blocks: block b, piece 2 tt + q (tt < 8, q < 2): W0[16 (8 b + tt) + i][8 g + 4 q .. + 3] (zero beyond the inputs)
+ *               forward, layer l = 1 .. n_hidden_layers - 1, 16 blocks mo, piece t:  W_l[16 mo + i][16 t + 4 g .. + 3]
+ *               backward, layer l = n_hidden_layers - 1 .. 1, 16 blocks ko, piece t: {W_l[16 t + 4 g + r][16 ko + i], r = 0..3}
+ *   d_table   f32 [tg_mlp_f32w_table_floats()]: [5][256] hidden biases | [4][256] head weights (rows >= outputs zero) | [4] head bias
+ *   d_acts / d_dz as for tg_mlp_f32_forward_backward (d_acts[0] and d_dz[top] may be NULL). */
+int64_t tg_mlp_f32w_stream_floats(int32_t n_hidden_layers);
+int64_t tg_mlp_f32w_table_floats(void);
+int  tg_mlp_f32w_blocks(void);
+int  tg_mlp_f32w_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers, int64_t rows,
+                         float* d_out, void* stream);
+int  tg_mlp_f32w_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers,
+                                  int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream);
 enum { TG_F32DW_MM = 0, TG_F32DW_HEAD = 1 };
 typedef struct tg_f32_dw_job {
     const float* d_p;
@@ -572,6 +595,25 @@ int64_t tg_learn_count_workspace(int64_t entries);
 int  tg_learn_count(const uint8_t* d_mask, int64_t entries, int64_t expected_rows, void* d_work, int64_t work_bytes, int64_t* d_total,
                     void* stream);
 int  tg_learn_compact(const tg_compact_args* args, void* stream);
+
+/* ---- PPO's prologue (algorithms/ppo.py:93-139) without a host round trip ----
+ * tg_scatter_rows: d_dst[d_idx[r]] = d_src[r * src_stride] for r < rows -- the critic's values of the valid rows (the no-grad
+ *   forward's padded output, column 0) back onto the zeroed [T][n] grid (ppo.py:93 evaluated on the valid rows only).
+ * tg_ppo_returns: returns and advantages of every (t, e) and their masked fp64 moments in two launches.  monte_carlo != 0:
+ *   R = tg_rtg_scan(rew, mask, gamma), A = R - V (ppo.py:100-111); else tg_gae_scan (ppo.py:112-124: A by GAE(gamma, lam), R = V + A).
+ *   d_adv / d_ret f32 [T][n] (distinct); d_moments f64 [2][3] = {count, sum, sum of squares} of the valid advantages, then of the
+ *   valid returns; d_work f64 [6 n] scratch.  Bit-identical to tg_rtg_scan / `rtg - V` / tg_gae_scan + tg_masked_moments(group = n).
+ * tg_ppo_norm: from d_moments (after the ranks' all-reduce, if any) the f32 [8] the loss heads read through
+ *   tg_chain_loss.d_norm8 / tg_loss_args.d_norm + d_coef: {adv mean, 1 / (adv std + 1e-8), ret mean, 1 / (ret std + 1e-8),
+ *   -1 / n, c1 / n, kl_coeff / n, n} with the unbiased std clamped at 0, in torch's own order of fp64 / fp32 operations
+ *   (ppo.py:138-139, :165-179).
+ * tg_gather_rows2: d_dst0[r] = d_src0[d_idx[r]] (and d_dst1 / d_src1 when given): `advantages[mask]`, `returns[mask]`. */
+int  tg_scatter_rows(const float* d_src, int64_t src_stride, const int64_t* d_idx, int64_t rows, float* d_dst, void* stream);
+int  tg_ppo_returns(const float* d_rew, const float* d_values, const uint8_t* d_mask, float gamma, float lam, int monte_carlo,
+                    float* d_adv, float* d_ret, int64_t n, int32_t T, double* d_moments, double* d_work, void* stream);
+int  tg_ppo_norm(const double* d_moments, double c1, double kl_coeff, float* d_norm8, void* stream);
+int  tg_gather_rows2(const int64_t* d_idx, int64_t rows, const float* d_src0, float* d_dst0, const float* d_src1, float* d_dst1,
+                     void* stream);
 
 /* ---- Measurement instruments (bench.py's roofline object; nothing on the product path calls them) ----
  * tg_clock_probe_attach: the update's persistent kernels are bound by the package power limit, i.e. by the shader clock the chip

@@ -100,7 +100,7 @@ def run_cases(names, rank, world, group=None, device=None, emulate_world=2, grou
         rec["optimizer_steps"] = steps["n"]
         rec["stats"] = {k: v for k, v in algo.last_stats.items()}
         if algo_name == "ppo":
-            rec["moments"] = list(algo._norm_host)
+            rec["moments"] = algo.norm8[:4].tolist()        # (the global normalisation constants, as the loss heads read them)
         rec["n_valid_local"] = int(tr.mask.sum().item())
         m = algo._mlp(pol.actor)
         rec["learner_path"] = ("chain" if (m is not None and m._chain is not None and m._bchain is not None) else

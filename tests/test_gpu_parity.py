@@ -1283,6 +1283,61 @@ def test_returns_moments_is_bit_identical_to_the_standalone_kernels(tg, dev, T, 
     assert torch.equal(mom0.view(torch.int64), mom1.view(torch.int64))       # bit for bit (NaN-safe)
 
 
+@pytest.mark.parametrize("T,n", [(1, 1), (7, 3), (64, 65), (129, 300), (500, 80), (256, 4100)])
+@pytest.mark.parametrize("monte_carlo", [True, False])
+def test_ppo_prologue_kernels_are_bit_identical_to_the_sequence_they_replace(tg, dev, T, n, monte_carlo):
+    """PPO's prologue without a host round trip (tg_scatter_rows / tg_ppo_returns / tg_ppo_norm / tg_gather_rows2) against what
+    learn() ran before: zeros + index_copy_, tg_rtg_scan + `rtg - V` or tg_gae_scan (both pinned to the reference: ppo.py:100-124),
+    two tg_masked_moments, torch's fp64 / fp32 arithmetic for mean / 1 / (std + 1e-8) (ppo.py:138-139) and the host's 1 / n, two
+    index_selects -- same bits everywhere, ragged lengths, masks with holes."""
+    K = tg.hip_ops
+    g = torch.Generator(device="cpu").manual_seed(T * 131 + n)
+    lens = torch.randint(0, T + 1, (n,), generator=g)
+    lens[0] = T
+    mask = (torch.arange(T).view(T, 1) < lens.view(1, n))
+    if T > 2:
+        mask[T // 2, ::7] = False
+    rew = (torch.randn(T, n, generator=g) * mask).to(dev)
+    mask = mask.to(torch.uint8).to(dev)
+    idx = mask.reshape(-1).nonzero().squeeze(1)
+    rows = idx.numel()
+    v_rows = torch.randn(rows, 4, generator=g).to(dev)                     # (the critic's padded output: column 0 is the value)
+    gamma, lam, c1, klc = 0.99, 0.95, 0.5, 0.3
+    # ---- before
+    V0 = torch.zeros(T * n, device=dev)
+    V0.index_copy_(0, idx, v_rows[:, 0].contiguous())
+    V0 = V0.view(T, n)
+    if monte_carlo:
+        ret0 = K.rtg_scan(rew, mask, gamma)
+        adv0 = ret0 - V0
+    else:
+        adv0, ret0 = K.gae_scan(rew, V0, mask, gamma, lam)
+    m0 = torch.cat([K.masked_moments(adv0, mask, n), K.masked_moments(ret0, mask, n)])
+    cnt, s1, s2 = m0[:, 0], m0[:, 1], m0[:, 2]
+    mean = s1 / cnt
+    std = torch.sqrt(torch.clamp((s2 - s1 * mean) / (cnt - 1.0), min=0.0)).float()
+    inv = 1.0 / (std + 1e-8)
+    norm0 = torch.stack([mean[0].float(), inv[0], mean[1].float(), inv[1]])
+    n_glob = float(cnt[0].item())
+    coef0 = torch.tensor([-1.0 / n_glob, c1 / n_glob, klc / n_glob, n_glob], dtype=torch.float64).float() if n_glob > 0 else None
+    # ---- after
+    V1 = torch.zeros(T, n, device=dev)
+    K.scatter_rows(v_rows, idx, V1)
+    adv1, ret1 = torch.empty(T, n, device=dev), torch.empty(T, n, device=dev)
+    m1 = K.ppo_returns(rew, V1, mask, gamma, lam, monte_carlo, adv1, ret1)
+    norm8 = K.ppo_norm(m1, c1, klc)
+    a_rows, r_rows = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    K.gather_rows2(idx, adv1, a_rows, ret1, r_rows)
+    torch.cuda.synchronize()
+    bits = lambda t: t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int64)
+    assert torch.equal(V0, V1)
+    assert torch.equal(bits(adv0), bits(adv1)) and torch.equal(bits(ret0), bits(ret1))
+    assert torch.equal(bits(m0), bits(m1))
+    assert torch.equal(bits(norm0), bits(norm8[:4])), (norm0.tolist(), norm8.tolist())       # (NaN-safe: one valid row -> NaN std, like torch)
+    assert torch.equal(bits(coef0.to(dev)), bits(norm8[4:]))
+    assert torch.equal(a_rows, adv0.reshape(-1).index_select(0, idx)) and torch.equal(r_rows, ret0.reshape(-1).index_select(0, idx))
+
+
 def test_returns_moments_horizon_limit(tg, dev):
     """The advertised limit launches (the kernel's LDS is dynamic to the last byte), one step more is refused with a message --
     and GRPO.learn() at that horizon takes tg_rtg_scan + tg_masked_moments instead of raising."""
@@ -1385,7 +1440,8 @@ def test_learn_compaction_at_c3_size(tg, dev):
 
 
 @pytest.mark.parametrize("kind,cdt,hidden", [("grpo", None, (128, 128)), ("grpo", torch.bfloat16, (128, 128, 128)), ("ppo", torch.bfloat16, (256, 256, 256)),
-                                             ("ppo", None, (64, 64)), ("ppo", None, (40, 40))])
+                                             ("ppo", None, (64, 64)), ("ppo", None, (40, 40)), ("ppo_gae", None, (64, 64)),
+                                             ("ppo_gae", torch.bfloat16, (128, 128, 128))])
 def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, kind, cdt, hidden):
     """learn() on the native prologue (tg_returns_moments / tg_learn_count / tg_learn_compact) against the same learn() on the torch
     prologue that nets outside its gate take (mask.nonzero(), index_selects, prepare_input; forced here by patching the gate shut):
@@ -1398,15 +1454,16 @@ def test_learn_is_bit_identical_with_and_without_the_native_prologue(tg, dev, ki
             Alg._GpuLearner._prepare_enqueue = lambda self, *a, **k: None
         try:
             torch.manual_seed(11)
-            cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
+            cls = tg.GaussianActorCritic_NeuralNetwork if kind.startswith("ppo") else tg.GaussianActor_NeuralNetwork
             pol = cls(20, 4, hidden, cov=0.3, device=dev)
             mgr = tg.RolloutManager(lambda: tg.QuadPole(max_steps=120), pol, num_workers=6, num_episodes_per_worker=40, seed=5, compute_dtype=cdt,
                                     restart=kind == "grpo")
             buf = tg.Rollout_Buffer(mgr)
             buf.sample()
             opt = torch.optim.Adam(pol.parameters(), lr=3e-4)
-            if kind == "ppo":
-                algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, gamma=0.99, batch_size=None, autocast_dtype=cdt)
+            if kind.startswith("ppo"):
+                algo = tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, gamma=0.99, batch_size=None, autocast_dtype=cdt,
+                              monte_carlo=kind == "ppo")
             else:
                 algo = tg.GRPO(epsilon=0.15, beta=0.5, gamma=0.9, policy=pol, optimizer=opt, updates_per_iter=2, autocast_dtype=cdt)
             algo.learn(buf)
@@ -2168,7 +2225,9 @@ def test_stream_refresher_equals_the_per_stream_refresh(tg, dev, cdt, hidden, mo
 # the fp32 chain learner (csrc/mlp_f32_chain.hip): the reference's own precision and net sizes
 # --------------------------------------------------------------------------------------------
 F32_SHAPES = [(5, 1, (128, 128)), (20, 4, (128,) * 4), (10, 2, (64,)), (5, 1, (64, 64, 64)), (32, 4, (128, 128, 128)), (3, 1, (128,)),
-              (12, 3, (128, 128)), (20, 4, (128, 128)), (32, 2, (128, 128)), (7, 2, (128, 128))]       # (two 128-wide layers: the 8-wave weight-gradient job at every padded input width)
+              (12, 3, (128, 128)), (20, 4, (128, 128)), (32, 2, (128, 128)), (7, 2, (128, 128)),       # (two 128-wide layers: the 8-wave weight-gradient job at every padded input width)
+              # H = 256 (csrc/mlp_f32_wide.hip): the reference's QuadPole factory shape (quadpole_pipeline_ppo.py:54-58) and its edges
+              (20, 4, (256,) * 5), (5, 1, (256, 256)), (10, 2, (256,)), (32, 3, (256, 256, 256))]
 
 
 @pytest.mark.parametrize("dims", F32_SHAPES)
@@ -2244,7 +2303,8 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monke
     assert torch.equal(sr, s) and torch.equal(dout_r, dout)
     assert all(torch.equal(a, b) for a, b in zip(got_r, got_r2))
     n_hidden = len(hidden)
-    if n_hidden >= 2:
+    wide = hidden[0] == 256                                             # (the H = 256 learner stores everything: its weight gradients are GEMMs for now)
+    if n_hidden >= 2 and not wide:
         # neither the first activation nor the top dZ was written; everything in between is the same bits as in the storing run.
         # The top layer's mask travels as 4 words per row: feature 32 mt + 8 q + 4 hh + low <-> word hh * (H / 64) + mt // 2,
         # bit low + 4 q + 16 (mt % 2)  (include/trajopt_grpo_hip.h, tg_mlp_f32_forward_backward)
@@ -2598,8 +2658,8 @@ def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A
     gradients and post-step weights (pipelines/quadpole_pipeline_ppo.py:55-58, algorithms/grpo.py:106-148).
     The FIRST update's gradients are taken on the reference's own initial weights: one forward / backward pass, nothing else.
       fp32: h128 (5-128x4) runs on the fp32 chain learner (tg_mlp_f32_forward_backward / tg_mlp_f32_weight_grad -- asserted
-        below: a gate that regresses must not silently re-test hipBLASLt), h256 on the per-layer GemmMLP path (library GEMMs +
-        HIP glue).  First gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on the GPU sits at
+        below: a gate that regresses must not silently re-test hipBLASLt), h256 on the H = 256 chain learner (tg_mlp_f32w_forward_backward; its weight gradients are
+        still split-K GEMMs).  First gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on the GPU sits at
         the same 3-5e-3 in three critic layers (a ReLU that flips for one row between the CPU's and the GPU's summation
         order), everything else at 1e-6; post-step weights <= 1e-5 (<= 0.5 % Adam-amplified outliers).  (The tight anchors of
         the fp32 chain kernels are test_f32_chain_update_matches_fp64_autograd and test_c2_size_grpo_learn_matches_the_oracle.)
@@ -2638,8 +2698,8 @@ def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A
         for net in nets:
             m = algo._mlp(net)
             assert m._f32 is not None and m._dw_ws is not None, "5-128x4 fp32 fell off the fp32 chain learner"
-    else:
-        assert all(algo._mlp(net)._f32 is None for net in nets)   # (256 wide: outside mlp_f32_chain.hip's gate)
+    else:                                                         # 256 wide at the reference's precision: csrc/mlp_f32_wide.hip
+        assert all(algo._mlp(net)._f32 is not None and algo._mlp(net)._f32.wide for net in nets), "20-256x5 fp32 fell off the H = 256 chain learner"
     st = algo.last_stats
     assert st["n_valid"] == int(g["n_valid"])
     lt = 2e-5 if cdt is None else 2e-3

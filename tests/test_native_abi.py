@@ -46,7 +46,8 @@ def test_single_hip_runtime_is_shared_with_torch():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(N.EnvParams) == 4 * 4 + 8 + 12 * 8
     assert C.sizeof(N.Traj) == 6 * 8 + 8 + 4 + 4
-    assert C.sizeof(N.LossArgs) == 8 * 11 + 8 * 4 + 4 * 5 + 4 + 8 * 5   # incl. 4 bytes of padding before d_grad_mean
+    assert C.sizeof(N.LossArgs) == 8 * 11 + 8 * 4 + 4 * 5 + 4 + 8 * 5 + 8   # incl. 4 bytes of padding before d_grad_mean; ABI 12: d_coef appended
+    assert N.LossArgs.d_coef.offset == 184 and N.ChainLoss.d_norm8.offset == C.sizeof(N.ChainLoss) - 8 == 136   # ABI 12: d_norm8 appended
     assert C.sizeof(N.DwJob) == 4 * 8 + 8 + 3 * 4 + 4 + 8 and N.DwJob.d_aux.offset == 56   # tg_dw_job (ABI 4: d_aux appended)
     assert (N.TG_DW_HH, N.TG_DW_HX, N.TG_DW_DH, N.TG_DW_HR, N.TG_DW_RH) == (0, 1, 2, 3, 4)
     assert C.sizeof(N.CompactArgs) == 160 and N.CompactArgs.d_moments.offset == 136 and N.CompactArgs.rows_cap.offset == 152   # tg_compact_args

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TG_NATIVE_LIB: another build of the same library (probe builds with different compile-time flags, tools/mall_probe.py)
 LIB_PATH = os.environ.get("TG_NATIVE_LIB") or os.path.join(_HERE, "libtrajopt_grpo_hip.so")
-ABI_VERSION = 11                     # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
+ABI_VERSION = 12                     # TG_ABI_VERSION of include/trajopt_grpo_hip.h this binding was written for
 
 TG_ENV_CARTPOLE, TG_ENV_QUADPOLE2D, TG_ENV_QUADPOLE, TG_ENV_QUADROTOR12, TG_ENV_PENDULUM = 0, 1, 2, 3, 4
 TG_F32, TG_F64 = 0, 1
@@ -46,7 +46,7 @@ class LossArgs(C.Structure):
                 ("var", C.c_float * 8), ("act_dim", C.c_int32), ("epsilon", C.c_float), ("surr_coef", C.c_float),
                 ("critic_coef", C.c_float), ("kl_coef", C.c_float),
                 ("d_grad_mean", C.c_void_p), ("d_grad_value", C.c_void_p), ("d_sums", C.c_void_p),
-                ("d_work", C.c_void_p), ("M", C.c_int64)]
+                ("d_work", C.c_void_p), ("M", C.c_int64), ("d_coef", C.c_void_p)]
 
 
 class DwJob(C.Structure):
@@ -95,7 +95,7 @@ class ChainLoss(C.Structure):
                 ("act_col_stride", C.c_int64), ("d_logp_old", C.c_void_p), ("d_adv", C.c_void_p), ("d_ret", C.c_void_p),
                 ("norm_mean", C.c_float), ("norm_inv", C.c_float), ("var", C.c_float * 4), ("epsilon", C.c_float), ("surr_coef", C.c_float),
                 ("critic_coef", C.c_float), ("kl_coef", C.c_float), ("d_dout8", C.c_void_p), ("d_head_slabs", C.c_void_p),
-                ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p), ("d_logp_old_out", C.c_void_p)]
+                ("d_work", C.c_void_p), ("d_bias_partial", C.c_void_p), ("d_logp_old_out", C.c_void_p), ("d_norm8", C.c_void_p)]
 
 class CompactArgs(C.Structure):
     """tg_compact_args (include/trajopt_grpo_hip.h)."""
@@ -163,6 +163,12 @@ SIGNATURES = {
     "tg_mlp_f32_forward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, _VP, _VP]),
     "tg_mlp_f32_forward_backward": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP,
                                               C.POINTER(ChainLoss), _VP]),
+    "tg_mlp_f32w_stream_floats": (C.c_int64, [_I32]),
+    "tg_mlp_f32w_table_floats": (C.c_int64, []),
+    "tg_mlp_f32w_blocks": (C.c_int, []),
+    "tg_mlp_f32w_forward": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I64, _VP, _VP]),
+    "tg_mlp_f32w_forward_backward": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(ChainLoss), _VP]),
     "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),
     "tg_mlp_f32_weight_grad": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, _VP]),
     "tg_mlp_f32_weight_grad_adam": (C.c_int, [_I32, C.POINTER(F32DwJob), _I32, _I64, _VP, _I64, _VP, _I32, _VP, C.POINTER(AdamRider), _VP]),
@@ -175,6 +181,10 @@ SIGNATURES = {
     "tg_learn_count_workspace": (C.c_int64, [_I64]),
     "tg_learn_count": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP, _VP]),
     "tg_learn_compact": (C.c_int, [C.POINTER(CompactArgs), _VP]),
+    "tg_scatter_rows": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP]),
+    "tg_ppo_returns": (C.c_int, [_VP, _VP, _VP, _F, _F, C.c_int, _VP, _VP, _I64, _I32, _VP, _VP, _VP]),
+    "tg_ppo_norm": (C.c_int, [_VP, C.c_double, C.c_double, _VP, _VP]),
+    "tg_gather_rows2": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),
     "tg_clock_probe_attach": (C.c_int, [_I32, _VP]),
     "tg_mfma_sustained_probe_blocks": (C.c_int, []),
     "tg_mfma_sustained_probe_flops": (C.c_double, [_I32, _I32]),

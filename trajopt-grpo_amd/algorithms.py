@@ -322,7 +322,7 @@ class _GpuLearner(Algorithm):
         and the step: the fp32 chain learner, one rank (no all-reduce), the update's rows in ONE chunk, and an optimizer that holds
         exactly this net's parameters.  None otherwise -- the caller then all-reduces and calls _optimizer_step() as before."""
         m = self._mlp(net)
-        if not (whole_update and m is not None and m._f32 is not None) or D.rank_world(self.process_group)[1] != 1 or D._ALWAYS:
+        if not (whole_update and m is not None and m._f32 is not None and not m._f32.wide) or D.rank_world(self.process_group)[1] != 1 or D._ALWAYS:
             return None                     # (TG_COLLECTIVES_AT_WORLD_1=1: the gradient all-reduce is wanted even at one rank)
         refresher = self._optimizer_setup(net)
         if refresher is None or not self._adam_covers_bucket:
@@ -445,6 +445,14 @@ class _GpuLearner(Algorithm):
         d1 = d1_c[:rows] if d1_c is not None else None
         M.set_ones_column(xin, ones >= 0)
         return idx, xin, act, d0, d1
+
+    def _small(self, name, numel, dtype, device):
+        """A cached device buffer whose size does not follow the row count (the row-sized workspace rounds up to a whole chunk)."""
+        cache = self.__dict__.setdefault("_small_bufs", {})
+        t = cache.get(name)
+        if t is None or t.numel() != numel or t.dtype != dtype or t.device != device:
+            cache[name] = t = torch.empty(numel, dtype=dtype, device=device)
+        return t
 
     def _logp_nograd(self, actor, xin, act, var):
         out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
@@ -579,17 +587,12 @@ class PPO(_GpuLearner):
         # None = torch.randperm on the device from `seed` (the reference draws torch.randperm on the CPU, ppo.py:148)
         self.permutation_fn = None
 
-    def _values_nograd(self, xin):
-        out = torch.empty(xin.shape[0], dtype=torch.float32, device=xin.device)
-        for lo in range(0, xin.shape[0], self.chunk_rows):
-            hi = min(lo + self.chunk_rows, xin.shape[0])
-            out[lo:hi] = self._forward(self.policy.critic, xin[lo:hi]).reshape(-1)
-        return out
-
-    def _step(self, xin, act, adv, ret, old_logp, norm, var, n_global, sums_out, last=True, write_old=False):
-        """One optimizer step on the given rows (all local rows, or one minibatch).  write_old: this is the first step of a full-batch
-        learn() on the fp32 chain learner -- its forward pass WRITES `old_logp` (ppo.py:142-143 takes the old log-probabilities from
-        the current policy: the same numbers) instead of reading it."""
+    def _step(self, xin, act, adv, ret, old_logp, norm8, var, sums_out, host=None, last=True, write_old=False):
+        """One optimizer step on the given rows (all local rows, or one minibatch).  norm8: the device f32 [8] of tg_ppo_norm -- the
+        normalisation constants of ppo.py:138-139 and the 1 / n of :165-179, read by the loss heads on the device.  host: minibatch
+        mode only -- (the four normalisation constants as a list, this step's global row count): the 1 / n of a minibatch is its own.
+        write_old: this is the first step of a full-batch learn() on a chain learner -- its forward pass WRITES `old_logp` (ppo.py:142-143
+        takes the old log-probabilities from the current policy: the same numbers) instead of reading it."""
         actor, critic = self.policy.actor, self.policy.critic
         self._zero_grads()
         # [actor | critic] loss sums: a row of the learn()'s pre-zeroed table when there is one (full batch: one fill per learn(), not per update)
@@ -597,23 +600,28 @@ class PPO(_GpuLearner):
         sums = both[0]
         m_a, m_c = self._mlp(actor), self._mlp(critic)
         fuse = m_a is not None and m_c is not None and m_a.can_fuse_head() and m_c.can_fuse_head()
+        if host is None:
+            dev8, nh, coefs = norm8, (None,) * 4, (0.0, 0.0, 0.0)
+        else:
+            dev8, nh, n_global = None, host[0], host[1]
+            coefs = (-1.0 / n_global, self.c1 / n_global, self.kl_coeff / n_global)
         for lo in range(0, xin.shape[0], self.chunk_rows):
             hi = min(lo + self.chunk_rows, xin.shape[0])
             if fuse:            # both loss heads + head gradients inside the forward chains (tg_mlp_forward_chain_loss)
-                nh = self._norm_host
-                m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2], var=var,
-                                 epsilon=self.epsilon, surr_coef=-1.0 / n_global, kl_coef=self.kl_coeff / n_global, sums_out=both[0],
-                                 logp_old_out=old_logp[lo:hi] if write_old else None)
+                m_a.forward_loss(xin[lo:hi], 0, act=act[lo:hi], logp_old=old_logp[lo:hi], adv=adv[lo:hi], norm=nh[0:2] if host else None,
+                                 var=var, epsilon=self.epsilon, surr_coef=coefs[0], kl_coef=coefs[2], sums_out=both[0],
+                                 logp_old_out=old_logp[lo:hi] if write_old else None, norm8=dev8)
                 m_a.backward_fused()
-                m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4], critic_coef=self.c1 / n_global, sums_out=both[1])
+                m_c.forward_loss(xin[lo:hi], 1, ret=ret[lo:hi], norm=nh[2:4] if host else None, critic_coef=coefs[1], sums_out=both[1],
+                                 norm8=dev8)
                 m_c.backward_fused()
                 continue
             mean = self._forward(actor, xin[lo:hi], train=True, view=True)         # the loss kernel takes a row stride
             vout = self._forward(critic, xin[lo:hi], train=True)
             value = vout.reshape(-1).contiguous()
             _, s, g_mean, g_val = K.surrogate_loss(mean.detach(), value.detach(), act[lo:hi], old_logp[lo:hi], adv[lo:hi],
-                                                   ret[lo:hi], None, norm, var, self.epsilon, -1.0 / n_global,
-                                                   self.c1 / n_global, self.kl_coeff / n_global, want_total=False)
+                                                   ret[lo:hi], None, norm8[:4], var, self.epsilon, coefs[0], coefs[1], coefs[2],
+                                                   want_total=False, coef=norm8[4:7] if host is None else None)
             self._backward(actor, mean, g_mean)
             self._backward(critic, vout, g_val.view_as(vout))
             sums += s
@@ -625,75 +633,82 @@ class PPO(_GpuLearner):
         traj = device_trajectory(buffer, self.policy.device)
         var = self.policy.var
         T, n = traj.T, traj.n
+        cap = T * n
         rew = traj.rew if traj.rew.dtype == torch.float32 else traj.rew.float()
-        m_a, m_c = self._mlp(self.policy.actor), self._mlp(self.policy.critic)
+        actor, critic = self.policy.actor, self.policy.critic
+        m_a, m_c = self._mlp(actor), self._mlp(critic)
         if m_a is not None and m_c is not None and m_a.in_pad != m_c.in_pad:
             m_a.disable_f32_chain()                       # (only one of the two fits the fp32 chain learner: both take the
             m_c.disable_f32_chain()                       #  per-layer path, so that they keep sharing ONE prepared input)
-        self._entry_refresh(self.policy.actor, self.policy.critic)
-        # the valid rows (ppo.py:126-135): index, padded input row (actor and critic share input width / compute dtype), action
-        prepared = self._prepare(traj, m_a) if (m_c is not None and m_a is not None and m_c.in_pad == m_a.in_pad and m_c.cd == m_a.cd) else None
+        # the valid rows (ppo.py:126-135): index, padded input row (actor and critic share input width / compute dtype), action --
+        # enqueued on the buffers' capacity; the host asks for the row count (and waits for the rollout) only after everything that
+        # does not depend on it has been enqueued too
+        shared = m_c is not None and m_a is not None and m_c.in_pad == m_a.in_pad and m_c.cd == m_a.cd
+        handle = self._prepare_enqueue(traj, m_a) if shared else None
+        self._entry_refresh(actor, critic)
+        _ = self.bucket                                                     # (the gradient windows exist before can_fuse_head() asks)
+        dev = traj.mask.device
+        V = self._ws.get("V", cap, 1, torch.float32, dev, cap).view(T, n)
+        V.zero_()                                                           # padded entries: V = 0 (they never reach a result)
+        adv_full = self._ws.get("adv_full", cap, 1, torch.float32, dev, cap).view(T, n)
+        ret_full = self._ws.get("ret_full", cap, 1, torch.float32, dev, cap).view(T, n)
+        work = self._small("ppo_work", 6 * n, torch.float64, dev)
+        prepared = self._prepare_finish(handle)
         if prepared is not None:
             idx, xin, act, _, _ = prepared
         else:
             idx, X, act = self._gather_valid(traj)
-            xin = self._prep(self.policy.actor, X, traj.T * traj.n)
-        X = xin                                                             # (below: row count and device only)
-        # V on valid rows only; padded rows never reach a result (they are masked in both scans)
-        v_valid = self._values_nograd(xin)                                  # ppo.py:93
-        V = torch.zeros(T * n, dtype=torch.float32, device=X.device)
-        V.index_copy_(0, idx, v_valid)
-        V = V.view(T, n)
-        if self.monte_carlo:
-            rtg = K.rtg_scan(rew, traj.mask, self.gamma)                    # ppo.py:100-109
-            adv_full = rtg - V                                              # ppo.py:111
-        else:
-            adv_full, rtg = K.gae_scan(rew, V, traj.mask, self.gamma, self.lam)   # ppo.py:112-124
-        # global (all ranks) moments of the valid advantages and returns -> fused normalisation
-        m = torch.cat([K.masked_moments(adv_full, traj.mask, n), K.masked_moments(rtg, traj.mask, n)])   # [2][3]
-        D.allreduce_sum_(m, self.process_group, "ppo_moments")
-        cnt, s1, s2 = m[:, 0], m[:, 1], m[:, 2]
-        mean = s1 / cnt
-        std = torch.sqrt(torch.clamp((s2 - s1 * mean) / (cnt - 1.0), min=0.0)).float()     # unbiased, ppo.py:138-139
-        inv = 1.0 / (std + 1e-8)
-        norm = torch.stack([mean[0].float(), inv[0], mean[1].float(), inv[1]]).contiguous()
-        n_global = float(cnt[0].item())
-        self._norm_host = norm.tolist()          # (the fused loss head takes the four numbers as kernel arguments)
-        adv = adv_full.reshape(-1).index_select(0, idx)
-        ret = rtg.reshape(-1).index_select(0, idx)
-        # ppo.py:142-143: the old log-probabilities come from the CURRENT policy -- on the fp32 chain learner the first full-batch
+            xin = self._prep(actor, X, cap)
+        n_rows = xin.shape[0]
+        # ppo.py:93: V of the valid rows (padded rows are masked in both scans), scattered onto the [T][n] grid by the launch that
+        # follows each chunk's no-grad pass
+        for lo in range(0, n_rows, self.chunk_rows):
+            hi = min(lo + self.chunk_rows, n_rows)
+            out = m_c.forward(xin[lo:hi], keep=False, padded=True) if m_c is not None else self._forward(critic, xin[lo:hi])
+            K.scatter_rows(out, idx[lo:hi], V)
+        # ppo.py:100-124 + the masked moments of :138-139 in two launches; the ranks' sums in one all-reduce; the normalisation
+        # constants and 1 / n on the device (tg_ppo_norm): nothing of this visits the host
+        moments = K.ppo_returns(rew, V, traj.mask, self.gamma, self.lam, self.monte_carlo, adv_full, ret_full, work)
+        D.allreduce_sum_(moments, self.process_group, "ppo_moments")
+        norm8 = K.ppo_norm(moments, self.c1, self.kl_coeff, out=self._small("norm8", 8, torch.float32, dev))
+        self.norm8 = norm8                                                  # (diagnostics: this learn()'s constants, on the device)
+        adv = self._ws.get("row0", n_rows, 1, torch.float32, dev, cap).view(-1)
+        ret = self._ws.get("row1", n_rows, 1, torch.float32, dev, cap).view(-1)
+        K.gather_rows2(idx, adv_full, adv, ret_full, ret)
+        # ppo.py:142-143: the old log-probabilities come from the CURRENT policy -- on a chain learner the first full-batch
         # update's own forward pass writes them (ratio exactly 1 there, as in the reference), no no-grad pass
-        _ = self.bucket                                                     # (the gradient windows exist before can_fuse_head() asks)
         fold_old = (_FOLD_OLD_LOGP and self.batch_size is None and self.updates_per_iter > 0 and m_a is not None and m_c is not None
                     and m_a.can_write_old_logp() and m_c.can_fuse_head())
-        old_logp = (self._ws.get("old_logp", X.shape[0], 1, torch.float32, X.device, traj.T * traj.n).view(-1) if fold_old else
-                    self._logp_nograd(self.policy.actor, xin, act, var))
-        n_rows = X.shape[0]
+        old_logp = (self._ws.get("old_logp", n_rows, 1, torch.float32, dev, cap).view(-1) if fold_old else
+                    self._logp_nograd(actor, xin, act, var))
         all_sums = []
-        self._sum_rows = (list(torch.zeros(self.updates_per_iter, 2, 4, dtype=torch.float64, device=X.device).unbind(0))
+        self._sum_rows = (list(torch.zeros(self.updates_per_iter, 2, 4, dtype=torch.float64, device=dev).unbind(0))
                           if self.batch_size is None and self.updates_per_iter > 0 else None)
+        norm_host = None
         for u in range(self.updates_per_iter):
             final = u == self.updates_per_iter - 1
             if self.batch_size is None:
                 # full batch: the reference permutes and takes one "minibatch" of everything (ppo.py:147-150)
-                self._step(xin, act, adv, ret, old_logp, norm, var, n_global, all_sums, last=final, write_old=fold_old and u == 0)
+                self._step(xin, act, adv, ret, old_logp, norm8, var, all_sums, last=final, write_old=fold_old and u == 0)
             else:
                 if self.permutation_fn is not None:
-                    perm = self.permutation_fn(n_rows, X.device)
+                    perm = self.permutation_fn(n_rows, dev)
                 else:
                     if self._gen is None:
-                        self._gen = torch.Generator(device=X.device)
+                        self._gen = torch.Generator(device=dev)
                         self._gen.manual_seed(self._seed)
-                    perm = torch.randperm(n_rows, device=X.device, generator=self._gen)
+                    perm = torch.randperm(n_rows, device=dev, generator=self._gen)
                 # every rank takes the same number of optimizer steps (each one is a collective); a rank that has run
                 # out of rows joins the remaining ones with an empty slice
-                local_bs, n_steps, sizes = D.minibatch_schedule(n_rows, self.batch_size, self.process_group, X.device)
+                local_bs, n_steps, sizes = D.minibatch_schedule(n_rows, self.batch_size, self.process_group, dev)
+                if norm_host is None:
+                    norm_host = norm8[:4].tolist()           # (a minibatch's 1 / n is its own: host numbers; one read per learn())
                 for k in range(n_steps):
                     b = perm[k * local_bs:(k + 1) * local_bs]
                     # (the minibatch's rows are copies: they keep the prepared input's ones column, and say so)
                     self._step(M.inherit_ones_column(xin.index_select(0, b), xin), act.index_select(0, b), adv.index_select(0, b),
-                               ret.index_select(0, b), old_logp.index_select(0, b), norm, var, float(sizes[k]), all_sums,
-                               last=final and k == n_steps - 1)
+                               ret.index_select(0, b), old_logp.index_select(0, b), norm8, var, all_sums,
+                               host=(norm_host, float(sizes[k])), last=final and k == n_steps - 1)
         self._check_deferred()                                              # (this learn()'s own row count: landed long ago)
         self._copy_policy_to_old()                                          # ppo.py:186
         if all_sums:
@@ -703,12 +718,13 @@ class PPO(_GpuLearner):
             D.allreduce_sum_(S, self.process_group, "loss_stats")
             nn = S[:, 3]
             ent = 0.5 * act.shape[1] * (1.0 + math.log(2 * math.pi)) + 0.5 * float(torch.log(var).sum())
-            actor = (-S[:, 0] / nn)
-            critic = (S[:, 1] / nn)
+            a_loss = (-S[:, 0] / nn)
+            c_loss = (S[:, 1] / nn)
             kl = (S[:, 2] / nn)
-            total = actor + self.c1 * critic - self.entropy * ent + self.kl_coeff * kl
-            self._stats_pending = lambda: {"actor_loss": actor.tolist(), "critic_loss": critic.tolist(), "kl_div": kl.tolist(),
-                                           "total_loss": total.tolist(), "entropy": ent, "n_valid": n_global}
+            total = a_loss + self.c1 * c_loss - self.entropy * ent + self.kl_coeff * kl
+            n_dev = moments[0, 0].clone()                                   # (the buffers above are re-used by the next learn())
+            self._stats_pending = lambda: {"actor_loss": a_loss.tolist(), "critic_loss": c_loss.tolist(), "kl_div": kl.tolist(),
+                                           "total_loss": total.tolist(), "entropy": ent, "n_valid": float(n_dev)}
 
     def metadata(self) -> dict:
         return {"algorithm": "PPO", "epsilon": self.epsilon, "c1": self.c1, "kl_coeff": self.kl_coeff,

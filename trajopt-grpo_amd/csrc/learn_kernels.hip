@@ -325,6 +325,24 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
     }
 }
 
+// dst[idx[r]] = src[r * stride]: the critic's values of the valid rows back onto the [T][n] grid (what `V = zeros; V.index_copy_(0, idx,
+// v)` did, algorithms/ppo.py:93 evaluated on valid rows only)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, int64_t stride, const int64_t* __restrict__ idx,
+                                                           int64_t rows, float* __restrict__ dst) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x)
+        dst[idx[r]] = src[r * stride];
+}
+
+// dst0[r] = src0[idx[r]], dst1[r] = src1[idx[r]]: `adv[mask]`, `returns[mask]` (ppo.py:126-135) in one launch
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const int64_t* __restrict__ idx, int64_t rows, const float* __restrict__ src0,
+                                                           float* __restrict__ dst0, const float* __restrict__ src1, float* __restrict__ dst1) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = idx[r];
+        dst0[r] = src0[f];
+        if (dst1) dst1[r] = src1[f];
+    }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -394,6 +412,26 @@ int tg_learn_compact(const tg_compact_args* p, void* stream) {
     if (a.obs_f64) hipLaunchKernelGGL(compact_rows_kernel<double>, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(compact_rows_kernel<float>, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
     TG_LAUNCH_CHECK("tg_learn_compact");
+    return TG_OK;
+}
+
+int tg_scatter_rows(const float* d_src, int64_t src_stride, const int64_t* d_idx, int64_t rows, float* d_dst, void* stream) {
+    TG_REQUIRE(rows >= 0 && src_stride >= 1, "tg_scatter_rows: bad sizes");
+    if (rows == 0) return TG_OK;
+    TG_REQUIRE(d_src && d_idx && d_dst, "tg_scatter_rows: null pointer");
+    const unsigned grid = (unsigned)(ceil_div(rows, 256) < 4096 ? ceil_div(rows, 256) : 4096);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride, d_idx, rows, d_dst);
+    TG_LAUNCH_CHECK("tg_scatter_rows");
+    return TG_OK;
+}
+
+int tg_gather_rows2(const int64_t* d_idx, int64_t rows, const float* d_src0, float* d_dst0, const float* d_src1, float* d_dst1, void* stream) {
+    TG_REQUIRE(rows >= 0, "tg_gather_rows2: negative row count");
+    if (rows == 0) return TG_OK;
+    TG_REQUIRE(d_idx && d_src0 && d_dst0 && ((d_src1 == nullptr) == (d_dst1 == nullptr)), "tg_gather_rows2: null pointer");
+    const unsigned grid = (unsigned)(ceil_div(rows, 256) < 4096 ? ceil_div(rows, 256) : 4096);
+    hipLaunchKernelGGL(gather_rows2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_idx, rows, d_src0, d_dst0, d_src1, d_dst1);
+    TG_LAUNCH_CHECK("tg_gather_rows2");
     return TG_OK;
 }
 

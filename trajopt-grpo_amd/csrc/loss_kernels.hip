@@ -42,7 +42,7 @@ struct LossK {
     const float* mean; int64_t mean_rs;
     const float* act; int64_t act_rs, act_cs;
     const float* logp_old; const float* adv; const float* value; const float* ret;
-    const uint8_t* mask; const float* norm;
+    const uint8_t* mask; const float* norm; const float* coef;
     Var8 v;
     float epsilon, surr_coef, critic_coef, kl_coef;
     float* grad_mean; float* grad_value; double* work; int64_t M;
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void surrogate_loss_kernel(LossK p) {
     double s_surr = 0, s_crit = 0, s_kl = 0, s_cnt = 0;
     float n_am = 0.f, n_ai = 1.f, n_rm = 0.f, n_ri = 1.f;
     if (p.norm != nullptr) { n_am = p.norm[0]; n_ai = p.norm[1]; n_rm = p.norm[2]; n_ri = p.norm[3]; }
+    if (p.coef != nullptr) { p.surr_coef = p.coef[0]; p.critic_coef = p.coef[1]; p.kl_coef = p.coef[2]; }
     const float lo = 1.0f - p.epsilon, hi = 1.0f + p.epsilon;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.M; i += (int64_t)gridDim.x * blockDim.x) {
         const bool valid = p.mask == nullptr || p.mask[i] != 0;
@@ -193,7 +194,7 @@ int tg_surrogate_loss(const tg_loss_args* a, void* stream) {
     k.mean = a->d_mean; k.mean_rs = a->mean_row_stride;
     k.act = a->d_act; k.act_rs = a->act_row_stride; k.act_cs = a->act_col_stride;
     k.logp_old = a->d_logp_old; k.adv = a->d_adv; k.value = a->d_value; k.ret = a->d_ret;
-    k.mask = a->d_mask; k.norm = a->d_norm;
+    k.mask = a->d_mask; k.norm = a->d_norm; k.coef = a->d_coef;
     k.epsilon = a->epsilon; k.surr_coef = a->surr_coef; k.critic_coef = a->critic_coef; k.kl_coef = a->kl_coef;
     k.grad_mean = a->d_grad_mean; k.grad_value = a->d_grad_value; k.work = a->d_work; k.M = a->M;
     hipStream_t st = (hipStream_t)stream;

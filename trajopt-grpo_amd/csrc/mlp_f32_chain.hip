@@ -24,6 +24,7 @@
 
 #include "tg_common.hpp"
 #include "adam_update.hpp"
+#include "f32_loss.hpp"
 
 #ifndef TG_F32DW_STAMPS
 #define TG_F32DW_STAMPS 0          /* diagnostic build: s_memtime stamps around the phases of the wide job's stage loop (never in the product) */
@@ -47,17 +48,6 @@ struct F32Net {
     const uint4* blocks;    // H x H layers: forward blocks [n_hh][H/32][H/8][64] x 16 B, then the backward (transposed) blocks, top layer first
     int32_t n_hh;           // H x H layers (hidden layers - 1)
     int32_t k2;             // first-layer k pairs = padded input width / 2 (multiple of 4, <= 16)
-};
-
-struct F32Loss {            // the loss head (as ChainLoss of mlp_fwd_chain.hip)
-    int32_t kind, A;        // 0: actor (clipped surrogate + KL-ish penalty), 1: critic (squared error)
-    const float* act;       // actor: [rows][A] contiguous; critic: the returns [rows]
-    const float* logp_old; const float* adv;
-    float* logp_old_out;    // non-null: the old policy is the current one -- the row's log-probability is its old log-probability, written here
-    float n_m, n_i;         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
-    float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
-    float* dout4;           // out: d loss / d head output, f32 [rows][4] (columns >= A zero)
-    double* work;           // out: f64 [grid][4] partial loss sums (surrogate, squared error, KL, count)
 };
 
 struct F32ChainArgs {
@@ -108,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     const F32Net& net = a.net;
     const int n_hh = net.n_hh, K2 = net.k2;
     const int n_stream = n_hh * MT * (kTrain ? 2 : 1);              // blocks per round (the same sequence every round)
+    if constexpr (kTrain) f32_loss_from_device(a.loss);
     const bool resident = a.resident != 0;
     // LDS (f32_chain_lds() on the host computes the same sizes): the block ring (2 blocks) or the whole resident stream, the
     // first layer's fragments, bias / head tables, the ReLU mask bits of the (n_hh + 1) hidden layers, the loss-sum scratch
@@ -306,45 +297,8 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
         } else {
             // ---- loss head (loss_kernels.hip::surrogate_loss_kernel, same arithmetic), evaluated by both lane halves ----
             const F32Loss& L = a.loss;
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            float c_surr = 0.f, c_crit = 0.f, c_kl = 0.f;
-            if (L.kind == 0) {
-                float quad = 0.f, dmu[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float d = (k < L.A ? L.act[rowc * L.A + k] : 0.f) - o[k];
-                    dmu[k] = d;
-                    quad += d * d * L.inv_var[k];
-                }
-                const float lp = -0.5f * quad + L.logp_const;
-                float lpo;
-                if (L.logp_old_out != nullptr) {
-                    lpo = lp;
-                    if (valid && h == 0) L.logp_old_out[row] = lp;
-                } else {
-                    lpo = L.logp_old[rowc];
-                }
-                const float adv = (L.adv[rowc] - L.n_m) * L.n_i;
-                const float rho = expf(lp - lpo);
-                const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
-                const float surr1 = rho * adv, surr2 = fminf(fmaxf(rho, lo), hi) * adv;
-                const bool inside = (rho >= lo) && (rho <= hi);
-                const float w = inside ? 1.0f : (surr1 < surr2 ? 1.0f : 0.0f);
-                c_surr = fminf(surr1, surr2);
-                float dlp = L.surr_coef * adv * rho * w;
-                if (L.kl_coef != 0.0f) {
-                    const float eo = expf(lpo);
-                    c_kl = eo * (lpo - lp);
-                    dlp -= L.kl_coef * eo;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = dlp * dmu[k] * L.inv_var[k];
-            } else {
-                const float d = o[0] - (L.act[rowc] - L.n_m) * L.n_i;
-                c_crit = d * d;
-                g[0] = L.critic_coef * 2.0f * d;
-            }
-            if (!valid) { g[0] = g[1] = g[2] = g[3] = 0.f; }
+            float g[4], c_surr, c_crit, c_kl;
+            f32_loss_row(L, o, row, rowc, valid, h == 0, g, c_surr, c_crit, c_kl);
             if (valid && h == 0) {
                 s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
                 *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{g[0], g[1], g[2], g[3]};
@@ -1759,19 +1713,7 @@ int tg_mlp_f32_forward_backward(const float* d_x, int32_t in_pad, const float* d
     }
     a.top_mask = (uint32_t*)d_top_maskbits;
     a.x = d_x; a.rows = rows;
-    F32Loss& L = a.loss;
-    L.kind = loss->kind; L.A = loss->act_dim;
-    L.act = loss->kind == 0 ? loss->d_act : loss->d_ret;
-    L.logp_old = loss->d_logp_old; L.adv = loss->d_adv; L.logp_old_out = loss->kind == 0 ? loss->d_logp_old_out : nullptr;
-    L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
-    float logdet = 0.f;
-    for (int k = 0; k < 4; ++k) {
-        L.inv_var[k] = k < loss->act_dim ? 1.0f / loss->var[k] : 0.f;
-        if (k < loss->act_dim) logdet += logf(loss->var[k]);
-    }
-    L.logp_const = -0.5f * (float)loss->act_dim * 1.8378770664093453f - 0.5f * logdet;
-    L.epsilon = loss->epsilon; L.surr_coef = loss->surr_coef; L.critic_coef = loss->critic_coef; L.kl_coef = loss->kl_coef;
-    L.dout4 = (float*)loss->d_dout8; L.work = loss->d_work;
+    fill_f32_loss(a.loss, loss);
     hipStream_t st = (hipStream_t)stream;
     return hidden == 128 ? launch_f32_chain<128, true>(a, st) : launch_f32_chain<64, true>(a, st);
 }

@@ -1,0 +1,387 @@
+// The fp32 chain learner at H = 256: the reference's own QuadPole factory at the reference's own precision
+// (pipelines/quadpole_pipeline_ppo.py:54-58: GaussianActorCritic_NeuralNetwork 20-256x5-{4,1}, fp32) -- forward pass, loss head
+// (algorithms/ppo.py:159-179) and backward-DATA pass of a row in ONE launch, as mlp_f32_chain.hip does for H = 64 / 128.
+//
+// Why a different machine than mlp_f32_chain.hip.  There a wave owns 32 rows on v_mfma_f32_32x32x2_f32 and keeps a layer's input
+// AND output in registers: 2 x (H / 32) x 16 = 256 registers at H = 256 -- they do not exist at two waves per SIMD.  Here a wave
+// owns 16 rows on v_mfma_f32_16x16x4_f32 (same 64 flop / clk / SIMD): a 16-feature tile is 4 accumulator registers, a layer's
+// input + output 2 x 16 x 4 = 128.  Transposed form Y^T = W . X^T as everywhere in this tree: the 16 columns of a tile are 16 rows
+// of the batch; lane (j = lane & 15, g = lane >> 4) of an accumulator tile t holds features 16 t + 4 g + r (r = 0..3) of row j, and
+// register r of the four lane groups IS the B operand of MFMA step (t, r) of the next layer (contraction indices 16 t + 4 g + r,
+// g = 0..3).  The A operand of that step, lane (i, g), is W[out i][16 t + 4 g + r]: a lane's four steps of one t are FOUR
+// CONSECUTIVE floats of a weight row -- one ds_read_b128 per four products, and the weight stream is the matrix itself in 16-B
+// pieces (mlp.F32WideStream).  The backward pass is the same machine on W^T with a mask multiply instead of bias + ReLU.
+//
+// Two 4-wave workgroups per CU instead of one 8-wave workgroup: the two waves of a SIMD then belong to DIFFERENT workgroups and
+// drift out of phase, so one wave's epilogue / barrier wait hides behind the other's products (mlp_f32_chain.hip's eight waves
+// meet at a barrier per block, their epilogues coincide, and its matrix pipe is 64 % busy).  Weights: one 16-feature output block
+// (16 KiB = 16 pieces of 1 KiB) at a time through a ring of 3 slots, LDS-DMA, counted vmcnt + one raw s_barrier per block
+// (mfma_ring.hpp's discipline).  Biases and the head stay in LDS; the ReLU mask bits of a wave's rows live in LDS between the passes.
+#include <stdlib.h>
+
+#include "tg_common.hpp"
+#include "mfma_ring.hpp"
+#include "f32_loss.hpp"
+
+namespace tg {
+
+constexpr int kWideH = 256;
+constexpr int kWideMaxHidden = 5;       // hidden layers (the first + up to 4 H x H)
+
+struct F32WideArgs {
+    const float* x;             // [rows][in_pad] f32, zero padded (in_pad a multiple of 8, <= 32)
+    int32_t in_pad;
+    int32_t n_hh;               // H x H layers (hidden layers - 1)
+    int64_t rows;
+    const uint4* stream;        // blocks of 16 KiB: [first layer: 2][forward: n_hh x 16][backward: n_hh x 16, top layer first]
+    const float* table;         // [kWideMaxHidden][H] hidden biases | [4][H] head weights (rows >= A zero) | [4] head bias (+ 12 pad)
+    float* acts[kWideMaxHidden];    // training: post-ReLU outputs of the hidden layers f32 [rows][H]; [0] may be null (rebuilt by the
+                                    // weight-gradient job), the others are written
+    float* dz[kWideMaxHidden];      // training: d loss / d pre-activation f32 [rows][H]; [n_hh] (the top layer's) may be null
+    float* out;                 // no-grad pass: head output f32 [rows][4]
+    F32Loss loss;
+};
+
+__device__ static inline uint4 wide_lds_u4(const uint4* __restrict__ p) { return *p; }
+__device__ static inline float4 wide_lds_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+__device__ static inline float wide_lds_f(const float* __restrict__ p) { return *p; }
+__device__ static inline uint2 wide_lds_u2(const uint32_t* __restrict__ p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ static inline void wide_lds_st2(uint32_t* __restrict__ p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+
+constexpr int kWidePieces = 16;                         // 1-KiB pieces per block
+constexpr int kWideSlot = kWidePieces * 64;             // uint4 per ring slot
+constexpr int kWideD = 3, kWideP = kWideD - 1;          // ring slots, blocks in flight
+constexpr int kWideWaves = 4;
+constexpr int kWideTable = (kWideMaxHidden + 4) * kWideH + 16;      // floats
+
+static size_t f32_wide_lds() {
+    return (size_t)kWideD * kWideSlot * 16 + (size_t)kWideTable * 4 + (size_t)kWideMaxHidden * kWideWaves * 64 * 8 + 4 * 4 * 8;
+}
+
+TG_CLOCK_PROBE_VAR(g_probe_f32_wide, attach_probe_f32_wide)
+
+template <bool kTrain>
+__global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
+    constexpr int H = kWideH, NT = H / 16, D = kWideD, P = kWideP, WPW = kWideWaves, KS = kWidePieces;
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    uint4* ring = lds;
+    float* table = reinterpret_cast<float*>(ring + D * kWideSlot);
+    float* wh_s = table + kWideMaxHidden * H;
+    float* bh_s = wh_s + 4 * H;
+    uint32_t* bits_s = reinterpret_cast<uint32_t*>(table + kWideTable);       // [layer][wave][64 lanes][2 words]
+    double* red_s = reinterpret_cast<double*>(bits_s + kWideMaxHidden * WPW * 64 * 2);
+    const int n_hh = a.n_hh;
+    const int n_blocks = 2 + n_hh * NT * (kTrain ? 2 : 1);                    // blocks per round (the same sequence every round)
+    const uint4* wfrag = a.stream;
+    const int64_t rows = a.rows;
+    const int64_t n_rounds = (rows + 63) / 64;
+    F32Loss L = a.loss;                                                       // (a local copy: scalars in registers, not a re-read kernarg)
+    if constexpr (kTrain) {
+        f32_loss_from_device(L);
+        TG_CLOCK_PROBE_BEGIN(g_probe_f32_wide)
+    }
+    // a.acts[l] / a.dz[l] with a run-time l would put the whole argument struct into scratch: uniform selects instead
+    auto pick = [](float* const (&p)[kWideMaxHidden], int l) {
+        float* r = p[0];
+#pragma unroll
+        for (int q = 1; q < kWideMaxHidden; ++q) r = l == q ? p[q] : r;
+        return r;
+    };
+    for (int q = tid; q < kWideTable; q += 256) table[q] = a.table[q];
+
+    // ---- ring prologue: blocks 0 .. P-1 in flight ----
+    int pre_pos = 0, pre_slot = 0, cur_slot = 0;
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+        ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
+        pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
+    }
+    __syncthreads();                                                          // (the tables; drains the prologue's DMA too: once)
+    // counted wait for the block about to be consumed: behind its DMA there are always the (P - 1) x KS / WPW pieces of the later
+    // blocks; the activation stores issued in between are not counted (a store-free stretch -- the first layer, the head -- must
+    // not let the wait pass early), so a wait also retires the stores of the block before last: they have had a block to complete
+    constexpr int kWait = (P - 1) * (KS / WPW);
+
+    auto relu_bits4 = [&](f32x4& v) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m |= (v[r] > 0.0f ? 1u : 0u) << r;
+            v[r] = fmaxf(v[r], 0.0f);
+        }
+        return m;
+    };
+    // one 16-feature output tile against a whole H-wide operand: 64 products, the lane's A operands 16 B at a time
+    // (the A operands of pieces t + 2, t + 3 are requested before the products of pieces t, t + 1 are issued: an LDS round trip is
+    // ~100 cycles, eight products 256)
+    auto tile_products = [&](const uint4* __restrict__ cur, const f32x4 (&xin)[NT], f32x4 acc) {
+        const uint4* __restrict__ p = cur + lane;
+        uint4 wa = wide_lds_u4(p), wb = wide_lds_u4(p + 64);
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+            uint4 na = wa, nb = wb;
+            if (t + 2 < NT) { na = wide_lds_u4(p + (t + 2) * 64); nb = wide_lds_u4(p + (t + 3) * 64); }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), xin[t][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), xin[t][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), xin[t][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), xin[t][3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t + 1][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t + 1][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t + 1][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t + 1][3], acc, 0, 0, 0);
+            wa = na; wb = nb;
+        }
+        // pin that order (hipcc otherwise sinks every read to just in front of its products): 4 reads, then 8 products + the 2 reads
+        // of the group after next, ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < NT / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            if (i + 2 < NT / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        return acc;
+    };
+    auto bits_slot = [&](int layer) { return bits_s + ((layer * WPW + wave) * 64 + lane) * 2; };
+    auto store_tile = [&](float* gptr, int64_t row, int mo, const f32x4& v) {
+        *reinterpret_cast<float4*>(gptr + row * H + 16 * mo + 4 * g) = float4{v[0], v[1], v[2], v[3]};
+    };
+
+    double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
+
+    for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+        const int64_t row = round * 64 + wave * 16 + j;
+        const bool valid = row < rows;
+        const int64_t rowc = valid ? row : rows - 1;
+        f32x4 xin[NT], xout[NT];
+        uint32_t mb0 = 0, mb1 = 0;                       // this layer's ReLU mask bits: tile t -> bits 4 (t & 7) .. + 3 of word t >> 3
+
+        // ---- layer 0: K padded to 32 in the stream (8 steps per tile); lane group g holds x[8 g .. 8 g + 8) ----
+        {
+            float xr[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                // (no load under a branch: clamped address, select)
+                const int c0 = 8 * g + 4 * q;
+                const bool in = c0 < a.in_pad;
+                const float4 v = *reinterpret_cast<const float4*>(a.x + rowc * a.in_pad + (in ? c0 : 0));
+                xr[4 * q] = in ? v.x : 0.f; xr[4 * q + 1] = in ? v.y : 0.f; xr[4 * q + 2] = in ? v.z : 0.f; xr[4 * q + 3] = in ? v.w : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                TG_RING_ADVANCE(kWait)
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) {
+                    const int mo = 8 * b + tt;
+                    const float4 b4 = wide_lds_f4(table + 16 * mo + 4 * g);
+                    f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint4 w4 = wide_lds_u4(cur + (2 * tt + q) * 64 + lane);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w4.x), xr[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w4.y), xr[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w4.z), xr[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w4.w), xr[4 * q + 3], acc, 0, 0, 0);
+                    }
+                    const uint32_t m = relu_bits4(acc);
+                    if (mo < 8) mb0 |= m << (4 * mo); else mb1 |= m << (4 * (mo - 8));
+                    xin[mo] = acc;
+                    if constexpr (kTrain) {
+                        if (valid && a.acts[0] != nullptr) store_tile(a.acts[0], row, mo, acc);
+                    }
+                }
+            }
+            if constexpr (kTrain) wide_lds_st2(bits_slot(0), uint2{mb0, mb1});
+        }
+        // ---- hidden H x H layers: one streamed block per 16 output features ----
+        for (int l = 1; l <= n_hh; ++l) {
+            mb0 = mb1 = 0;
+            const float* bias_l = table + l * H + 4 * g;
+            float* act_l = kTrain ? pick(a.acts, l) : nullptr;
+#pragma unroll
+            for (int mo = 0; mo < NT; ++mo) {
+                TG_RING_ADVANCE(kWait)
+                const float4 b4 = wide_lds_f4(bias_l + 16 * mo);
+                f32x4 acc = tile_products(cur, xin, f32x4{b4.x, b4.y, b4.z, b4.w});
+                const uint32_t m = relu_bits4(acc);
+                if (mo < 8) mb0 |= m << (4 * mo); else mb1 |= m << (4 * (mo - 8));
+                xout[mo] = acc;
+                if constexpr (kTrain) {
+                    if (valid) store_tile(act_l, row, mo, acc);
+                }
+            }
+            if constexpr (kTrain) wide_lds_st2(bits_slot(l), uint2{mb0, mb1});
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xin[t] = xout[t];
+        }
+        // ---- head: <= 4 outputs as fp32 dot products over the lane's 64 features, the four lane groups added in a fixed order ----
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const int A = kTrain ? L.A : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < A) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
+                    s = fmaf(xin[t][0], w.x, s);
+                    s = fmaf(xin[t][1], w.y, s);
+                    s = fmaf(xin[t][2], w.z, s);
+                    s = fmaf(xin[t][3], w.w, s);
+                }
+                // (g0 + g1) + (g2 + g3): every lane group ends up with the same bits
+                const float p1 = __shfl_xor(s, 16, 64);
+                const float pair = (g & 1) ? p1 + s : s + p1;
+                const float p2 = __shfl_xor(pair, 32, 64);
+                o[k] = ((g & 2) ? p2 + pair : pair + p2) + wide_lds_f(bh_s + k);
+            }
+        if constexpr (!kTrain) {
+            if (valid && g == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
+        } else {
+            float gr[4], c_surr, c_crit, c_kl;
+            f32_loss_row(L, o, row, rowc, valid, g == 0, gr, c_surr, c_crit, c_kl);
+            if (valid && g == 0) {
+                s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
+                *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{gr[0], gr[1], gr[2], gr[3]};
+            }
+            // ---- backward: dZ_top = (g . W_head) * (a_top > 0), then dZ_below = (W^T . dZ) * mask per layer, top down ----
+            // (mb0 / mb1 still hold the top layer's mask bits)
+            float* dz_top = pick(a.dz, n_hh);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t mw = (t < 8 ? mb0 >> (4 * t) : mb1 >> (4 * (t - 8)));
+                float4 s = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < L.A) {
+                        const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
+                        s.x = fmaf(gr[k], w.x, s.x); s.y = fmaf(gr[k], w.y, s.y); s.z = fmaf(gr[k], w.z, s.z); s.w = fmaf(gr[k], w.w, s.w);
+                    }
+                f32x4 d;
+                d[0] = (mw & 1u) ? s.x : 0.f;
+                d[1] = (mw & 2u) ? s.y : 0.f;
+                d[2] = (mw & 4u) ? s.z : 0.f;
+                d[3] = (mw & 8u) ? s.w : 0.f;
+                xin[t] = d;
+                if (valid && dz_top != nullptr) store_tile(dz_top, row, t, d);
+            }
+            for (int l = n_hh; l >= 1; --l) {
+                const uint2 mk = wide_lds_u2(bits_slot(l - 1));
+                float* dz_l = pick(a.dz, l - 1);
+#pragma unroll
+                for (int ko = 0; ko < NT; ++ko) {
+                    TG_RING_ADVANCE(kWait)
+                    f32x4 acc = tile_products(cur, xin, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const uint32_t mw = (ko < 8 ? mk.x >> (4 * ko) : mk.y >> (4 * (ko - 8)));
+                    acc[0] = (mw & 1u) ? acc[0] : 0.f;
+                    acc[1] = (mw & 2u) ? acc[1] : 0.f;
+                    acc[2] = (mw & 4u) ? acc[2] : 0.f;
+                    acc[3] = (mw & 8u) ? acc[3] : 0.f;
+                    xout[ko] = acc;
+                    if (valid) store_tile(dz_l, row, ko, acc);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xin[t] = xout[t];
+            }
+        }
+    }
+    // the ring's prefetches of a round that never came: let them land before the workgroup's LDS goes away
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (kTrain) {
+        // loss sums: lanes -> wave (fixed shuffle tree) -> workgroup (waves in order): deterministic
+        double v[4] = {s_surr, s_crit, s_kl, s_cnt};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red_s[wave * 4 + k] = v[k];
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double t = 0.0;
+            for (int w = 0; w < WPW; ++w) t += red_s[w * 4 + tid];
+            L.work[(int64_t)blockIdx.x * 4 + tid] = t;
+        }
+        TG_CLOCK_PROBE_END(g_probe_f32_wide)
+    }
+}
+
+static int f32_wide_grid(int64_t rows) {
+    const int64_t n_rounds = ceil_div(rows, 64);
+    const int slots = 2 * device_cus();
+    return (int)(n_rounds < slots ? n_rounds : slots);
+}
+
+template <bool kTrain>
+static int launch_f32_wide(const F32WideArgs& args, hipStream_t st) {
+    auto kern = mlp_f32_wide_kernel<kTrain>;
+    const size_t shmem = f32_wide_lds();
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32w_forward")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)f32_wide_grid(args.rows)), dim3(256), shmem, st, args);
+    TG_LAUNCH_CHECK("tg_mlp_f32w_forward");
+    return TG_OK;
+}
+
+static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers,
+                         int64_t rows, const char* what) {
+    if (!(n_hidden_layers >= 1 && n_hidden_layers <= kWideMaxHidden))
+        return set_error(TG_ERR_ARG, "%s: %d hidden layers outside 1..%d", what, n_hidden_layers, kWideMaxHidden);
+    if (!(in_pad >= 8 && in_pad <= 32 && in_pad % 8 == 0)) return set_error(TG_ERR_ARG, "%s: padded input width %d (a multiple of 8, <= 32)", what, in_pad);
+    if (!d_x || !d_stream || !d_table) return set_error(TG_ERR_ARG, "%s: null pointer", what);
+    if (rows < 0) return set_error(TG_ERR_ARG, "%s: negative row count", what);
+    if (((uintptr_t)d_x | (uintptr_t)d_stream) & 15) return set_error(TG_ERR_ARG, "%s: input / stream not 16-B aligned", what);
+    a.x = d_x; a.in_pad = in_pad; a.n_hh = n_hidden_layers - 1; a.rows = rows;
+    a.stream = reinterpret_cast<const uint4*>(d_stream); a.table = d_table;
+    return TG_OK;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_mlp_f32w_blocks(void) { return 2 * device_cus(); }
+
+int64_t tg_mlp_f32w_stream_floats(int32_t n_hidden_layers) { return (int64_t)(2 + 2 * (n_hidden_layers - 1) * (kWideH / 16)) * kWidePieces * 256; }
+
+int64_t tg_mlp_f32w_table_floats(void) { return kWideTable; }
+
+int tg_mlp_f32w_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers, int64_t rows,
+                        float* d_out, void* stream) {
+    F32WideArgs a{};
+    if (int rc = fill_f32_wide(a, d_x, in_pad, d_stream, d_table, n_hidden_layers, rows, "tg_mlp_f32w_forward")) return rc;
+    TG_REQUIRE(d_out, "tg_mlp_f32w_forward: null output");
+    if (rows == 0) return TG_OK;
+    a.out = d_out;
+    return launch_f32_wide<false>(a, (hipStream_t)stream);
+}
+
+int tg_mlp_f32w_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers,
+                                 int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream) {
+    F32WideArgs a{};
+    if (int rc = fill_f32_wide(a, d_x, in_pad, d_stream, d_table, n_hidden_layers, rows, "tg_mlp_f32w_forward_backward")) return rc;
+    TG_REQUIRE(loss && d_acts && d_dz, "tg_mlp_f32w_forward_backward: null pointer");
+    TG_REQUIRE(loss->d_dout8 && loss->d_work, "tg_mlp_f32w_forward_backward: loss outputs missing");
+    TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_f32w_forward_backward: %d outputs (1..4)", loss->act_dim);
+    TG_REQUIRE(loss->kind == 1 ? (loss->d_ret != nullptr && loss->act_dim == 1)
+                               : (loss->d_act && loss->d_adv && (loss->d_logp_old || loss->d_logp_old_out) && loss->act_row_stride == loss->act_dim &&
+                                  loss->act_col_stride == 1),
+               "tg_mlp_f32w_forward_backward: loss inputs missing (the actions must be contiguous [rows][A])");
+    if (rows == 0) return TG_OK;
+    for (int l = 0; l < n_hidden_layers; ++l) {
+        TG_REQUIRE((d_acts[l] || l == 0) && (d_dz[l] || l == n_hidden_layers - 1), "tg_mlp_f32w_forward_backward: buffer %d is null", l);
+        a.acts[l] = (float*)d_acts[l];
+        a.dz[l] = (float*)d_dz[l];
+    }
+    fill_f32_loss(a.loss, loss);
+    return launch_f32_wide<true>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

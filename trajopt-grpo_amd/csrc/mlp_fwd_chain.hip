@@ -49,6 +49,8 @@ struct ChainLoss {                          // (kept small: every field is a sca
     const float* logp_old; const float* adv;
     float n_m, n_i;                         // normalisation of the advantage (actor) / return (critic): (x - n_m) * n_i
     float inv_var[4]; float logp_const, epsilon, surr_coef, critic_coef, kl_coef;
+    const float* norm8;                     // non-null: n_m / n_i and the three coefficients come from this device f32 [8] (tg_ppo_norm's
+                                            // output: PPO's normalisation constants and 1 / n never visit the host), read once at entry
     uint16_t* dout8;                        // out: d loss / d head output, bf16 [rows][8], zero padded (tg_mlp_backward_chain's input)
     float* head_slabs;                      // out: f32 [grid][4][16][H] partial head weight gradients
     double* work;                           // out: f64 [grid][4] partial loss sums (surrogate, squared error, KL, count)
@@ -219,6 +221,13 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                                                                     ChainActs acts, float* __restrict__ out, int32_t out_cols,
                                                                     ChainLoss L) {
     static_assert(!kHead || (kStore && !kA0), "the fused head belongs to the learner's training pass");
+    if constexpr (kHead) {
+        if (L.norm8 != nullptr) {                                       // (uniform scalar loads, before anything is in flight)
+            const int q = L.kind == 1 ? 2 : 0;
+            L.n_m = L.norm8[q]; L.n_i = L.norm8[q + 1];
+            L.surr_coef = L.norm8[4]; L.critic_coef = L.norm8[5]; L.kl_coef = L.norm8[6];
+        }
+    }
     constexpr int MT = H / 32, KS = H / 16, K8 = H / 32;               // blocks per layer, 1-KiB pieces per block, k-steps per block
     constexpr int P = D - 1;
     // counted wait for block c: all but the youngest N vector-memory operations have retired.  Behind DMA(c) there are
@@ -665,7 +674,7 @@ int tg_mlp_forward_chain_loss(const void* d_x, const void* d_wfrag, const float*
         L.kind = 2;
         L.logp_old = loss->d_logp_old_out;
     }
-    L.n_m = loss->norm_mean; L.n_i = loss->norm_inv;
+    L.n_m = loss->norm_mean; L.n_i = loss->norm_inv; L.norm8 = loss->d_norm8;
     float logdet = 0.f;
     for (int k = 0; k < 4; ++k) {
         L.inv_var[k] = k < loss->act_dim ? 1.0f / loss->var[k] : 0.f;

@@ -90,12 +90,11 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__
     }
 }
 
-// per-env masked partial moments (count, sum, sum of squares) in fp64
-__global__ __launch_bounds__(256) void env_moments_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
-                                                          int64_t n, int32_t T, double* __restrict__ work) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double cnt = 0, s1 = 0, s2 = 0;
+// one env's masked moments (count, sum, sum of squares) in fp64, ascending time: the ONE body behind env_moments_kernel and
+// ppo_returns_kernel (their sums must agree bit for bit)
+__device__ static inline void lane_moments(const float* x, const uint8_t* __restrict__ mask, int64_t n, int32_t T, int64_t i,
+                                           double& cnt, double& s1, double& s2) {
+    cnt = 0, s1 = 0, s2 = 0;
     for (int32_t t0 = 0; t0 < T; t0 += kChunk) {
         const int32_t c = (T - t0) < kChunk ? (T - t0) : kChunk;
         float v[kChunk];
@@ -116,9 +115,102 @@ __global__ __launch_bounds__(256) void env_moments_kernel(const float* __restric
             }
         }
     }
+}
+
+// per-env masked partial moments (count, sum, sum of squares) in fp64
+__global__ __launch_bounds__(256) void env_moments_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                          int64_t n, int32_t T, double* __restrict__ work) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double cnt, s1, s2;
+    lane_moments(x, mask, n, T, i, cnt, s1, s2);
     work[i] = cnt;
     work[n + i] = s1;
     work[2 * n + i] = s2;
+}
+
+// PPO's advantages and returns with their per-env moments in ONE launch (algorithms/ppo.py:100-124, :138-139): what
+// tg_rtg_scan + `rtg - V` (Monte Carlo) or tg_gae_scan, followed by the env stage of tg_masked_moments on each of the two, computes
+// -- the same operations in the same order, so the same bits.  A lane owns an env: the backward recurrence writes adv / ret
+// [T][n], then the lane reads its own column back in ascending time for the fp64 sums (same-thread store -> load: program order).
+// work: f64 [3][2 n]: plane j = {count, sum, sum of squares}, advantages in columns [0, n), returns in [n, 2 n) -- the layout
+// group_moments_kernel reduces as two groups of n.
+template <bool kGae>
+__global__ __launch_bounds__(256) void ppo_returns_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                          const uint8_t* __restrict__ mask, float gamma, float lam, float* adv,
+                                                          float* ret, int64_t n, int32_t T, double* __restrict__ work) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float carry = 0.0f;      // Monte Carlo: (gamma * R[t+1]) * m[t+1]
+    float next_v_m = 0.0f;   // GAE: V[t+1] * m[t+1]
+    float next_a_m = 0.0f;   // GAE: (gamma*lam*A[t+1]) * m[t+1]
+    const float gl = rn_mul(gamma, lam);
+    for (int32_t t_hi = T; t_hi > 0; t_hi -= kChunk) {
+        const int32_t cnt = t_hi < kChunk ? t_hi : kChunk;
+        float r[kChunk], v[kChunk];
+        uint8_t m[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            if (k < cnt) {
+                const int64_t idx = (int64_t)(t_hi - 1 - k) * n + i;
+                r[k] = rew[idx];
+                v[k] = val[idx];
+                m[k] = mask[idx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            if (k < cnt) {
+                const int32_t t = t_hi - 1 - k;
+                const int64_t idx = (int64_t)t * n + i;
+                const float mf = (float)m[k];
+                if constexpr (kGae) {                            // gae_scan_kernel's step
+                    float a;
+                    if (t == T - 1) {
+                        a = rn_sub(r[k], v[k]);
+                    } else {
+                        const float delta = rn_sub(rn_add(r[k], rn_mul(gamma, next_v_m)), v[k]);
+                        a = rn_add(delta, next_a_m);
+                    }
+                    adv[idx] = a;
+                    ret[idx] = rn_add(v[k], a);
+                    next_v_m = rn_mul(v[k], mf);
+                    next_a_m = rn_mul(rn_mul(gl, a), mf);
+                } else {                                         // rtg_scan_kernel's step, then ppo.py:111's A = R - V
+                    const float R = rn_add(rn_mul(r[k], mf), carry);
+                    ret[idx] = R;
+                    adv[idx] = rn_sub(R, v[k]);
+                    carry = rn_mul(rn_mul(gamma, R), mf);
+                }
+            }
+        }
+    }
+    double c0, s1, s2;
+    lane_moments(adv, mask, n, T, i, c0, s1, s2);
+    work[i] = c0; work[2 * n + i] = s1; work[4 * n + i] = s2;
+    lane_moments(ret, mask, n, T, i, c0, s1, s2);
+    work[n + i] = c0; work[3 * n + i] = s1; work[5 * n + i] = s2;
+}
+
+// ppo.py:138-139 and the 1 / n of :165-179 on the device, from the (all-reduced) moments [2][3] = {count, sum, sum of squares} of
+// the valid advantages and returns: out f32 [8] = {adv mean, 1 / (adv std + 1e-8), ret mean, 1 / (ret std + 1e-8), -1 / n, c1 / n,
+// kl_coeff / n, n}.  torch's own sequence of fp64 / fp32 operations (unbiased std, clamped at 0; NaN for n < 2, like torch).
+__global__ void ppo_norm_kernel(const double* __restrict__ moments, double c1, double kl_coeff, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int q = 0; q < 2; ++q) {
+        const double cnt = moments[3 * q], s1 = moments[3 * q + 1], s2 = moments[3 * q + 2];
+        const double mean = s1 / cnt;
+        const double var = (s2 - s1 * mean) / (cnt - 1.0);
+        const float stdf = (float)sqrt(var < 0.0 ? 0.0 : var);            // (NaN stays NaN)
+        out[2 * q] = (float)mean;
+        out[2 * q + 1] = rn_div(1.0f, rn_add(stdf, 1e-8f));
+    }
+    const double n = moments[0];
+    out[4] = (float)(-1.0 / n);
+    out[5] = (float)(c1 / n);
+    out[6] = (float)(kl_coeff / n);
+    out[7] = (float)n;
 }
 
 // one workgroup per group: fixed-order reduction of the group's per-env partials
@@ -217,6 +309,33 @@ int tg_masked_moments(const float* d_x, const uint8_t* d_mask, int64_t n, int32_
     hipLaunchKernelGGL(group_moments_kernel, dim3((unsigned)(n / group_size)), dim3(256), 0, (hipStream_t)stream, d_work, n,
                        group_size, d_moments);
     TG_LAUNCH_CHECK("tg_masked_moments(group)");
+    return TG_OK;
+}
+
+int tg_ppo_returns(const float* d_rew, const float* d_values, const uint8_t* d_mask, float gamma, float lam, int monte_carlo,
+                   float* d_adv, float* d_ret, int64_t n, int32_t T, double* d_moments, double* d_work, void* stream) {
+    TG_REQUIRE(d_rew && d_values && d_mask && d_adv && d_ret && d_moments && d_work, "tg_ppo_returns: null pointer");
+    TG_REQUIRE(n > 0 && T > 0, "tg_ppo_returns: bad sizes n=%lld T=%d", (long long)n, T);
+    TG_REQUIRE(d_adv != d_ret, "tg_ppo_returns: adv and ret must be distinct buffers");
+    hipStream_t st = (hipStream_t)stream;
+    const int block = n <= ((int64_t)1 << 18) ? 64 : 256;
+    if (monte_carlo)
+        hipLaunchKernelGGL(ppo_returns_kernel<false>, dim3((unsigned)ceil_div(n, block)), dim3(block), 0, st, d_rew, d_values, d_mask, gamma,
+                           lam, d_adv, d_ret, n, T, d_work);
+    else
+        hipLaunchKernelGGL(ppo_returns_kernel<true>, dim3((unsigned)ceil_div(n, block)), dim3(block), 0, st, d_rew, d_values, d_mask, gamma,
+                           lam, d_adv, d_ret, n, T, d_work);
+    TG_LAUNCH_CHECK("tg_ppo_returns");
+    // the per-env partials as two groups of n (advantages | returns): tg_masked_moments' group stage, once
+    hipLaunchKernelGGL(group_moments_kernel, dim3(2), dim3(256), 0, st, d_work, 2 * n, n, d_moments);
+    TG_LAUNCH_CHECK("tg_ppo_returns(group)");
+    return TG_OK;
+}
+
+int tg_ppo_norm(const double* d_moments, double c1, double kl_coeff, float* d_norm8, void* stream) {
+    TG_REQUIRE(d_moments && d_norm8, "tg_ppo_norm: null pointer");
+    hipLaunchKernelGGL(ppo_norm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_moments, c1, kl_coeff, d_norm8);
+    TG_LAUNCH_CHECK("tg_ppo_norm");
     return TG_OK;
 }
 

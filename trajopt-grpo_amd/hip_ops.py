@@ -118,6 +118,58 @@ def learn_compact(traj, offsets, rows_cap: int, xin: torch.Tensor, ones_col: int
     N.check(N.load().tg_learn_compact(C.byref(a), _st(xin)), "tg_learn_compact")
 
 
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst.view(-1)[idx[r]] = src[r][0] (tg_scatter_rows): src f32 [rows][>= 1] with any row stride, idx int64 [rows], dst f32."""
+    N.require_cuda(src, idx, dst)
+    rows = idx.numel()
+    assert src.dtype == dst.dtype == torch.float32 and idx.dtype == torch.int64 and idx.is_contiguous() and dst.is_contiguous()
+    assert src.dim() == 2 and src.shape[0] >= rows
+    N.check(N.load().tg_scatter_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), rows, dst.data_ptr(), _st(dst)), "tg_scatter_rows")
+
+
+def ppo_returns(rew, values, mask, gamma: float, lam: float, monte_carlo: bool, adv: torch.Tensor, ret: torch.Tensor,
+                work: torch.Tensor = None) -> torch.Tensor:
+    """tg_ppo_returns: fills adv / ret f32 [T][n] (ppo.py:100-124) and returns the f64 [2][3] masked moments {count, sum, sum of
+    squares} of the advantages and of the returns -- bit-identical to rtg_scan / `rtg - values` / gae_scan + masked_moments(group = n)."""
+    N.require_cuda(rew, values, mask, adv, ret, work)
+    T, n = rew.shape
+    for t in (rew, values, adv, ret):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == T * n
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == T * n
+    if work is None:
+        work = torch.empty(6 * n, dtype=torch.float64, device=rew.device)
+    assert work.dtype == torch.float64 and work.numel() >= 6 * n
+    moments = torch.empty(2, 3, dtype=torch.float64, device=rew.device)
+    N.check(N.load().tg_ppo_returns(rew.data_ptr(), values.data_ptr(), mask.data_ptr(), float(gamma), float(lam), 1 if monte_carlo else 0,
+                                    adv.data_ptr(), ret.data_ptr(), n, T, moments.data_ptr(), work.data_ptr(), _st(rew)), "tg_ppo_returns")
+    return moments
+
+
+def ppo_norm(moments: torch.Tensor, c1: float, kl_coeff: float, out: torch.Tensor = None) -> torch.Tensor:
+    """tg_ppo_norm: f32 [8] = {adv mean, 1 / (adv std + 1e-8), ret mean, 1 / (ret std + 1e-8), -1 / n, c1 / n, kl_coeff / n, n} on the
+    device (what the loss heads read through `norm8=`)."""
+    N.require_cuda(moments, out)
+    assert moments.dtype == torch.float64 and moments.is_contiguous() and moments.numel() == 6
+    if out is None:
+        out = torch.empty(8, dtype=torch.float32, device=moments.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 8
+    N.check(N.load().tg_ppo_norm(moments.data_ptr(), float(c1), float(kl_coeff), out.data_ptr(), _st(moments)), "tg_ppo_norm")
+    return out
+
+
+def gather_rows2(idx: torch.Tensor, src0: torch.Tensor, dst0: torch.Tensor, src1: torch.Tensor = None, dst1: torch.Tensor = None) -> None:
+    """dst0[r] = src0.view(-1)[idx[r]] (and dst1 / src1): tg_gather_rows2."""
+    N.require_cuda(idx, src0, dst0, src1, dst1)
+    rows = idx.numel()
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    for s_, d_ in ((src0, dst0), (src1, dst1)):
+        assert (s_ is None) == (d_ is None)
+        if s_ is not None:
+            assert s_.dtype == d_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous() and d_.numel() >= rows
+    N.check(N.load().tg_gather_rows2(idx.data_ptr(), rows, src0.data_ptr(), dst0.data_ptr(), N.ptr(src1), N.ptr(dst1), _st(idx)),
+            "tg_gather_rows2")
+
+
 def _var_array(var):
     v = [float(x) for x in var]
     return (C.c_float * len(v))(*v), len(v)
@@ -140,10 +192,11 @@ def gaussian_logp(mean: torch.Tensor, act: torch.Tensor, var, out: torch.Tensor 
 
 
 def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilon, surr_coef, critic_coef, kl_coef,
-                   want_total: bool = True):
+                   want_total: bool = True, coef: torch.Tensor = None):
     """One launch of tg_surrogate_loss: returns (total f32 scalar, sums f64[4], d total/d mean, d total/d value|None).
-    want_total=False skips the handful of scalar launches that combine the sums (the learners only use the sums)."""
-    N.require_cuda(mean, act, logp_old, adv)
+    want_total=False skips the handful of scalar launches that combine the sums (the learners only use the sums).
+    coef: device f32 [3] {surr_coef, critic_coef, kl_coef} used instead of the three host numbers (PPO: tg_ppo_norm's output [4:7])."""
+    N.require_cuda(mean, act, logp_old, adv, coef)
     assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.stride(1) == 1
     M, A = mean.shape
     a = N.LossArgs()
@@ -157,6 +210,9 @@ def surrogate_loss(mean, value, act, logp_old, adv, ret, mask, norm, var, epsilo
         a.d_value, a.d_ret, a.d_grad_value = value.data_ptr(), ret.data_ptr(), grad_value.data_ptr()
     a.d_mask = N.ptr(mask)
     a.d_norm = N.ptr(norm)
+    if coef is not None:
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.numel() >= 3 and not want_total
+        a.d_coef = coef.data_ptr()
     va, k = _var_array(var)
     assert k == A
     for i in range(A):

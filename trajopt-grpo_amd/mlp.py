@@ -168,6 +168,8 @@ class GemmMLP:
         self.f32_store_all = False
         if compute_dtype == torch.float32 and f32_chain_supported(net):
             self._f32 = F32ChainStream(net, f32_chain_supported(net))
+        elif compute_dtype == torch.float32 and f32_wide_supported(net):
+            self._f32 = F32WideStream(net)                      # H = 256: csrc/mlp_f32_wide.hip
         self.in_pad = _round_up(self.in_dim, 32) if self._f32 is None else self._f32.in_pad
         self.out_pad = _round_up(self.out_dim, 8)
         self.w, self.b = [], []
@@ -236,12 +238,14 @@ class GemmMLP:
         if shape in _LOGGED_SHAPES:
             return
         _LOGGED_SHAPES.add(shape)
-        if self._f32 is not None:
+        if self._f32 is not None and self._f32.wide:
+            _LOG.info("%s: fp32 chain learner at H = 256 (tg_mlp_f32w_forward / _forward_backward; weight gradients: split-K GEMMs)", shape)
+        elif self._f32 is not None:
             _LOG.info("%s: fp32 chain learner (tg_mlp_f32_forward / _forward_backward / _weight_grad)", shape)
         elif self._chain is not None and self._bchain is not None:
             _LOG.info("%s: bf16 chain kernels (tg_mlp_forward_chain[_loss] / tg_mlp_backward_chain / tg_mlp_weight_grad)", shape)
         else:
-            why = ("fp32 chain learner: hidden width 64 / 128, 1-4 equal hidden layers, <= 32 inputs, <= 4 outputs"
+            why = ("fp32 chain learners: hidden width 64 / 128 with 1-4 equal hidden layers or 256 with 1-5, <= 32 inputs, <= 4 outputs"
                    if self.cd == torch.float32 else
                    "bf16 chain kernels: hidden width 128 / 256, 3-6 equal hidden layers, <= 32 inputs, <= 8 outputs"
                    + ("; the forward chain alone covers this net" if self._chain is not None else ""))
@@ -340,8 +344,12 @@ class GemmMLP:
             f = self._f32
             assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
             out = torch.empty(xp.shape[0], 4, dtype=torch.float32, device=xp.device)
-            N.check(N.load().tg_mlp_f32_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.H, f.n_hidden, xp.shape[0],
-                                                out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32_forward")
+            if f.wide:
+                N.check(N.load().tg_mlp_f32w_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.table.data_ptr(), f.n_hidden, xp.shape[0],
+                                                     out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32w_forward")
+            else:
+                N.check(N.load().tg_mlp_f32_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.H, f.n_hidden, xp.shape[0],
+                                                    out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32_forward")
             self._acts = self._bits = None
             return out if padded else out[:, :self.out_dim].contiguous()
         if self._chain is not None and xp.shape[0] > 0:
@@ -400,16 +408,18 @@ class GemmMLP:
 
     @torch.no_grad()
     def forward_loss(self, xp: torch.Tensor, kind: int, *, act=None, logp_old=None, adv=None, ret=None, norm=None, var=None,
-                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0, sums_out=None, logp_old_out=None) -> torch.Tensor:
+                     epsilon=0.0, surr_coef=0.0, critic_coef=0.0, kl_coef=0.0, sums_out=None, logp_old_out=None, norm8=None) -> torch.Tensor:
         """Training forward pass with the loss head inside it (kind 0: actor, clipped surrogate; kind 1: critic, squared error).
         Stores what backward_fused() needs, adds the head's weight / bias gradient into their windows and returns the f64 sums
         [surrogate, squared error, KL, count] of these rows -- or, given `sums_out` (f64 [4] on the device), ADDS them there and
         returns None; on the fp32 chain learner that addition rides on backward_fused()'s reduction launch (no launches of its own),
-        so `sums_out` is complete once backward_fused() has been enqueued."""
+        so `sums_out` is complete once backward_fused() has been enqueued.
+        norm8: device f32 [8] (hip_ops.ppo_norm): the normalisation pair and the three coefficients are read from it on the device;
+        `norm` and the `*_coef` arguments are then ignored."""
         lib = N.load()
         if self._f32 is not None:
             return self._forward_loss_f32(xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out,
-                                          logp_old_out)
+                                          logp_old_out, norm8)
         self._flush_riders()                 # (a forward_loss() that was never followed by backward_fused(): its head gradient is due)
         self._fresh("chain")
         L = len(self.linears)
@@ -425,7 +435,7 @@ class GemmMLP:
         slabs, work, bpart = self._head_ws
         # (norm = host pair (mean, 1 / (std + eps)) of the advantage / return, or None; logp_old_out: the old policy is the current
         # one -- this pass writes the old log-probabilities instead of reading them)
-        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out)
+        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out, norm8)
         a.d_dout8, a.d_head_slabs, a.d_work, a.d_bias_partial = dz_head.data_ptr(), slabs.data_ptr(), work.data_ptr(), bpart.data_ptr()
         ptrs = (N.C.c_void_p * (L - 1))(*[N.ptr(t) or None for t in hid])
         mptrs = (N.C.c_void_p * (L - 1))(*[t.data_ptr() for t in bits])
@@ -467,8 +477,13 @@ class GemmMLP:
             work, n, sums = loss_rider
             sums += work[:n * 4].view(n, 4).sum(0)
 
-    def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out=None) -> "N.ChainLoss":
+    def _loss_args(self, kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out=None,
+                   norm8=None) -> "N.ChainLoss":
         a = N.ChainLoss()
+        if norm8 is not None:
+            N.require_cuda(norm8)
+            assert norm8.dtype == torch.float32 and norm8.is_contiguous() and norm8.numel() == 8
+            a.d_norm8 = norm8.data_ptr()
         a.kind, a.act_dim = kind, self.out_dim
         if kind == 0:
             N.require_cuda(act, logp_old, adv, logp_old_out)
@@ -499,7 +514,7 @@ class GemmMLP:
         return self.can_fuse_head()
 
     def _forward_loss_f32(self, xp, kind, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, sums_out=None,
-                          logp_old_out=None):
+                          logp_old_out=None, norm8=None):
         """forward_loss() of an fp32 net: forward + loss head + backward-data pass in ONE launch (tg_mlp_f32_forward_backward);
         every hidden layer's activation and dZ is written for backward_fused() (tg_mlp_f32_weight_grad)."""
         lib = N.load()
@@ -509,15 +524,16 @@ class GemmMLP:
         assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
         # with >= 2 hidden layers the first activation and the top layer's dZ are neither written nor read: the weight-gradient job
         # that needs them rebuilds them from the input row / from d loss / d output + the top layer's mask bits (16 B per row)
-        rec = nh >= 2 and not self.f32_store_all
+        # (the H = 256 learner has no weight-gradient job of its own yet: everything is stored, the gradients are split-K GEMMs)
+        rec = nh >= 2 and not self.f32_store_all and not f.wide
         acts = [None if (rec and i == 0) else self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
         dzs = [None if (rec and i == nh - 1) else self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
         tmask = self._ws.get("fmask", rows, 4, torch.int32, dev) if rec else None
         dout = self._ws.get("fz_head", rows, 4, torch.float32, dev)
-        nblk = lib.tg_mlp_f32_blocks()
+        nblk = lib.tg_mlp_f32w_blocks() if f.wide else lib.tg_mlp_f32_blocks()
         if self._head_ws is None:
             self._head_ws = torch.empty(nblk * 4, dtype=torch.float64, device=dev)
-        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out)
+        a = self._loss_args(kind, rows, act, logp_old, adv, ret, norm, var, epsilon, surr_coef, critic_coef, kl_coef, logp_old_out, norm8)
         a.d_dout8, a.d_work = dout.data_ptr(), self._head_ws.data_ptr()
         ptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in acts])
         zptrs = (N.C.c_void_p * nh)(*[N.ptr(t) for t in dzs])
@@ -525,15 +541,19 @@ class GemmMLP:
         if self.fwd_events is not None:
             ev = N.event_pair()
             ev[0].record()
-        N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.ptr(tmask),
-                                                N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
+        if f.wide:
+            N.check(lib.tg_mlp_f32w_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.table.data_ptr(), nh, rows, ptrs, zptrs,
+                                                     N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32w_forward_backward")
+        else:
+            N.check(lib.tg_mlp_f32_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), H, nh, rows, ptrs, zptrs, N.ptr(tmask),
+                                                    N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32_forward_backward")
         if ev is not None:
             ev[1].record()
             # matrix-core flops per row: first layer + forward and backward products of the H x H layers (head: vector unit)
             # algorithmic flops per row (un-padded): forward first layer + H x H layers + head, backward head + H x H layers
             self.fwd_events.append((ev[0], ev[1], rows, 2 * H * self.in_dim + 4 * (nh - 1) * H * H + 4 * H * self.out_dim,
-                                    f"tg::mlp_f32_chain_kernel<{H},true>"))
-        grid = min(nblk, -(-rows // 256))
+                                    "tg::mlp_f32_wide_kernel<true>" if f.wide else f"tg::mlp_f32_chain_kernel<{H},true>"))
+        grid = min(nblk, -(-rows // (64 if f.wide else 256)))
         self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
         assert getattr(self, "_loss_rider", None) is None, "forward_loss(sums_out=...) must be followed by backward_fused()"
         if sums_out is not None:
@@ -546,6 +566,29 @@ class GemmMLP:
         f = self._f32
         xp, acts, dzs, dout = self._acts[0], self._acts[1:], self._bits, self._dz_head
         rows, H, nh, lin = xp.shape[0], f.H, f.n_hidden, self.linears
+        if f.wide:
+            # interim: the weight gradients of the H = 256 fp32 learner as split-K GEMMs over the stored operands (hipBLASLt) -- the
+            # chain kernel is this tree's, the dW job is not written yet
+            assert adam is None
+            rider = getattr(self, "_loss_rider", None)
+            self._loss_rider = None
+            if rider is not None:
+                rider[1].add_(self._head_ws[:rider[0] * 4].view(rider[0], 4).sum(0))
+            ev = None
+            if self.dw_events is not None:
+                ev = N.event_pair()
+                ev[0].record()
+            for i in range(nh):
+                self._dw_into(lin[i].weight.grad, dzs[i], xp if i == 0 else acts[i - 1])
+                lin[i].bias.grad.add_(dzs[i].sum(0))
+            self._dw_into(lin[nh].weight.grad, dout, acts[nh - 1])
+            lin[nh].bias.grad.add_(dout[:, :self.out_dim].sum(0))
+            if ev is not None:
+                ev[1].record()
+                self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * self.in_dim + 2 * H * self.out_dim,
+                                       "hipBLASLt split-K GEMMs (mlp_f32 wide learner, interim)"))
+            self._acts = self._bits = self._dz_head = self._tmask = None
+            return
         if nh == 1:
             assert acts[0] is not None and dzs[0] is not None
         if self._dw_ws is None:
@@ -1052,7 +1095,89 @@ def f32_chain_supported(net) -> int:
     return H
 
 
+def f32_wide_supported(net) -> int:
+    """256 if `net` is Linear(S<=32, 256) ReLU [Linear(256, 256) ReLU]{0..4} Linear(256, A<=4) -- the reference's QuadPole factory
+    (pipelines/quadpole_pipeline_ppo.py:54-58: 20-256x5-{4,1}) -- else 0."""
+    if not supports(net):
+        return 0
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
+    if H != 256 or not (1 <= len(lin) - 1 <= 5) or lin[0].in_features > 32 or lin[-1].out_features > 4:
+        return 0
+    if any(l.out_features != H for l in lin[:-1]) or any(l.in_features != H for l in lin[1:]):
+        return 0
+    return H
+
+
+class F32WideStream:
+    """The fp32 weight stream + tables of the H = 256 chain learner (csrc/mlp_f32_wide.hip), refreshed from the master weights with ONE
+    gather.  16-KiB blocks of 16 pieces x 64 lanes x 16 B, lane = (i = lane & 15, g = lane >> 4); a lane's 16 B are four consecutive
+    floats of a weight row (forward) or of a weight column (backward):
+      first layer, 2 blocks: block b, piece 2 tt + q:     W0[16 (8 b + tt) + i][8 g + 4 q + e]      (zero beyond the inputs)
+      forward, layer l = 1 .. nh - 1, block mo, piece t:  W_l[16 mo + i][16 t + 4 g + e]
+      backward, layer l = nh - 1 .. 1, block ko, piece t: W_l[16 t + 4 g + e][16 ko + i]
+    then the tables: [5][256] hidden biases | [4][256] head weights (rows >= A zero) | [4] head bias | 12 zeros."""
+    wide = True
+
+    def __init__(self, net):
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        self.lin, self.H = lin, 256
+        H = 256
+        dev = lin[0].weight.device
+        nh = len(lin) - 1
+        self.n_hidden, self.in_dim, self.out_dim = nh, lin[0].in_features, lin[-1].out_features
+        self.in_pad = _round_up(self.in_dim, 8)
+        woff, off = [], 0
+        for l in lin:
+            woff.append(off)
+            off += l.weight.numel()
+        boff = []
+        for l in lin:
+            boff.append(off)
+            off += l.bias.numel()
+        zero_at = off
+        lane = torch.arange(64, device=dev).view(1, 64, 1)
+        i, g = lane & 15, lane >> 4
+        e = torch.arange(4, device=dev).view(1, 1, 4)
+        idx = []
+        # first layer: 16 tiles x 2 pieces
+        q = torch.arange(2, device=dev).view(2, 1, 1)
+        for mo in range(16):
+            col = (8 * g + 4 * q + e).expand(2, 64, 4)
+            src = woff[0] + (16 * mo + i) * self.in_dim + col
+            idx.append(torch.where(col < self.in_dim, src, torch.full_like(src, zero_at)).reshape(-1))
+        t = torch.arange(16, device=dev).view(16, 1, 1)
+        k = (16 * t + 4 * g + e).expand(16, 64, 4)                                   # the contraction index of piece t, lane group g
+        for l in range(1, nh):                                                       # forward: W_l[16 mo + i][k]
+            for mo in range(16):
+                idx.append((woff[l] + (16 * mo + i) * H + k).reshape(-1))
+        for l in range(nh - 1, 0, -1):                                               # backward: W_l[k][16 ko + i]
+            for ko in range(16):
+                idx.append((woff[l] + k * H + (16 * ko + i)).reshape(-1))
+        n_stream = sum(x.numel() for x in idx)
+        for l in range(5):
+            idx.append(boff[l] + torch.arange(H, device=dev) if l < nh else torch.full((H,), zero_at, device=dev))
+        for a in range(4):
+            idx.append(woff[nh] + a * H + torch.arange(H, device=dev) if a < self.out_dim else torch.full((H,), zero_at, device=dev))
+        idx.append(torch.tensor([boff[nh] + a if a < self.out_dim else zero_at for a in range(4)] + [zero_at] * 12, device=dev))
+        self._idx = torch.cat([x.reshape(-1) for x in idx])
+        lib = N.load()
+        assert n_stream == lib.tg_mlp_f32w_stream_floats(nh) and self._idx.numel() - n_stream == lib.tg_mlp_f32w_table_floats()
+        self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.stream = torch.empty(self._idx.numel(), dtype=torch.float32, device=dev)          # blocks, then the tables
+        self.table = self.stream[n_stream:]
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Two launches: concatenate the master tensors, gather."""
+        src = torch.cat([l.weight.reshape(-1) for l in self.lin] + [l.bias for l in self.lin] + [self._zero])
+        torch.index_select(src if src.dtype == torch.float32 else src.float(), 0, self._idx, out=self.stream)
+
+
 class F32ChainStream:
+    wide = False
+
     """The fp32 weight stream of the chain learner, refreshed from the master weights with ONE gather:
       [first layer, MFMA fragment order: H/32 tiles x k2/4 groups x 64 lanes x 4]  lane (i, kk), step s = 4 g + e of tile mo holds
                                                                                  W0[32 mo + i][s + kk k2]   (k2 = in_pad / 2)
