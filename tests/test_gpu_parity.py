@@ -2303,7 +2303,7 @@ def test_f32_chain_update_matches_fp64_autograd(tg, dev, dims, kind, rows, monke
     assert torch.equal(sr, s) and torch.equal(dout_r, dout)
     assert all(torch.equal(a, b) for a, b in zip(got_r, got_r2))
     n_hidden = len(hidden)
-    wide = hidden[0] == 256                                             # (the H = 256 learner stores everything: its weight gradients are GEMMs for now)
+    wide = hidden[0] == 256                                             # (the H = 256 learner stores everything: its weight-gradient jobs rebuild nothing yet)
     if n_hidden >= 2 and not wide:
         # neither the first activation nor the top dZ was written; everything in between is the same bits as in the storing run.
         # The top layer's mask travels as 4 words per row: feature 32 mt + 8 q + 4 hh + low <-> word hh * (H / 64) + mt // 2,
@@ -2659,7 +2659,7 @@ def test_learn_at_chain_kernel_shapes_matches_reference(tg, dev, kind, tag, S, A
     The FIRST update's gradients are taken on the reference's own initial weights: one forward / backward pass, nothing else.
       fp32: h128 (5-128x4) runs on the fp32 chain learner (tg_mlp_f32_forward_backward / tg_mlp_f32_weight_grad -- asserted
         below: a gate that regresses must not silently re-test hipBLASLt), h256 on the H = 256 chain learner (tg_mlp_f32w_forward_backward; its weight gradients are
-        still split-K GEMMs).  First gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on the GPU sits at
+        are tg_mlp_f32_weight_grad jobs).  First gradients within 1e-2 in L2 per tensor and 1e-4 in the median -- torch autograd on the GPU sits at
         the same 3-5e-3 in three critic layers (a ReLU that flips for one row between the CPU's and the GPU's summation
         order), everything else at 1e-6; post-step weights <= 1e-5 (<= 0.5 % Adam-amplified outliers).  (The tight anchors of
         the fp32 chain kernels are test_f32_chain_update_matches_fp64_autograd and test_c2_size_grpo_learn_matches_the_oracle.)

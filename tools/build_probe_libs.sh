@@ -12,3 +12,4 @@ build dwstamps    "-DTG_F32DW_STAMPS=1"                                         
 build fusedbound  "-DTG_ABLATE_FUSED_CHAIN=1"                                            # upper bound of a fused bf16 forward + loss + backward chain kernel
 build tiledstore  "-DTG_TILED_STORE=1"                                                   # chain kernels store their tiles untransposed into a tiled layout (timing only)
 for v in 3 4 5 6; do build p8abl$v "-DTG_F32DW_ABLATE=$v"; done                            # one-barrier 8-wave fp32 weight-gradient job: no rebuild / no products / no DMA / a third of the rebuild's vector instructions gone (tools/f32_dw_pipe_ablation.sh)
+for v in 1 2; do build headrelay$v "-DTG_ABLATE_HEAD_RELAY=$v"; done                       # forward chain's head hand-off: removed / without its barriers (tools/head_relay_ab.sh)

@@ -4,15 +4,16 @@ import trajopt_grpo_amd as tg
 from trajopt_grpo_amd import _native as N
 dev = torch.device("cuda", 0)
 lib = N.load()
-H, rows = 128, 1 << 20
+H, rows = int(os.environ.get("H", 128)), int(os.environ.get("ROWS", 1 << 20))       # H=256: the 8-wave job kernel of mlp_f32_wide.hip
+XC = 8 if H != 256 else 24
 ws = torch.empty(lib.tg_mlp_f32_weight_grad_workspace(H) // 4, device=dev)
-dz = torch.randn(rows, H, device=dev); a = torch.randn(rows, H, device=dev); x = torch.randn(rows, 8, device=dev); g = torch.randn(rows, 4, device=dev)
-wg = torch.zeros(H, H, device=dev); bg = torch.zeros(H, device=dev); w0 = torch.zeros(H, 5, device=dev); wh = torch.zeros(1, H, device=dev); bh = torch.zeros(1, device=dev)
+dz = torch.randn(rows, H, device=dev); a = torch.randn(rows, H, device=dev); x = torch.randn(rows, XC, device=dev); g = torch.randn(rows, 4, device=dev)
+wg = torch.zeros(H, H, device=dev); bg = torch.zeros(H, device=dev); w0 = torch.zeros(H, 5 if H != 256 else 20, device=dev); wh = torch.zeros(1, H, device=dev); bh = torch.zeros(1, device=dev)
 def job(kind, p, q, ncols, w, b, m_out, n_out):
     j = N.F32DwJob(); j.d_p, j.d_q, j.d_wgrad, j.d_bgrad = p.data_ptr(), q.data_ptr(), w.data_ptr(), b.data_ptr()
     j.wgrad_ld, j.kind, j.n_cols, j.m_out, j.n_out = w.stride(0), kind, ncols, m_out, n_out
     return j
-J = {"mm": job(0, dz, a, H, wg, bg, H, H), "x": job(0, dz, x, 8, w0, bg, H, 5), "head": job(1, g, a, H, wh, bh, 1, H)}
+J = {"mm": job(0, dz, a, H, wg, bg, H, H), "x": job(0, dz, x, XC, w0, bg, H, 5 if H != 256 else 20), "head": job(1, g, a, H, wh, bh, 1, H)}
 def run(names):
     arr = (N.F32DwJob * len(names))(*[J[n] for n in names])
     def f():
@@ -25,7 +26,7 @@ def run(names):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 10 * 1e3
 sel = os.environ.get("JOBS")
-for names in ([sel.split(",")] if sel else (["mm"], ["x"], ["head"], ["mm", "mm"], ["x", "head"], ["mm", "x", "head"])):
+for names in ([sel.split(",")] if sel else (["mm"], ["x"], ["head"], ["mm", "mm"], ["x", "head"], ["mm", "x", "head"], ["mm"] * 4, ["mm"] * 4 + ["x", "head"])):
     print(names, "%.0f us" % run(names), flush=True)
 
 if os.environ.get("STAMPS"):

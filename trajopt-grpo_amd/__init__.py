@@ -1,8 +1,12 @@
 """MI355X-native drop-in for the rollout -> returns -> GRPO/PPO update path of
 Dyllon-Preston/trajopt-grpo: same `Env / Policy / RolloutManager / Rollout_Buffer / GRPO / PPO /
 Pipeline` Python surface, backed by hand-written HIP kernels (gfx950) behind the C ABI in
-include/trajopt_grpo_hip.h, PyTorch-ROCm GEMMs for the MLP, and one RCCL gradient all-reduce per
-optimizer step.  Import as `trajopt_grpo_amd` (the directory name carries a hyphen).
+include/trajopt_grpo_hip.h -- environment dynamics, returns / advantages, the MLP's forward, loss head,
+backward and weight-gradient passes on the matrix cores (bf16 chains at 128 / 256 wide, fp32 chains at
+64 / 128 / 256 wide: every net shape the reference's factories build), the optimizer step -- and one RCCL
+gradient all-reduce per optimizer step.  PyTorch supplies device memory, streams and torch.distributed;
+nets outside the kernels' shapes fall back to hipBLASLt GEMMs through torch and say so on the
+`trajopt_grpo_amd` logger.  Import as `trajopt_grpo_amd` (the directory name carries a hyphen).
 """
 from . import _native
 from .environments import Box, Env, CartPole, Pendulum, QuadPole, QuadPole2D, QuadPoleSwarm, Quadrotor, QuadrotorSwarm

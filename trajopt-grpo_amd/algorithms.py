@@ -322,7 +322,7 @@ class _GpuLearner(Algorithm):
         and the step: the fp32 chain learner, one rank (no all-reduce), the update's rows in ONE chunk, and an optimizer that holds
         exactly this net's parameters.  None otherwise -- the caller then all-reduces and calls _optimizer_step() as before."""
         m = self._mlp(net)
-        if not (whole_update and m is not None and m._f32 is not None and not m._f32.wide) or D.rank_world(self.process_group)[1] != 1 or D._ALWAYS:
+        if not (whole_update and m is not None and m._f32 is not None) or D.rank_world(self.process_group)[1] != 1 or D._ALWAYS:
             return None                     # (TG_COLLECTIVES_AT_WORLD_1=1: the gradient all-reduce is wanted even at one rank)
         refresher = self._optimizer_setup(net)
         if refresher is None or not self._adam_covers_bucket:

@@ -53,6 +53,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef TG_ABLATE_FUSED_CHAIN
 #define TG_ABLATE_FUSED_CHAIN 0
 #endif
+// Probe builds only (tools/build_probe_libs.sh `headrelay1` / `headrelay2`): what the forward chain's head hand-off -- the top
+// activation relayed block by block through shared LDS tiles behind eight workgroup barriers, so that the head's weight gradient
+// is contracted on chip -- costs: 1 = the relay removed, 2 = the relay without its barriers.  Results meaningless.
+#ifndef TG_ABLATE_HEAD_RELAY
+#define TG_ABLATE_HEAD_RELAY 0
+#endif
 __device__ static inline int64_t mem_row(int64_t r) {
 #if TG_PROBE_ROW_WINDOW
     return r & (int64_t)(TG_PROBE_ROW_WINDOW - 1);

@@ -25,6 +25,7 @@
 #include "tg_common.hpp"
 #include "adam_update.hpp"
 #include "f32_loss.hpp"
+#include "f32_dw.hpp"
 
 #ifndef TG_F32DW_STAMPS
 #define TG_F32DW_STAMPS 0          /* diagnostic build: s_memtime stamps around the phases of the wide job's stage loop (never in the product) */
@@ -407,27 +408,7 @@ static int launch_f32_chain(const F32ChainArgs& args_in, hipStream_t st) {
 // through registers one stage ahead (the products of a stage take 64 MFMAs x 64 cycles per wave: nothing to hide behind).
 // Bias sums and the head's gradient (4 x H) are fp32 vector arithmetic beside the matrix work.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int kF32DwMaxJobs = 8;
-enum : int32_t { F32DW_MM = 0, F32DW_HEAD = 1 };
-struct F32DwJob {
-    const float* p;         // MM: dZ f32 [rows][M = H];            HEAD: g f32 [rows][4]
-    const float* q;         // MM: A  f32 [rows][N] (N = H, or the padded input width <= 32);  HEAD: A_top f32 [rows][H]
-    int32_t kind, n;        // n: columns of q
-    int32_t first_block, n_blocks, slab_len;
-    int64_t slab_off;
-    // wide job with rebuilt operands and riders (see f32_dw_fused): bit 0: Q = relu(W0 x + b0) from the net input rows (`q` = x
-    // f32 [rows][in_pad]), the first layer's gradient rides; bit 1: P = (g . W_head) * mask from d loss / d output (`p` = g f32
-    // [rows][4]) and the top layer's ReLU mask bits, the head's gradient rides
-    int32_t recompute, in_pad, in_dim, act_dim;
-    const float* w0;        // Linear 0 weight, f32 [H][in_dim] (the master tensor)
-    const float* b0;        // Linear 0 bias f32 [H]
-    const float* wh;        // head weight f32 [act_dim][H] (the master tensor)
-    const uint32_t* mask;   // u32 [rows][4]: the top hidden layer's ReLU mask bits as tg_mlp_f32_forward_backward writes them
-    const float* a_top;     // head rider: the top activation f32 [rows][H]
-    const float* dz0;       // first-layer rider: the bottom dZ f32 [rows][H]
-    int32_t ring_slots;     // 2 or 3
-};
-struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
+// (kF32DwMaxJobs, F32DwJob, F32DwArgs: f32_dw.hpp -- shared with the H = 256 job of mlp_f32_wide.hip)
 
 // Stages flow HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no staging registers) through a ring of kSlots slots with
 // kSlots - 1 stages in flight, counted `s_waitcnt vmcnt` + ONE raw `s_barrier` per stage (mfma_ring.hpp's discipline: every
@@ -1731,9 +1712,9 @@ int tg_debug_f32_stamps2(unsigned long long* host_out) {
 #endif
 
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden) {
-    if (hidden != 64 && hidden != 128) return 0;
-    // (a fused job's slab: the layer's gradient + both riders')
-    return (int64_t)f32_dw_max_blocks() * (hidden * hidden + hidden + hidden * 32 + hidden + 4 * hidden + 4) * (int64_t)sizeof(float);
+    if (hidden != 64 && hidden != 128 && hidden != 256) return 0;
+    // (a fused job's slab: the layer's gradient + both riders'; H = 256 runs one workgroup per CU: half the slots)
+    return (int64_t)(hidden == 256 ? device_cus() : f32_dw_max_blocks()) * (hidden * hidden + hidden + hidden * 32 + hidden + 4 * hidden + 4) * (int64_t)sizeof(float);
 }
 
 int tg_mlp_f32_weight_grad(int32_t hidden, const tg_f32_dw_job* jobs, int32_t n_jobs, int64_t rows, void* d_workspace,
@@ -1758,7 +1739,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         // still have run -- refuse, so that the caller takes the separate launch)
         TG_REQUIRE(rows > 0, "tg_mlp_f32_weight_grad_adam: no rows: run the optimizer step as its own launch");
     }
-    TG_REQUIRE(hidden == 64 || hidden == 128, "tg_mlp_f32_weight_grad: hidden width %d unsupported (64, 128)", hidden);
+    TG_REQUIRE(hidden == 64 || hidden == 128 || hidden == 256, "tg_mlp_f32_weight_grad: hidden width %d unsupported (64, 128, 256)", hidden);
     TG_REQUIRE(n_jobs >= 1 && n_jobs <= kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d jobs outside 1..%d", n_jobs, kF32DwMaxJobs);
     TG_REQUIRE(rows >= 0, "tg_mlp_f32_weight_grad: negative row count");
     TG_REQUIRE(workspace_bytes >= tg_mlp_f32_weight_grad_workspace(hidden), "tg_mlp_f32_weight_grad: workspace of %lld B is smaller than %lld B",
@@ -1793,7 +1774,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         } else {
             TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
             TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
-            TG_REQUIRE(jb.recompute >= 0 && jb.recompute <= 3 && (jb.recompute == 0 || jb.n_cols == H), "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
+            TG_REQUIRE(jb.recompute >= 0 && jb.recompute <= 3 && (jb.recompute == 0 || (jb.n_cols == H && H != 256)), "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
             TG_REQUIRE(!(jb.recompute & 1) || (jb.d_w0 && jb.d_b0 && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad &&
                                                jb.d_dz0 && jb.d_w0grad && jb.d_b0grad && jb.w0grad_ld >= jb.in_dim),
                        "tg_mlp_f32_weight_grad: job %d rebuilds the first activation: first-layer weights / input width / rider missing", j);
@@ -1822,10 +1803,10 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         }
         light_sum += bytes[j];
     }
-    const int max_blocks = f32_dw_max_blocks();
+    const int max_blocks = H == 256 ? device_cus() : f32_dw_max_blocks();      // (H = 256: one 8-wave workgroup per CU)
     // share of the slots that goes to the wide jobs: in proportion to estimated time per row -- a wide job's products at ~70 % of
     // the fp32 matrix rate of one workgroup per CU against a light job's bytes at the ~12 GB/s one workgroup streams
-    const double t_wide = wide_sum * (H == 128 ? 0.085 : 0.085 / 4), t_light = (double)light_sum / 12000.0;
+    const double t_wide = wide_sum * (H == 256 ? 0.30 : (H == 128 ? 0.085 : 0.085 / 4)), t_light = (double)light_sum / (H == 256 ? 20000.0 : 12000.0);
     int wide_slots = 0;
     if (n_wide) {
         const double share = t_wide / (t_wide + t_light);
@@ -1866,7 +1847,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         dj.a_top = jb.d_a_top; dj.dz0 = jb.d_dz0; dj.ring_slots = ring_slots[j];
         dj.first_block = grid;
         // at least 4 stages per workgroup
-        const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H == 128 ? 16 : 32) : (H == 128 ? 32 : 64)));
+        const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H >= 128 ? 16 : 32) : (H >= 128 ? 32 : 64)));
         const int cap = (int)(n_st < 4 ? 1 : (n_st / 4 > 1 << 20 ? 1 << 20 : n_st / 4));
         dj.n_blocks = alloc[j] < cap ? alloc[j] : cap;
         dj.slab_len = jb.recompute ? fused_slab[j] : f32_dw_slab_len(H, jb.kind, jb.n_cols);
@@ -1964,6 +1945,8 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
                      : jobs[0].in_pad == 16 ? launch8(mlp_f32_dw_fused8_kernel<128, 16, false>)
                      : jobs[0].in_pad == 24 ? launch8(mlp_f32_dw_fused8_kernel<128, 24, false>) : launch8(mlp_f32_dw_fused8_kernel<128, 32, false>);
         if (rc) return rc;
+    } else if (hidden == 256) {
+        if (int rc = launch_f32_wide_dw(args, rows, (float*)d_workspace, grid, st)) return rc;
     } else if (hidden == 128) {
         auto kern = mlp_f32_dw_kernel<128>;
         static LdsOptIn opt_in;

@@ -22,6 +22,7 @@
 #include "tg_common.hpp"
 #include "mfma_ring.hpp"
 #include "f32_loss.hpp"
+#include "f32_dw.hpp"
 
 namespace tg {
 
@@ -340,6 +341,250 @@ static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const
     a.stream = reinterpret_cast<const uint4*>(d_stream); a.table = d_table;
     return TG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradients at H = 256 (what `loss.backward()` leaves in .grad, algorithms/ppo.py:181-183): dW_l = dZ_l^T . A_{l-1}, db_l =
+// column sums of dZ_l, head dW_h = g^T . A_top -- the jobs of tg_mlp_f32_weight_grad, one 8-wave workgroup per CU.
+//   wide job (a 256 x 256 layer): the whole gradient lives in the workgroup's accumulators -- wave (wm, wn) of a 2 x 4 grid owns a
+//     128 x 64 block = 4 x 2 tiles of v_mfma_f32_32x32x2_f32 (128 registers).  The contraction runs over ROWS: A operand lane
+//     (i, kk) = P[row 2 s + kk][m0 + i], B operand lane (j, kk) = Q[row 2 s + kk][n0 + j], straight out of row-major LDS panels
+//     (one conflict-free ds_read_b32 per operand: 6 reads per 8 products).  A stage = 16 rows of P and of Q (32 KiB), LDS-DMA
+//     through 3 slots, counted vmcnt + one raw s_barrier per stage; no per-stage epilogue, so the eight waves in lock step lose
+//     nothing but the barrier's skew.  Bias sums: one thread per column and half stage, beside the matrix work.
+//   light jobs (first layer: P = dZ_0, Q = the padded input rows; head: Q = the top activation, P = d loss / d output): bound by
+//     the bytes of their one wide operand; a stage = 32 rows of it (32 KiB) + the narrow operand as a [32][32]-float image.
+// Slabs: as mlp_f32_chain.hip's jobs write them -- [256][N] row-major then the 256 bias sums (head: [4][256] then 4) -- for the
+// same fixed-order reduction launch (mlp_f32_dw_finish_kernel, which may carry the optimizer step).
+// ------------------------------------------------------------------------------------------------------------------------
+static __device__ uint4 g_f32w_zero16;
+typedef __attribute__((address_space(3))) void f32w_lds_void;
+
+constexpr int kWdSRW = 16, kWdSRL = 32;                                 // rows per stage: wide / light
+constexpr int kWdSlotW = 2 * kWdSRW * kWideH * 4;                       // 32 KiB
+constexpr int kWdSlotL = kWdSRL * kWideH * 4 + kWdSRL * 128;            // 36 KiB
+constexpr int kWdD = 3, kWdP = kWdD - 1;
+constexpr int kWdNGW = 4, kWdNGL = 5;                                   // DMA instructions per wave and stage
+constexpr int kWdLds = kWdD * (kWdSlotL > kWdSlotW ? kWdSlotL : kWdSlotW);
+
+// `nrow` rows x 256 floats of `gsrc` (row-major) from row r0 on into a linear LDS panel: 1 KiB pieces = one row each, waves take
+// pieces wave, wave + 8, ...  kZero: rows past the end arrive as zeros instead of as re-reads of the last row
+template <bool kZero>
+__device__ static inline void f32w_dma_rows(const float* __restrict__ gsrc, int64_t r0, int64_t rows, char* panel, int nrow, int wave, int lane) {
+    for (int q = wave; q < nrow; q += 8) {
+        const int64_t r = r0 + q;
+        const uint4* src = reinterpret_cast<const uint4*>(gsrc + (r < rows ? r : rows - 1) * kWideH) + lane;
+        if constexpr (kZero) src = r < rows ? src : &g_f32w_zero16;
+        __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(panel + q * 1024), 16, 0, 0);
+    }
+}
+
+TG_CLOCK_PROBE_VAR(g_probe_f32_wide_dw, attach_probe_f32_wide_dw)
+
+__global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args, int64_t rows, float* __restrict__ ws) {
+    constexpr int H = kWideH;
+    extern __shared__ uint4 lds[];
+    char* lds_c = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    TG_CLOCK_PROBE_BEGIN(g_probe_f32_wide_dw)
+    // this workgroup's job (uniform)
+    int ji = 0;
+#pragma unroll
+    for (int t = 1; t < kF32DwMaxJobs; ++t)
+        if (t < args.n_jobs && (int)blockIdx.x >= args.job[t].first_block) ji = t;
+    const float* jp = args.job[0].p; const float* jq = args.job[0].q;
+    int jkind = args.job[0].kind, jn = args.job[0].n, jfirst = args.job[0].first_block, jnb = args.job[0].n_blocks, jslab = args.job[0].slab_len;
+    int64_t joff = args.job[0].slab_off;
+#pragma unroll
+    for (int t = 1; t < kF32DwMaxJobs; ++t)
+        if (ji == t) {
+            jp = args.job[t].p; jq = args.job[t].q; jkind = args.job[t].kind; jn = args.job[t].n; jfirst = args.job[t].first_block;
+            jnb = args.job[t].n_blocks; jslab = args.job[t].slab_len; joff = args.job[t].slab_off;
+        }
+    const int my = (int)blockIdx.x - jfirst, nb = jnb;
+    const bool head = jkind == F32DW_HEAD, narrow = !head && jn <= 32;
+    float* slab = ws + joff + (int64_t)my * jslab;
+
+    if (!head && !narrow) {
+        // ================= wide job =================
+        constexpr int SR = kWdSRW, D = kWdD, P = kWdP, NG = kWdNGW;
+        const int64_t n_st = (rows + SR - 1) / SR;
+        const int wm = wave >> 2, wn = wave & 3;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+        float bsum = 0.f;
+        const int bcol = tid & 255, brow0 = (tid >> 8) * (SR / 2);       // bias: column, first row of this thread's half stage
+        auto issue = [&](int64_t sg, int slot) {
+            char* sb = lds_c + slot * kWdSlotW;
+            f32w_dma_rows<true>(jp, sg * SR, rows, sb, SR, wave, lane);
+            f32w_dma_rows<false>(jq, sg * SR, rows, sb + SR * H * 4, SR, wave, lane);
+        };
+        int64_t sg_issue = my;
+        int slot_issue = 0, slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < P; ++t) {
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        }
+#pragma unroll 1
+        for (int64_t sg = my; sg < n_st; sg += nb) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+            const float* Pp = reinterpret_cast<const float*>(lds_c + slot * kWdSlotW);
+            const float* Qp = Pp + SR * H;
+            slot = slot + 1 == D ? 0 : slot + 1;
+            const float* pa = Pp + kk * H + 128 * wm + i;
+            const float* qa = Qp + kk * H + 64 * wn + i;
+            float av[4], bv[2], an[4], bn[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) av[x] = wide_lds_f(pa + 32 * x);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bv[y] = wide_lds_f(qa + 32 * y);
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s) {
+                if (s + 1 < SR / 2) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) an[x] = wide_lds_f(pa + (2 * s + 2) * H + 32 * x);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) bn[y] = wide_lds_f(qa + (2 * s + 2) * H + 32 * y);
+                }
+                bsum += wide_lds_f(Pp + (brow0 + s) * H + bcol);          // (rows past the end are zeros)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) av[x] = an[x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bv[y] = bn[y];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+        // the two half stages' bias sums meet in LDS and are added in a fixed order
+        float* red = reinterpret_cast<float*>(lds_c);
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < H) slab[H * H + tid] = red[tid] + red[H + tid];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int m0 = 128 * wm + 32 * x, n0 = 64 * wn + 32 * y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * H + n0 + i] = acc[x][y][r];
+            }
+    } else {
+        // ================= light job: one wide operand, 32 rows per stage =================
+        constexpr int SR = kWdSRL, D = kWdD, P = kWdP, NG = kWdNGL;
+        const int64_t n_st = (rows + SR - 1) / SR;
+        const float* wide = head ? jq : jp;             // head: the top activation; first layer: the bottom dZ
+        const float* thin = head ? jp : jq;             // head: g [rows][4]; first layer: x [rows][N]
+        const int thin_f4 = head ? 1 : jn / 4;          // float4 per row of the narrow operand
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float hacc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+        const int bcol = tid & 255, brow0 = (tid >> 8) * (SR / 2);
+        auto issue = [&](int64_t sg, int slot) {
+            char* sb = lds_c + slot * kWdSlotL;
+            const int64_t r0 = sg * SR;
+            // (the first layer's dZ arrives as zeros past the end: its products and column sums need no masking; the head's
+            // activation is clamped and its g rows arrive as zeros)
+            if (head) f32w_dma_rows<false>(wide, r0, rows, sb, SR, wave, lane);
+            else f32w_dma_rows<true>(wide, r0, rows, sb, SR, wave, lane);
+            // the narrow operand as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece, 4 pieces (waves 4..7 repeat)
+            const int piece = wave & 3;
+            const int64_t r = r0 + piece * 8 + (lane >> 3);
+            const int c4 = lane & 7;
+            const uint4* src = (c4 < thin_f4 && r < rows) ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : &g_f32w_zero16;
+            __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(sb + SR * H * 4 + piece * 1024), 16, 0, 0);
+        };
+        int64_t sg_issue = my;
+        int slot_issue = 0, slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < P; ++t) {
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        }
+#pragma unroll 1
+        for (int64_t sg = my; sg < n_st; sg += nb) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+            const float* W = reinterpret_cast<const float*>(lds_c + slot * kWdSlotL);
+            const float* T = W + SR * H;                // the narrow image [SR][32]
+            slot = slot + 1 == D ? 0 : slot + 1;
+            if (head) {
+                // one column and half a stage per thread; the activation rows past the end are re-reads, their g rows zeros
+#pragma unroll 4
+                for (int r = 0; r < SR / 2; ++r) {
+                    const float4 g4 = wide_lds_f4(T + 32 * (brow0 + r));
+                    const float qv = wide_lds_f(W + (brow0 + r) * H + bcol);
+                    hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
+                    hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
+                }
+                if (tid < 4) {
+                    for (int r = 0; r < SR; ++r) bsum += wide_lds_f(T + 32 * r + tid);
+                }
+            } else {
+#pragma unroll 8
+                for (int s = 0; s < SR / 2; ++s) {
+                    const float av = wide_lds_f(W + (2 * s + kk) * H + 32 * wave + i);
+                    const float bv = wide_lds_f(T + (2 * s + kk) * 32 + i);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll 4
+                for (int r = 0; r < SR / 2; ++r) bsum += wide_lds_f(W + (brow0 + r) * H + bcol);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* red = reinterpret_cast<float*>(lds_c);
+        __syncthreads();
+        if (head) {
+            // the two half stages' sums, in a fixed order
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k * 512 + tid] = hacc[k];
+            __syncthreads();
+            if (tid < H) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) slab[k * H + tid] = red[k * 512 + tid] + red[k * 512 + H + tid];
+            }
+            if (tid < 4) slab[4 * H + tid] = bsum;
+        } else {
+            red[tid] = bsum;
+            __syncthreads();
+            if (tid < H) slab[H * 32 + tid] = red[tid] + red[H + tid];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[r];
+        }
+    }
+    TG_CLOCK_PROBE_END(g_probe_f32_wide_dw)
+}
+
+int launch_f32_wide_dw(const F32DwArgs& args, int64_t rows, float* d_workspace, int grid, hipStream_t st) {
+    auto kern = mlp_f32_wide_dw_kernel;
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, (size_t)kWdLds, opt_in, "tg_mlp_f32_weight_grad")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), (size_t)kWdLds, st, args, rows, d_workspace);
+    return TG_OK;
+}
+
+int attach_probe_f32w(int which, void* d_probe) { return which == 0 ? attach_probe_f32_wide(d_probe) : attach_probe_f32_wide_dw(d_probe); }
 
 }  // namespace tg
 

@@ -527,11 +527,14 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                         lds_store16(tw + (rl >> 2) * 256 + (rl & 3) * 64 + ((grp ^ ((rl >> 2) & 3)) * 16), __builtin_bit_cast(uint4, xin[c][b]));
                     }
                 };
+#if TG_ABLATE_HEAD_RELAY != 1                                  /* probe build 1: no relay at all (timing only: the head's weight gradient is not formed) */
                 write_tile(0);
 #pragma unroll
                 for (int b = 0; b < MT; ++b) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if TG_ABLATE_HEAD_RELAY != 2                                  /* probe build 2: the relay without its eight workgroup barriers (racy: timing only) */
                     __builtin_amdgcn_s_barrier();
+#endif
                     asm volatile("" ::: "memory");
                     if (b + 1 < MT) write_tile(b + 1);
                     f32x4 t = {};
@@ -549,6 +552,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void mlp_fwd_chain_kernel(const uint16
                                     __builtin_bit_cast(uint4, float4{h.x + t[0], h.y + t[1], h.z + t[2], h.w + t[3]}));
                     }
                 }
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next round's loss inputs overwrite what was read above)
                 dma_loss_inputs(round + gridDim.x);
             }

@@ -86,6 +86,7 @@ int attach_probe_fwd_chain_plain(void*);
 int attach_probe_bwd_chain(void*);
 int attach_probe_weight_grad(void*);
 int attach_probe_f32(int which, void*);
+int attach_probe_f32w(int which, void*);
 int attach_probe_mfma_loop(void*);
 
 // Per-DEVICE launch state (one process may drive several GPUs): the device ordinal of the calling thread, its CU count,

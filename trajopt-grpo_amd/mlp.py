@@ -239,7 +239,7 @@ class GemmMLP:
             return
         _LOGGED_SHAPES.add(shape)
         if self._f32 is not None and self._f32.wide:
-            _LOG.info("%s: fp32 chain learner at H = 256 (tg_mlp_f32w_forward / _forward_backward; weight gradients: split-K GEMMs)", shape)
+            _LOG.info("%s: fp32 chain learner at H = 256 (tg_mlp_f32w_forward / _forward_backward / tg_mlp_f32_weight_grad)", shape)
         elif self._f32 is not None:
             _LOG.info("%s: fp32 chain learner (tg_mlp_f32_forward / _forward_backward / _weight_grad)", shape)
         elif self._chain is not None and self._bchain is not None:
@@ -524,7 +524,7 @@ class GemmMLP:
         assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
         # with >= 2 hidden layers the first activation and the top layer's dZ are neither written nor read: the weight-gradient job
         # that needs them rebuilds them from the input row / from d loss / d output + the top layer's mask bits (16 B per row)
-        # (the H = 256 learner has no weight-gradient job of its own yet: everything is stored, the gradients are split-K GEMMs)
+        # (the H = 256 learner's weight-gradient jobs read every operand back: nothing is rebuilt there yet)
         rec = nh >= 2 and not self.f32_store_all and not f.wide
         acts = [None if (rec and i == 0) else self._ws.get(f"fa{i}", rows, H, torch.float32, dev) for i in range(nh)]
         dzs = [None if (rec and i == nh - 1) else self._ws.get(f"fz{i}", rows, H, torch.float32, dev) for i in range(nh)]
@@ -566,29 +566,6 @@ class GemmMLP:
         f = self._f32
         xp, acts, dzs, dout = self._acts[0], self._acts[1:], self._bits, self._dz_head
         rows, H, nh, lin = xp.shape[0], f.H, f.n_hidden, self.linears
-        if f.wide:
-            # interim: the weight gradients of the H = 256 fp32 learner as split-K GEMMs over the stored operands (hipBLASLt) -- the
-            # chain kernel is this tree's, the dW job is not written yet
-            assert adam is None
-            rider = getattr(self, "_loss_rider", None)
-            self._loss_rider = None
-            if rider is not None:
-                rider[1].add_(self._head_ws[:rider[0] * 4].view(rider[0], 4).sum(0))
-            ev = None
-            if self.dw_events is not None:
-                ev = N.event_pair()
-                ev[0].record()
-            for i in range(nh):
-                self._dw_into(lin[i].weight.grad, dzs[i], xp if i == 0 else acts[i - 1])
-                lin[i].bias.grad.add_(dzs[i].sum(0))
-            self._dw_into(lin[nh].weight.grad, dout, acts[nh - 1])
-            lin[nh].bias.grad.add_(dout[:, :self.out_dim].sum(0))
-            if ev is not None:
-                ev[1].record()
-                self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * self.in_dim + 2 * H * self.out_dim,
-                                       "hipBLASLt split-K GEMMs (mlp_f32 wide learner, interim)"))
-            self._acts = self._bits = self._dz_head = self._tmask = None
-            return
         if nh == 1:
             assert acts[0] is not None and dzs[0] is not None
         if self._dw_ws is None:
@@ -637,7 +614,8 @@ class GemmMLP:
             # algorithmic flops per row (un-padded): every layer's dZ^T A
             one_job = H == 128 and nh == 2
             self.dw_events.append((ev[0], ev[1], rows, 2 * (nh - 1) * H * H + 2 * H * self.in_dim + 2 * H * self.out_dim,
-                                   f"tg::mlp_f32_dw_fused8_kernel<{H},...> + finish" if one_job else f"tg::mlp_f32_dw_kernel<{H}> + finish"))
+                                   "tg::mlp_f32_wide_dw_kernel + finish" if f.wide else
+                                   (f"tg::mlp_f32_dw_fused8_kernel<{H},...> + finish" if one_job else f"tg::mlp_f32_dw_kernel<{H}> + finish")))
         self._acts = self._bits = self._dz_head = self._tmask = None
 
     @torch.no_grad()
