@@ -1,0 +1,11 @@
+#!/bin/bash
+# Where the fp32 H = 256 chain kernel's time goes: the product build against timing-only probe builds (-DTG_F32W_ABLATE bits: 1 = no block
+# barrier, 2 = no weight DMA inside the rounds, 4 = no activation / dZ stores), tg_mlp_f32w_forward_backward at 2^20 rows of 20-256x5-4.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R
+for lib in product f32wabl1 f32wabl2 f32wabl4 f32wabl7 product; do
+  if [ $lib = product ]; then unset TG_NATIVE_LIB; else export TG_NATIVE_LIB=$R/scratch/libtg_$lib.so; fi
+  python3 tools/f32_h256_probe.py --rows 1048576 --iters 5 --wide-only 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$lib: chain %.3f ms (%.1f TFLOP/s), no-grad forward %.3f ms' % (d['chain_ms'], 1126.6e9/d['chain_ms']/1e9 if False else (2*(20*256+4*65536+1024)+2*(4*65536+1024))*1048576/d['chain_ms']/1e9, d['nograd_ms']))"
+done

@@ -43,7 +43,10 @@ __device__ static inline void f32_loss_from_device(F32Loss& L) {
 }
 
 // One row: head outputs o[4] -> d loss / d output g[4] and the row's contributions to the loss sums.  `rowc` = the row clamped into
-// range (loads), `row` / `valid` / `writer` decide what is written (one lane per row writes).
+// range (loads), `row` / `valid` / `writer` decide what is written (one lane per row writes).  kZeroInvalid: a lane past the last row
+// gets g = 0 (mlp_f32_chain.hip); false: it keeps the clamped row's own g -- the H = 256 kernel lets such lanes recompute and
+// re-store the last row's values (identical bytes), so that every store instruction is issued whatever the row count.
+template <bool kZeroInvalid = true>
 __device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4], int64_t row, int64_t rowc, bool valid, bool writer,
                                            float (&g)[4], float& c_surr, float& c_crit, float& c_kl) {
     g[0] = g[1] = g[2] = g[3] = 0.f;
@@ -84,7 +87,9 @@ __device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4]
         c_crit = d * d;
         g[0] = L.critic_coef * 2.0f * d;
     }
-    if (!valid) { g[0] = g[1] = g[2] = g[3] = 0.f; }
+    if constexpr (kZeroInvalid) {
+        if (!valid) { g[0] = g[1] = g[2] = g[3] = 0.f; }
+    }
 }
 
 }  // namespace tg

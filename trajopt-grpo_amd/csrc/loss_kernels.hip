@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void surrogate_loss_kernel(LossK p) {
     double s_surr = 0, s_crit = 0, s_kl = 0, s_cnt = 0;
     float n_am = 0.f, n_ai = 1.f, n_rm = 0.f, n_ri = 1.f;
     if (p.norm != nullptr) { n_am = p.norm[0]; n_ai = p.norm[1]; n_rm = p.norm[2]; n_ri = p.norm[3]; }
-    if (p.coef != nullptr) { p.surr_coef = p.coef[0]; p.critic_coef = p.coef[1]; p.kl_coef = p.coef[2]; }
+    // (locals: writing into the by-value argument struct would send it to scratch)
+    float surr_coef = p.surr_coef, critic_coef = p.critic_coef, kl_coef = p.kl_coef;
+    if (p.coef != nullptr) { surr_coef = p.coef[0]; critic_coef = p.coef[1]; kl_coef = p.coef[2]; }
     const float lo = 1.0f - p.epsilon, hi = 1.0f + p.epsilon;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.M; i += (int64_t)gridDim.x * blockDim.x) {
         const bool valid = p.mask == nullptr || p.mask[i] != 0;
@@ -78,18 +80,18 @@ __global__ __launch_bounds__(256) void surrogate_loss_kernel(LossK p) {
             const float w = inside ? 1.0f : (surr1 < surr2 ? 1.0f : 0.0f);
             s_surr += (double)fminf(surr1, surr2);
             // d total / d logp
-            float dlp = p.surr_coef * adv * rho * w;
-            if (p.kl_coef != 0.0f) {
+            float dlp = surr_coef * adv * rho * w;
+            if (kl_coef != 0.0f) {
                 const float eo = expf(lpo);
                 s_kl += (double)(eo * (lpo - lp));
-                dlp -= p.kl_coef * eo;
+                dlp -= kl_coef * eo;
             }
 #pragma unroll
             for (int k = 0; k < A; ++k) g[k] = dlp * (a[k] - mu[k]) * p.v.inv_var[k];   // d logp / d mu_k
             if (p.value != nullptr) {
                 const float d = p.value[i] - (p.ret[i] - n_rm) * n_ri;
                 s_crit += (double)(d * d);
-                gv = p.critic_coef * 2.0f * d;
+                gv = critic_coef * 2.0f * d;
             }
             s_cnt += 1.0;
         }

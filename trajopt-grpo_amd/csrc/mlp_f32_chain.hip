@@ -99,7 +99,10 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
     const F32Net& net = a.net;
     const int n_hh = net.n_hh, K2 = net.k2;
     const int n_stream = n_hh * MT * (kTrain ? 2 : 1);              // blocks per round (the same sequence every round)
-    if constexpr (kTrain) f32_loss_from_device(a.loss);
+    // (a LOCAL copy: writing into the by-value argument struct itself sends all of it to scratch -- 272 B per lane and 23 more
+    // registers in this kernel, 9 % of a small PPO epoch, measured in round 5)
+    F32Loss L = a.loss;
+    if constexpr (kTrain) f32_loss_from_device(L);
     const bool resident = a.resident != 0;
     // LDS (f32_chain_lds() on the host computes the same sizes): the block ring (2 blocks) or the whole resident stream, the
     // first layer's fragments, bias / head tables, the ReLU mask bits of the (n_hh + 1) hidden layers, the loss-sum scratch
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
         }
         // ---- head: <= 4 outputs as fp32 dot products over the lane's features, the two halves added by one exchange ----
         float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const int A = kTrain ? a.loss.A : 4;
+        const int A = kTrain ? L.A : 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < A) {
@@ -297,7 +300,6 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
             if (valid && h == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
         } else {
             // ---- loss head (loss_kernels.hip::surrogate_loss_kernel, same arithmetic), evaluated by both lane halves ----
-            const F32Loss& L = a.loss;
             float g[4], c_surr, c_crit, c_kl;
             f32_loss_row(L, o, row, rowc, valid, h == 0, g, c_surr, c_crit, c_kl);
             if (valid && h == 0) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_chain_kernel(F32ChainArgs a) {
         if (tid < 4) {
             double t = 0.0;
             for (int w = 0; w < 8; ++w) t += red_s[w * 4 + tid];
-            a.loss.work[(int64_t)blockIdx.x * 4 + tid] = t;
+            L.work[(int64_t)blockIdx.x * 4 + tid] = t;
         }
     }
     if constexpr (kTrain) { TG_CLOCK_PROBE_END(g_probe_f32_chain) }
@@ -1806,7 +1808,9 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     const int max_blocks = H == 256 ? device_cus() : f32_dw_max_blocks();      // (H = 256: one 8-wave workgroup per CU)
     // share of the slots that goes to the wide jobs: in proportion to estimated time per row -- a wide job's products at ~70 % of
     // the fp32 matrix rate of one workgroup per CU against a light job's bytes at the ~12 GB/s one workgroup streams
-    const double t_wide = wide_sum * (H == 256 ? 0.30 : (H == 128 ? 0.085 : 0.085 / 4)), t_light = (double)light_sum / (H == 256 ? 20000.0 : 12000.0);
+    // (H = 256, one workgroup per CU, measured with tools/f32_dw_jobs_probe.py: 0.26 us per row and wide workgroup; a light workgroup
+    // streams ~17 GB/s)
+    const double t_wide = wide_sum * (H == 256 ? 0.26 : (H == 128 ? 0.085 : 0.085 / 4)), t_light = (double)light_sum / (H == 256 ? 17000.0 : 12000.0);
     int wide_slots = 0;
     if (n_wide) {
         const double share = t_wide / (t_wide + t_light);

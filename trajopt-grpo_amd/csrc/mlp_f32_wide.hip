@@ -24,6 +24,11 @@
 #include "f32_loss.hpp"
 #include "f32_dw.hpp"
 
+#ifndef TG_F32W_ABLATE
+#define TG_F32W_ABLATE 0           /* timing-only probe builds of the chain kernel (results meaningless): bit 0 = no block barrier, bit 1 = no
+                                      weight DMA inside the rounds, bit 2 = no activation / dZ stores (tools/f32_wide_ablation.sh) */
+#endif
+
 namespace tg {
 
 constexpr int kWideH = 256;
@@ -101,11 +106,26 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
         pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
     }
     __syncthreads();                                                          // (the tables; drains the prologue's DMA too: once)
-    // counted wait for the block about to be consumed: behind its DMA there are always the (P - 1) x KS / WPW pieces of the later
-    // blocks; the activation stores issued in between are not counted (a store-free stretch -- the first layer, the head -- must
-    // not let the wait pass early), so a wait also retires the stores of the block before last: they have had a block to complete
+    // counted wait for the block about to be consumed (vector-memory operations retire in issue order, stores included): behind its
+    // DMA there are always the (P - 1) x KS / WPW pieces of the later blocks, and -- in the training pass, where every H x H block
+    // ends with exactly ONE store instruction (a lane past the last row re-stores the last row's identical bytes: the instruction is
+    // issued whatever the row count) -- the stores of the two blocks before it.  A site whose two predecessors may not have stored
+    // (the first layer's blocks, the first two blocks of a layer) counts only the DMA: stricter, never weaker.  Without the store
+    // count every block also waited for the previous block's store and for a DMA piece issued one block ago: ~one L2 round trip.
     constexpr int kWait = (P - 1) * (KS / WPW);
+    constexpr int kWaitFull = kWait + (kTrain ? P : 0);
 
+#if TG_F32W_ABLATE
+#undef TG_RING_NEXT
+#define TG_RING_NEXT                                                                                       \
+    if (!(TG_F32W_ABLATE & 1)) __builtin_amdgcn_s_barrier();                                               \
+    asm volatile("" ::: "memory");                                                                         \
+    if (!(TG_F32W_ABLATE & 2)) ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);    \
+    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                                 \
+    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                                     \
+    const uint4* cur = ring + cur_slot * KS * 64;                                                          \
+    cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
+#endif
     auto relu_bits4 = [&](f32x4& v) {
         uint32_t m = 0;
 #pragma unroll
@@ -120,21 +140,25 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
     // ~100 cycles, eight products 256)
     auto tile_products = [&](const uint4* __restrict__ cur, const f32x4 (&xin)[NT], f32x4 acc) {
         const uint4* __restrict__ p = cur + lane;
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
         uint4 wa = wide_lds_u4(p), wb = wide_lds_u4(p + 64);
 #pragma unroll
         for (int t = 0; t < NT; t += 2) {
             uint4 na = wa, nb = wb;
             if (t + 2 < NT) { na = wide_lds_u4(p + (t + 2) * 64); nb = wide_lds_u4(p + (t + 3) * 64); }
+            // two accumulator chains (even / odd pieces), alternating: a dependent v_mfma_f32_16x16x4_f32 can issue 40 cycles after its
+            // predecessor, an independent one after 32 -- one chain alone caps a wave at 80 % of the pipe whenever its SIMD-mate stalls
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), xin[t][0], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t + 1][0], acc1, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), xin[t][1], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t + 1][1], acc1, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), xin[t][2], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t + 1][2], acc1, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), xin[t][3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t + 1][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t + 1][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t + 1][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t + 1][3], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t + 1][3], acc1, 0, 0, 0);
             wa = na; wb = nb;
         }
+        acc = acc + acc1;                                            // (a fixed order: deterministic)
         // pin that order (hipcc otherwise sinks every read to just in front of its products): 4 reads, then 8 products + the 2 reads
         // of the group after next, ...
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -147,7 +171,11 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
     };
     auto bits_slot = [&](int layer) { return bits_s + ((layer * WPW + wave) * 64 + lane) * 2; };
     auto store_tile = [&](float* gptr, int64_t row, int mo, const f32x4& v) {
+#if TG_F32W_ABLATE & 4
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
         *reinterpret_cast<float4*>(gptr + row * H + 16 * mo + 4 * g) = float4{v[0], v[1], v[2], v[3]};
+#endif
     };
 
     double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
                     if (mo < 8) mb0 |= m << (4 * mo); else mb1 |= m << (4 * (mo - 8));
                     xin[mo] = acc;
                     if constexpr (kTrain) {
-                        if (valid && a.acts[0] != nullptr) store_tile(a.acts[0], row, mo, acc);
+                        if (a.acts[0] != nullptr) store_tile(a.acts[0], rowc, mo, acc);
                     }
                 }
             }
@@ -202,15 +230,14 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
             float* act_l = kTrain ? pick(a.acts, l) : nullptr;
 #pragma unroll
             for (int mo = 0; mo < NT; ++mo) {
-                TG_RING_ADVANCE(kWait)
+                if (mo >= 2) { TG_RING_WAIT(kWaitFull) } else { TG_RING_WAIT(kWait) }
+                TG_RING_NEXT
                 const float4 b4 = wide_lds_f4(bias_l + 16 * mo);
                 f32x4 acc = tile_products(cur, xin, f32x4{b4.x, b4.y, b4.z, b4.w});
                 const uint32_t m = relu_bits4(acc);
                 if (mo < 8) mb0 |= m << (4 * mo); else mb1 |= m << (4 * (mo - 8));
                 xout[mo] = acc;
-                if constexpr (kTrain) {
-                    if (valid) store_tile(act_l, row, mo, acc);
-                }
+                if constexpr (kTrain) store_tile(act_l, rowc, mo, acc);
             }
             if constexpr (kTrain) wide_lds_st2(bits_slot(l), uint2{mb0, mb1});
 #pragma unroll
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
             if (valid && g == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
         } else {
             float gr[4], c_surr, c_crit, c_kl;
-            f32_loss_row(L, o, row, rowc, valid, g == 0, gr, c_surr, c_crit, c_kl);
+            f32_loss_row<false>(L, o, row, rowc, valid, g == 0, gr, c_surr, c_crit, c_kl);
             if (valid && g == 0) {
                 s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
                 *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{gr[0], gr[1], gr[2], gr[3]};
@@ -265,14 +292,15 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
                 d[2] = (mw & 4u) ? s.z : 0.f;
                 d[3] = (mw & 8u) ? s.w : 0.f;
                 xin[t] = d;
-                if (valid && dz_top != nullptr) store_tile(dz_top, row, t, d);
+                if (dz_top != nullptr) store_tile(dz_top, rowc, t, d);
             }
             for (int l = n_hh; l >= 1; --l) {
                 const uint2 mk = wide_lds_u2(bits_slot(l - 1));
                 float* dz_l = pick(a.dz, l - 1);
 #pragma unroll
                 for (int ko = 0; ko < NT; ++ko) {
-                    TG_RING_ADVANCE(kWait)
+                    // (the two blocks before any backward block stored: the top layer's last forward blocks, or this pass's own)
+                    TG_RING_ADVANCE(kWaitFull)
                     f32x4 acc = tile_products(cur, xin, f32x4{0.f, 0.f, 0.f, 0.f});
                     const uint32_t mw = (ko < 8 ? mk.x >> (4 * ko) : mk.y >> (4 * (ko - 8)));
                     acc[0] = (mw & 1u) ? acc[0] : 0.f;
@@ -280,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
                     acc[2] = (mw & 4u) ? acc[2] : 0.f;
                     acc[3] = (mw & 8u) ? acc[3] : 0.f;
                     xout[ko] = acc;
-                    if (valid) store_tile(dz_l, row, ko, acc);
+                    store_tile(dz_l, rowc, ko, acc);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) xin[t] = xout[t];
@@ -362,9 +390,10 @@ typedef __attribute__((address_space(3))) void f32w_lds_void;
 constexpr int kWdSRW = 16, kWdSRL = 32;                                 // rows per stage: wide / light
 constexpr int kWdSlotW = 2 * kWdSRW * kWideH * 4;                       // 32 KiB
 constexpr int kWdSlotL = kWdSRL * kWideH * 4 + kWdSRL * 128;            // 36 KiB
-constexpr int kWdD = 3, kWdP = kWdD - 1;
+constexpr int kWdDW = 4, kWdDL = 4;                                     // ring slots: wide jobs (bound by the matrix pipe: 9 GB/s per CU) /
+                                                                        // light jobs (bound by the bytes in flight: 3 stages = 108 KiB)
 constexpr int kWdNGW = 4, kWdNGL = 5;                                   // DMA instructions per wave and stage
-constexpr int kWdLds = kWdD * (kWdSlotL > kWdSlotW ? kWdSlotL : kWdSlotW);
+constexpr int kWdLds = kWdDL * kWdSlotL > kWdDW * kWdSlotW ? kWdDL * kWdSlotL : kWdDW * kWdSlotW;
 
 // `nrow` rows x 256 floats of `gsrc` (row-major) from row r0 on into a linear LDS panel: 1 KiB pieces = one row each, waves take
 // pieces wave, wave + 8, ...  kZero: rows past the end arrive as zeros instead of as re-reads of the last row
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
 
     if (!head && !narrow) {
         // ================= wide job =================
-        constexpr int SR = kWdSRW, D = kWdD, P = kWdP, NG = kWdNGW;
+        constexpr int SR = kWdSRW, D = kWdDW, P = D - 1, NG = kWdNGW;
         const int64_t n_st = (rows + SR - 1) / SR;
         const int wm = wave >> 2, wn = wave & 3;
         f32x16 acc[4][2];
@@ -468,6 +497,14 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
 #pragma unroll
                 for (int y = 0; y < 2; ++y) bv[y] = bn[y];
             }
+            // pin the order: a step's LDS reads (6 operands + 1 bias element, merged pairwise by hipcc: ~4 instructions) ahead of the
+            // previous step's 8 products
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s) {
+                if (s + 1 < SR / 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
         // the two half stages' bias sums meet in LDS and are added in a fixed order
@@ -486,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
             }
     } else {
         // ================= light job: one wide operand, 32 rows per stage =================
-        constexpr int SR = kWdSRL, D = kWdD, P = kWdP, NG = kWdNGL;
+        constexpr int SR = kWdSRL, D = kWdDL, P = D - 1, NG = kWdNGL;
         const int64_t n_st = (rows + SR - 1) / SR;
         const float* wide = head ? jq : jp;             // head: the top activation; first layer: the bottom dZ
         const float* thin = head ? jp : jq;             // head: g [rows][4]; first layer: x [rows][N]
