@@ -420,6 +420,14 @@ static int launch_f32_chain(const F32ChainArgs& args_in, hipStream_t st) {
 //   light job (first layer: P = dZ_0, narrow Q = the input rows; head: wide Q = the top activation, narrow P = d loss / d
 //   output): stage = SRL rows of the wide operand (16 KiB) + the narrow operand as a zero-padded [SRL][32] image (4-8 KiB), 3 slots.
 __device__ uint4 g_f32_zero16;
+// Its address, held in a register pair by the kernel that uses it (`const uint4* zero16 = f32_zero16_addr();` at the top): written
+// as `&g_f32_zero16` at the use, hipcc re-loads the symbol's address through the GOT in front of every LDS-DMA -- a scalar memory
+// round trip per piece inside the stage loops (found in round 5 on the H = 256 jobs: ~15 % of a stage).
+__device__ static inline const uint4* f32_zero16_addr() {
+    const uint4* z = &g_f32_zero16;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 #if TG_F32DW_STAMPS
 __device__ unsigned long long g_f32_stamps[4096 * 4];      // per wave: cycles in [wait + bias][arrive][products + reads], stages
 __device__ unsigned long long g_f32_stamps3[4096 * 12];     // fused job, per wave: cycles in [wait + barrier][issue][phase 1][barrier][operand reads][products], stages
@@ -450,14 +458,14 @@ struct F32DwGeom {
 // (kZeroTail: rows past the end arrive as zeros instead of as re-reads of the last row)
 template <int H, bool kZeroTail = false>
 __device__ static inline void f32_dma_wide(const float* __restrict__ g, int64_t r0, int64_t rows, char* panel, int first_piece,
-                                           int wave, int lane) {
+                                           int wave, int lane, const uint4* zero16 = nullptr) {
     using G = F32DwGeom<H>;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int piece = first_piece + 2 * wave + t;       // 8 pieces per 8-KiB half: waves take 2 each
         int64_t r = r0 + (int64_t)(piece - first_piece) * G::RPP + lane / G::LPR;
         const uint4* src = reinterpret_cast<const uint4*>(g + (r < rows ? r : rows - 1) * H) + lane % G::LPR;
-        if constexpr (kZeroTail) src = r < rows ? src : &g_f32_zero16;
+        if constexpr (kZeroTail) src = r < rows ? src : zero16;
         __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(panel + piece * 1024), 16, 0, 0);
     }
 }
@@ -494,6 +502,7 @@ struct F32FusedGeom {
 
 template <int H, bool kRecP, bool kRecQ>
 __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds_c, float* __restrict__ ws) {
+    const uint4* zero16 = f32_zero16_addr();
     using F = F32FusedGeom<H, kRecP, kRecQ>;
     constexpr int MT = H / 32, TW = MT >= 4 ? 2 : 1;
     constexpr int SR = F::SR, NG = F::NG;
@@ -535,10 +544,10 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
         char* sb = lds_c + slot * F::SLOT;
         const int64_t r0 = sg * SR;
         // (P-side operands arrive as zeros past the last row: no product or sum needs masking)
-        if constexpr (!kRecP) f32_dma_wide<H, true>(job.p, r0, rows, sb + F::OFF_P, 0, wave, lane);
+        if constexpr (!kRecP) f32_dma_wide<H, true>(job.p, r0, rows, sb + F::OFF_P, 0, wave, lane, zero16);
         if constexpr (!kRecQ) f32_dma_wide<H>(job.q, r0, rows, sb + F::OFF_Q, 0, wave, lane);
         if constexpr (kRecP) f32_dma_wide<H>(job.a_top, r0, rows, sb + F::OFF_AT, 0, wave, lane);
-        if constexpr (kRecQ) f32_dma_wide<H, true>(job.dz0, r0, rows, sb + F::OFF_Z0, 0, wave, lane);
+        if constexpr (kRecQ) f32_dma_wide<H, true>(job.dz0, r0, rows, sb + F::OFF_Z0, 0, wave, lane, zero16);
 #pragma unroll
         for (int t = 0; t < F::SPW; ++t) {
             const int pc = (wave + 4 * t) % F::N_SMALL;
@@ -547,14 +556,14 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
                 int64_t r = r0 + pc * 8 + (lane >> 3);
                 r = r < rows ? r : rows - 1;
                 const int c4 = lane & 7;
-                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(job.q + r * job.in_pad) + c4 : &g_f32_zero16;
+                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(job.q + r * job.in_pad) + c4 : zero16;
                 __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_X + pc * 1024), 16, 0, 0);
             } else {
                 // lanes [0, 32): the stage's g rows (16 B each; zeros past the last row); lanes [32, 64): its mask rows
                 const int rr = lane & 31;
                 const int64_t r = r0 + (rr < SR ? rr : SR - 1);
                 const int64_t rc = r < rows ? r : rows - 1;
-                const uint4* src = lane < 32 ? (r < rows ? reinterpret_cast<const uint4*>(job.p) + rc : &g_f32_zero16)
+                const uint4* src = lane < 32 ? (r < rows ? reinterpret_cast<const uint4*>(job.p) + rc : zero16)
                                              : reinterpret_cast<const uint4*>(job.mask) + rc;
                 __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_G), 16, 0, 0);
             }
@@ -782,6 +791,7 @@ __device__ static void f32_dw_fused(const F32DwJob& job, int64_t rows, char* lds
 
 template <int H>
 __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int64_t rows, float* __restrict__ ws) {
+    const uint4* zero16 = f32_zero16_addr();
     using G = F32DwGeom<H>;
     constexpr int MT = H / 32;
     constexpr int TW = MT >= 4 ? 2 : 1;                 // a wave's block of output tiles is TW x TW (H = 128: 2 x 2; H = 64: 1 x 1)
@@ -958,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
                 int64_t r = r0 + piece * 8 + (lane >> 3);
                 r = r < rows ? r : rows - 1;
                 const int c4 = lane & 7;
-                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : &g_f32_zero16;
+                const uint4* src = c4 < thin_f4 ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : zero16;
                 __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + 16384 + piece * 1024), 16, 0, 0);
             }
         };
@@ -1083,6 +1093,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_dw_kernel(F32DwArgs args, int6
 // what the stage's time follows (tools/f32_dw_pipe_ablation.sh).  Same bits: fma(0, x, o) == o.
 template <int H, int IN_PAD, bool kPipe, bool kLean = false>
 __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job, int64_t rows, float* __restrict__ ws) {
+    const uint4* zero16 = f32_zero16_addr();
     static_assert(!kLean || (kPipe && IN_PAD == 8), "the lean form is a specialisation of the one-barrier job at padded width 8");
     static_assert(H == 128, "one wave per 32 x 64 strip of a 128 x 128 gradient");
     static_assert(IN_PAD % 8 == 0 && IN_PAD >= 8 && IN_PAD <= 32, "padded input width");
@@ -1149,7 +1160,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
         const char* at_b = reinterpret_cast<const char*>(job.a_top + rbase * H);
         const char* z0_b = reinterpret_cast<const char*>(job.dz0 + rbase * H);
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(at_b + ow), (f32_lds_void*)(sb + F::OFF_AT + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(rr < n_valid ? reinterpret_cast<const uint4*>(z0_b + ow) : &g_f32_zero16,
+        __builtin_amdgcn_global_load_lds(rr < n_valid ? reinterpret_cast<const uint4*>(z0_b + ow) : zero16,
                                          (f32_lds_void*)(sb + F::OFF_Z0 + wave * 1024), 16, 0, 0);
         const int pc = wave % F::N_SMALL;                               // (waves 3..7 repeat a piece: every wave issues NG instructions)
         if (pc < SR / 8) {
@@ -1157,7 +1168,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             const int rx = pc * 8 + (lane >> 3), c4 = lane & 7;
             const char* x_b = reinterpret_cast<const char*>(job.q + rbase * IN_PAD);
             const uint32_t ox = (uint32_t)(rx < lim ? rx : lim) * (IN_PAD * 4) + c4 * 16;
-            __builtin_amdgcn_global_load_lds(c4 < thin_f4 ? reinterpret_cast<const uint4*>(x_b + ox) : &g_f32_zero16,
+            __builtin_amdgcn_global_load_lds(c4 < thin_f4 ? reinterpret_cast<const uint4*>(x_b + ox) : zero16,
                                              (f32_lds_void*)(sb + F::OFF_X + pc * 1024), 16, 0, 0);
         } else {
             // lanes [0, 32): the stage's g rows (16 B each; zeros past the last row); lanes [32, 64): its mask rows
@@ -1165,7 +1176,7 @@ __global__ __launch_bounds__(512, 4) void mlp_f32_dw_fused8_kernel(F32DwJob job,
             const uint32_t og = (uint32_t)(rg_ < lim ? rg_ : lim) * 16;
             const char* g_b = reinterpret_cast<const char*>(job.p + rbase * 4);
             const char* m_b = reinterpret_cast<const char*>(job.mask + rbase * 4);
-            const uint4* src = lane < 32 ? (rg_ < n_valid ? reinterpret_cast<const uint4*>(g_b + og) : &g_f32_zero16)
+            const uint4* src = lane < 32 ? (rg_ < n_valid ? reinterpret_cast<const uint4*>(g_b + og) : zero16)
                                          : reinterpret_cast<const uint4*>(m_b + og);
             __builtin_amdgcn_global_load_lds(src, (f32_lds_void*)(sb + F::OFF_G), 16, 0, 0);
         }

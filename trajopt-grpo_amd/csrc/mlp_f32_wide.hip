@@ -397,12 +397,17 @@ constexpr int kWdLds = kWdDL * kWdSlotL > kWdDW * kWdSlotW ? kWdDL * kWdSlotL : 
 
 // `nrow` rows x 256 floats of `gsrc` (row-major) from row r0 on into a linear LDS panel: 1 KiB pieces = one row each, waves take
 // pieces wave, wave + 8, ...  kZero: rows past the end arrive as zeros instead of as re-reads of the last row
-template <bool kZero>
-__device__ static inline void f32w_dma_rows(const float* __restrict__ gsrc, int64_t r0, int64_t rows, char* panel, int nrow, int wave, int lane) {
-    for (int q = wave; q < nrow; q += 8) {
+// (`zero` = &g_f32w_zero16 held in registers by the caller: written in place, hipcc re-loads the symbol's address through the GOT in
+// front of every DMA -- a scalar memory round trip per piece, ~15 % of a wide stage)
+template <bool kZero, int NROW>
+__device__ static inline void f32w_dma_rows(const float* __restrict__ gsrc, int64_t r0, int64_t rows, char* panel, int wave, int lane,
+                                            const uint4* zero) {
+#pragma unroll
+    for (int t = 0; t < NROW / 8; ++t) {
+        const int q = wave + 8 * t;
         const int64_t r = r0 + q;
         const uint4* src = reinterpret_cast<const uint4*>(gsrc + (r < rows ? r : rows - 1) * kWideH) + lane;
-        if constexpr (kZero) src = r < rows ? src : &g_f32w_zero16;
+        if constexpr (kZero) src = r < rows ? src : zero;
         __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(panel + q * 1024), 16, 0, 0);
     }
 }
@@ -415,6 +420,8 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
     char* lds_c = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
+    const uint4* zero16 = &g_f32w_zero16;
+    asm volatile("" : "+s"(zero16));                        // (opaque: the address stays in a register pair)
     TG_CLOCK_PROBE_BEGIN(g_probe_f32_wide_dw)
     // this workgroup's job (uniform)
     int ji = 0;
@@ -450,8 +457,8 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
         const int bcol = tid & 255, brow0 = (tid >> 8) * (SR / 2);       // bias: column, first row of this thread's half stage
         auto issue = [&](int64_t sg, int slot) {
             char* sb = lds_c + slot * kWdSlotW;
-            f32w_dma_rows<true>(jp, sg * SR, rows, sb, SR, wave, lane);
-            f32w_dma_rows<false>(jq, sg * SR, rows, sb + SR * H * 4, SR, wave, lane);
+            f32w_dma_rows<true, SR>(jp, sg * SR, rows, sb, wave, lane, zero16);
+            f32w_dma_rows<false, SR>(jq, sg * SR, rows, sb + SR * H * 4, wave, lane, zero16);
         };
         int64_t sg_issue = my;
         int slot_issue = 0, slot = 0;
@@ -479,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
             for (int x = 0; x < 4; ++x) av[x] = wide_lds_f(pa + 32 * x);
 #pragma unroll
             for (int y = 0; y < 2; ++y) bv[y] = wide_lds_f(qa + 32 * y);
+            float bcur = wide_lds_f(Pp + brow0 * H + bcol), bnext = 0.f;     // (bias column: consumed one step after it is read, like the operands)
 #pragma unroll
             for (int s = 0; s < SR / 2; ++s) {
                 if (s + 1 < SR / 2) {
@@ -486,8 +494,10 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
                     for (int x = 0; x < 4; ++x) an[x] = wide_lds_f(pa + (2 * s + 2) * H + 32 * x);
 #pragma unroll
                     for (int y = 0; y < 2; ++y) bn[y] = wide_lds_f(qa + (2 * s + 2) * H + 32 * y);
+                    bnext = wide_lds_f(Pp + (brow0 + s + 1) * H + bcol);
                 }
-                bsum += wide_lds_f(Pp + (brow0 + s) * H + bcol);          // (rows past the end are zeros)
+                bsum += bcur;                                             // (rows past the end are zeros)
+                bcur = bnext;
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -538,13 +548,13 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
             const int64_t r0 = sg * SR;
             // (the first layer's dZ arrives as zeros past the end: its products and column sums need no masking; the head's
             // activation is clamped and its g rows arrive as zeros)
-            if (head) f32w_dma_rows<false>(wide, r0, rows, sb, SR, wave, lane);
-            else f32w_dma_rows<true>(wide, r0, rows, sb, SR, wave, lane);
+            if (head) f32w_dma_rows<false, SR>(wide, r0, rows, sb, wave, lane, zero16);
+            else f32w_dma_rows<true, SR>(wide, r0, rows, sb, wave, lane, zero16);
             // the narrow operand as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece, 4 pieces (waves 4..7 repeat)
             const int piece = wave & 3;
             const int64_t r = r0 + piece * 8 + (lane >> 3);
             const int c4 = lane & 7;
-            const uint4* src = (c4 < thin_f4 && r < rows) ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : &g_f32w_zero16;
+            const uint4* src = (c4 < thin_f4 && r < rows) ? reinterpret_cast<const uint4*>(thin + r * (4 * thin_f4)) + c4 : zero16;
             __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(sb + SR * H * 4 + piece * 1024), 16, 0, 0);
         };
         int64_t sg_issue = my;
