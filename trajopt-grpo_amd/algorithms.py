@@ -682,8 +682,11 @@ class PPO(_GpuLearner):
         old_logp = (self._ws.get("old_logp", n_rows, 1, torch.float32, dev, cap).view(-1) if fold_old else
                     self._logp_nograd(actor, xin, act, var))
         all_sums = []
-        self._sum_rows = (list(torch.zeros(self.updates_per_iter, 2, 4, dtype=torch.float64, device=dev).unbind(0))
-                          if self.batch_size is None and self.updates_per_iter > 0 else None)
+        # full batch: the updates' [actor | critic] loss sums are the rows of ONE pre-zeroed table (update u <- row u): one fill, one
+        # all-reduce, and the arithmetic that turns them into losses waits until somebody asks (last_stats)
+        table = (torch.zeros(self.updates_per_iter, 2, 4, dtype=torch.float64, device=dev)
+                 if self.batch_size is None and self.updates_per_iter > 0 else None)
+        self._sum_rows = list(table.unbind(0))[::-1] if table is not None else None
         norm_host = None
         for u in range(self.updates_per_iter):
             final = u == self.updates_per_iter - 1
@@ -712,19 +715,21 @@ class PPO(_GpuLearner):
         self._check_deferred()                                              # (this learn()'s own row count: landed long ago)
         self._copy_policy_to_old()                                          # ppo.py:186
         if all_sums:
-            S2 = torch.stack(all_sums)                                      # [steps][actor | critic][4]
-            S = S2[:, 0].contiguous()
-            S[:, 1] += S2[:, 1, 1]                                          # the critic's squared error
-            D.allreduce_sum_(S, self.process_group, "loss_stats")
-            nn = S[:, 3]
+            S2 = table if table is not None else torch.stack(all_sums)      # [steps][actor | critic][4]
+            D.allreduce_sum_(S2, self.process_group, "loss_stats")
             ent = 0.5 * act.shape[1] * (1.0 + math.log(2 * math.pi)) + 0.5 * float(torch.log(var).sum())
-            a_loss = (-S[:, 0] / nn)
-            c_loss = (S[:, 1] / nn)
-            kl = (S[:, 2] / nn)
-            total = a_loss + self.c1 * c_loss - self.entropy * ent + self.kl_coeff * kl
+            c1, ent_c, kl_c = self.c1, self.entropy, self.kl_coeff
             n_dev = moments[0, 0].clone()                                   # (the buffers above are re-used by the next learn())
-            self._stats_pending = lambda: {"actor_loss": a_loss.tolist(), "critic_loss": c_loss.tolist(), "kl_div": kl.tolist(),
-                                           "total_loss": total.tolist(), "entropy": ent, "n_valid": float(n_dev)}
+
+            def stats():
+                S = S2[:, 0].clone()
+                S[:, 1] += S2[:, 1, 1]                                      # the critic's squared error
+                nn = S[:, 3]
+                a_loss, c_loss, kl = -S[:, 0] / nn, S[:, 1] / nn, S[:, 2] / nn
+                total = a_loss + c1 * c_loss - ent_c * ent + kl_c * kl
+                return {"actor_loss": a_loss.tolist(), "critic_loss": c_loss.tolist(), "kl_div": kl.tolist(),
+                        "total_loss": total.tolist(), "entropy": ent, "n_valid": float(n_dev)}
+            self._stats_pending = stats
 
     def metadata(self) -> dict:
         return {"algorithm": "PPO", "epsilon": self.epsilon, "c1": self.c1, "kl_coeff": self.kl_coeff,
