@@ -507,16 +507,6 @@ typedef struct tg_f32_dw_job {
     float*       d_w0grad;
     float*       d_b0grad;
     int64_t      w0grad_ld;
-    /* hidden = 256 (one workgroup per CU, every operand read back from HBM): the two light gradients may RIDE on wide jobs WITHOUT
-     * anything being rebuilt -- a light job of its own is bound by the ~17 GB/s one workgroup streams, a rider spreads the same bytes
-     * over every workgroup of its wide job:
-     *   bit 2 (recompute & 4): the FIRST layer's gradient rides -- d_dz0 f32 [rows][H], d_x = the net input f32 [rows][in_pad],
-     *     d_w0grad / d_b0grad / w0grad_ld / in_dim as above;
-     *   bit 3 (recompute & 8): the HEAD's gradient rides -- d_a_top f32 [rows][H], d_g = d loss / d output f32 [rows][4],
-     *     d_whgrad / d_bhgrad / whgrad_ld / act_dim as above.
-     * (bits 0 / 1 are not available at hidden = 256.) */
-    const float* d_x;
-    const float* d_g;
 } tg_f32_dw_job;
 int64_t tg_mlp_f32_weight_grad_workspace(int32_t hidden);
 /* d_loss_work / n_loss_rows / d_loss_sums (optional, both pointers or neither): the reduction launch also adds rows [0, n_loss_rows)

@@ -1533,8 +1533,10 @@ def test_first_update_can_stand_in_for_the_old_policy_pass(tg, dev, kind, cdt, h
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kind,cdt,hidden", [("grpo", None, (128, 128)), ("ppo", torch.bfloat16, (256, 256, 256)), ("ppo", None, (40, 40))])
-def test_weights_written_through_data_are_seen_by_the_next_rollout_and_learn(tg, dev, kind, cdt, hidden):
+@pytest.mark.parametrize("kind,cdt,hidden,graph", [("grpo", None, (128, 128), None), ("ppo", torch.bfloat16, (256, 256, 256), None), ("ppo", None, (40, 40), None),
+                                                   ("ppo", None, (40, 40), False),          # the EAGER per-step engine (it trusted the keys)
+                                                   ("ppo", None, (256, 256), False)])       # ... with the H = 256 fp32 chain's no-grad pass under it
+def test_weights_written_through_data_are_seen_by_the_next_rollout_and_learn(tg, dev, kind, cdt, hidden, graph):
     """a write through `param.data` moves no version counter, so keys alone would leave every derived layout (the
     learner's streams, the fused fp32 rollout's register stream) stale.  Layouts are rebuilt at every learn() / rollout entry
     whatever the keys say: a run whose weights are clamped through `.data` after every learn() must equal, bit for bit, the run
@@ -1544,7 +1546,7 @@ def test_weights_written_through_data_are_seen_by_the_next_rollout_and_learn(tg,
         cls = tg.GaussianActorCritic_NeuralNetwork if kind == "ppo" else tg.GaussianActor_NeuralNetwork
         S, A, env = (5, 1, lambda: tg.CartPole(max_steps=40)) if cdt is None else (20, 4, lambda: tg.QuadPole(max_steps=40))
         pol = cls(S, A, hidden, cov=0.4, device=dev)
-        mgr = tg.RolloutManager(env, pol, num_workers=4, num_episodes_per_worker=32, seed=2, compute_dtype=cdt)
+        mgr = tg.RolloutManager(env, pol, num_workers=4, num_episodes_per_worker=32, seed=2, compute_dtype=cdt, use_graph=graph)
         buf = tg.Rollout_Buffer(mgr)
         opt = torch.optim.Adam(pol.parameters(), lr=1e-2)
         algo = (tg.PPO(epsilon=0.2, policy=pol, optimizer=opt, ref_model=None, updates_per_iter=2, gamma=0.99, batch_size=None, autocast_dtype=cdt)

@@ -14,13 +14,6 @@ def job(kind, p, q, ncols, w, b, m_out, n_out):
     j.wgrad_ld, j.kind, j.n_cols, j.m_out, j.n_out = w.stride(0), kind, ncols, m_out, n_out
     return j
 J = {"mm": job(0, dz, a, H, wg, bg, H, H), "x": job(0, dz, x, XC, w0, bg, H, 5 if H != 256 else 20), "head": job(1, g, a, H, wh, bh, 1, H)}
-if H == 256:                                                 # wide jobs carrying a rider (recompute bits 4 / 8: nothing rebuilt)
-    bg0 = torch.zeros(H, device=dev)
-    jx = job(0, dz, a, H, wg, bg, H, H); jx.recompute, jx.in_pad, jx.in_dim = 4, XC, 20
-    jx.d_dz0, jx.d_x, jx.d_w0grad, jx.d_b0grad, jx.w0grad_ld = dz.data_ptr(), x.data_ptr(), w0.data_ptr(), bg0.data_ptr(), w0.stride(0)
-    jh = job(0, dz, a, H, wg, bg, H, H); jh.recompute, jh.act_dim = 8, 1
-    jh.d_a_top, jh.d_g, jh.d_whgrad, jh.d_bhgrad, jh.whgrad_ld = a.data_ptr(), g.data_ptr(), wh.data_ptr(), bh.data_ptr(), wh.stride(0)
-    J["mmx"], J["mmh"] = jx, jh
 def run(names):
     arr = (N.F32DwJob * len(names))(*[J[n] for n in names])
     def f():

@@ -70,8 +70,7 @@ class F32DwJob(C.Structure):
                 ("recompute", C.c_int32), ("in_pad", C.c_int32), ("in_dim", C.c_int32), ("act_dim", C.c_int32),
                 ("d_w0", C.c_void_p), ("d_b0", C.c_void_p), ("d_wh", C.c_void_p), ("d_maskbits", C.c_void_p),
                 ("d_a_top", C.c_void_p), ("d_whgrad", C.c_void_p), ("d_bhgrad", C.c_void_p), ("whgrad_ld", C.c_int64),
-                ("d_dz0", C.c_void_p), ("d_w0grad", C.c_void_p), ("d_b0grad", C.c_void_p), ("w0grad_ld", C.c_int64),
-                ("d_x", C.c_void_p), ("d_g", C.c_void_p)]
+                ("d_dz0", C.c_void_p), ("d_w0grad", C.c_void_p), ("d_b0grad", C.c_void_p), ("w0grad_ld", C.c_int64)]
 
 
 TG_F32DW_MM, TG_F32DW_HEAD = 0, 1

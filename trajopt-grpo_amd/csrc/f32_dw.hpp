@@ -24,8 +24,6 @@ struct F32DwJob {
     const float* a_top;     // head rider: the top activation f32 [rows][H]
     const float* dz0;       // first-layer rider: the bottom dZ f32 [rows][H]
     int32_t ring_slots;     // 2 or 3
-    const float* x;         // H = 256 riders (recompute & 4 / & 8, nothing rebuilt): the net input rows f32 [rows][in_pad] / d loss / d output
-    const float* g;         // f32 [rows][4]; their wide operands are dz0 / a_top above
 };
 struct F32DwArgs { F32DwJob job[kF32DwMaxJobs]; int32_t n_jobs; };
 

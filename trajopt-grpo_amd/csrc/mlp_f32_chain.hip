@@ -1787,13 +1787,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         } else {
             TG_REQUIRE(jb.n_cols == H || (jb.n_cols >= 8 && jb.n_cols <= 32 && jb.n_cols % 8 == 0), "tg_mlp_f32_weight_grad: job %d: %d columns", j, jb.n_cols);
             TG_REQUIRE(jb.m_out == H && jb.n_out >= 1 && jb.n_out <= jb.n_cols && jb.wgrad_ld >= jb.n_out, "tg_mlp_f32_weight_grad: job %d: bad window", j);
-            TG_REQUIRE(jb.recompute >= 0 && (H == 256 ? (jb.recompute & 3) == 0 && jb.recompute <= 12 : jb.recompute <= 3) && (jb.recompute == 0 || jb.n_cols == H),
-                       "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
-            TG_REQUIRE(!(jb.recompute & 4) || (jb.d_dz0 && jb.d_x && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad &&
-                                               jb.d_w0grad && jb.d_b0grad && jb.w0grad_ld >= jb.in_dim),
-                       "tg_mlp_f32_weight_grad: job %d carries the first layer's gradient: bottom dZ / input rows / windows missing", j);
-            TG_REQUIRE(!(jb.recompute & 8) || (jb.d_a_top && jb.d_g && jb.act_dim >= 1 && jb.act_dim <= 4 && jb.d_whgrad && jb.d_bhgrad && jb.whgrad_ld >= H),
-                       "tg_mlp_f32_weight_grad: job %d carries the head's gradient: top activation / d loss / d output / windows missing", j);
+            TG_REQUIRE(jb.recompute >= 0 && jb.recompute <= 3 && (jb.recompute == 0 || (jb.n_cols == H && H != 256)), "tg_mlp_f32_weight_grad: job %d: recompute %d", j, jb.recompute);
             TG_REQUIRE(!(jb.recompute & 1) || (jb.d_w0 && jb.d_b0 && jb.in_pad >= 8 && jb.in_pad <= 32 && jb.in_pad % 8 == 0 && jb.in_dim >= 1 && jb.in_dim <= jb.in_pad &&
                                                jb.d_dz0 && jb.d_w0grad && jb.d_b0grad && jb.w0grad_ld >= jb.in_dim),
                        "tg_mlp_f32_weight_grad: job %d rebuilds the first activation: first-layer weights / input width / rider missing", j);
@@ -1803,13 +1797,10 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
             if (jb.n_cols == H) {
                 ++n_wide;
                 // products per stage and wave: 32 (H = 128), + 8 for the first layer's tile; the head rider is vector work
-                weight[j] = 1.0 + ((jb.recompute & 1) ? 0.25 : 0.0) + ((jb.recompute & 2) ? 0.05 : 0.0) +
-                            ((jb.recompute & 4) ? 0.16 : 0.0) + ((jb.recompute & 8) ? 0.06 : 0.0);      // (H = 256 riders: 8 more products per 64 / vector work)
+                weight[j] = 1.0 + ((jb.recompute & 1) ? 0.25 : 0.0) + ((jb.recompute & 2) ? 0.05 : 0.0);
                 wide_sum += weight[j];
             }
-            if (H == 256 && jb.recompute) {
-                fused_slab[j] = H * H + H + ((jb.recompute & 4) ? H * 32 + H : 0) + ((jb.recompute & 8) ? 4 * H + 4 : 0);
-            } else if (jb.recompute) {
+            if (jb.recompute) {
                 auto fit = [&](auto geom) {
                     using F = decltype(geom);
                     ring_slots[j] = F::lds_bytes(3, jb.in_pad) <= F32DwGeom<128>::LDS_MAX ? 3 : 2;
@@ -1854,7 +1845,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
     }
     {
         int n_desc = 0;
-        for (int j = 0; j < n_jobs; ++j) n_desc += 2 + ((jobs[j].recompute & 5) ? 2 : 0) + ((jobs[j].recompute & 10) ? 2 : 0);
+        for (int j = 0; j < n_jobs; ++j) n_desc += 2 + ((jobs[j].recompute & 1) ? 2 : 0) + ((jobs[j].recompute & 2) ? 2 : 0);
         TG_REQUIRE(n_desc <= 2 * kF32DwMaxJobs, "tg_mlp_f32_weight_grad: %d gradient windows exceed %d", n_desc, 2 * kF32DwMaxJobs);
     }
     F32DwArgs args{};
@@ -1868,7 +1859,7 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         dj.p = jb.d_p; dj.q = jb.d_q; dj.kind = jb.kind; dj.n = jb.n_cols;
         dj.recompute = jb.recompute; dj.in_pad = jb.in_pad; dj.in_dim = jb.in_dim; dj.act_dim = jb.act_dim;
         dj.w0 = jb.d_w0; dj.b0 = jb.d_b0; dj.wh = jb.d_wh; dj.mask = jb.d_maskbits;
-        dj.a_top = jb.d_a_top; dj.dz0 = jb.d_dz0; dj.ring_slots = ring_slots[j]; dj.x = jb.d_x; dj.g = jb.d_g;
+        dj.a_top = jb.d_a_top; dj.dz0 = jb.d_dz0; dj.ring_slots = ring_slots[j];
         dj.first_block = grid;
         // at least 4 stages per workgroup
         const int64_t n_st = ceil_div(rows, (int64_t)(bytes[j] == 0 ? (H >= 128 ? 16 : 32) : (H >= 128 ? 32 : 64)));
@@ -1889,14 +1880,14 @@ int tg_mlp_f32_weight_grad_adam(int32_t hidden, const tg_f32_dw_job* jobs, int32
         }
         // the riders' parts of a fused job's slab: [H x H][H] | first layer [H x 32][H] | head [4 x H][4]
         int64_t roff = off + H * H + H;
-        if (jb.recompute & 5) {
+        if (jb.recompute & 1) {
             fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_w0grad, jb.w0grad_ld, dj.slab_len, dj.n_blocks, w0cols, H, jb.in_dim, elems};
             elems += H * jb.in_dim;
             fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + H * w0cols, jb.d_b0grad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, H, elems};
             elems += H;
             roff += H * w0cols + H;
         }
-        if (jb.recompute & 10) {
+        if (jb.recompute & 2) {
             fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff, jb.d_whgrad, jb.whgrad_ld, dj.slab_len, dj.n_blocks, H, jb.act_dim, H, elems};
             elems += jb.act_dim * H;
             fa.d[fa.n++] = F32FinishDesc{(const float*)d_workspace + roff + 4 * H, jb.d_bhgrad, (int64_t)H, dj.slab_len, dj.n_blocks, H, 1, jb.act_dim, elems};

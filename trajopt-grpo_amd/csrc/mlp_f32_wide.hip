@@ -26,7 +26,8 @@
 
 #ifndef TG_F32W_ABLATE
 #define TG_F32W_ABLATE 0           /* timing-only probe builds of the chain kernel (results meaningless): bit 0 = no block barrier, bit 1 = no
-                                      weight DMA inside the rounds, bit 2 = no activation / dZ stores (tools/f32_wide_ablation.sh) */
+                                      weight DMA inside the rounds, bit 2 = no activation / dZ stores (tools/f32_wide_ablation.sh); of the wide
+                                      weight-gradient job: bit 3 = no stage barrier, bit 4 = no DMA inside the stage loop */
 #endif
 
 namespace tg {
@@ -393,10 +394,7 @@ constexpr int kWdSlotL = kWdSRL * kWideH * 4 + kWdSRL * 128;            // 36 Ki
 constexpr int kWdDW = 4, kWdDL = 4;                                     // ring slots: wide jobs (bound by the matrix pipe: 9 GB/s per CU) /
                                                                         // light jobs (bound by the bytes in flight: 3 stages = 108 KiB)
 constexpr int kWdNGW = 4, kWdNGL = 5;                                   // DMA instructions per wave and stage
-constexpr int kWdSlotWR = kWdSlotW + kWdSRW * kWideH * 4 + kWdSRW * 128; // a wide stage with a rider: + its wide operand + the [16][32] image = 50 KiB
-constexpr int kWdDWR = 3;                                               // ... through 3 slots (150 KiB)
-constexpr int kWdLds0 = kWdDL * kWdSlotL > kWdDW * kWdSlotW ? kWdDL * kWdSlotL : kWdDW * kWdSlotW;
-constexpr int kWdLds = kWdDWR * kWdSlotWR > kWdLds0 ? kWdDWR * kWdSlotWR : kWdLds0;
+constexpr int kWdLds = kWdDL * kWdSlotL > kWdDW * kWdSlotW ? kWdDL * kWdSlotL : kWdDW * kWdSlotW;
 
 // `nrow` rows x 256 floats of `gsrc` (row-major) from row r0 on into a linear LDS panel: 1 KiB pieces = one row each, waves take
 // pieces wave, wave + 8, ...  kZero: rows past the end arrive as zeros instead of as re-reads of the last row
@@ -412,161 +410,6 @@ __device__ static inline void f32w_dma_rows(const float* __restrict__ gsrc, int6
         const uint4* src = reinterpret_cast<const uint4*>(gsrc + (r < rows ? r : rows - 1) * kWideH) + lane;
         if constexpr (kZero) src = r < rows ? src : zero;
         __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(panel + q * 1024), 16, 0, 0);
-    }
-}
-
-// One wide job for this workgroup's share of the stages (see the header of this section).  kRider: 0 = none; 1 = the FIRST layer's
-// gradient rides (rw = the bottom dZ [rows][256], rt = the net input rows, thin_f4 float4 each): one more 32 x 32 tile per wave
-// (dW_0 rows 32 wave .. + 32) and the column sums of dZ_0; 2 = the HEAD's gradient rides (rw = the top activation, rt = d loss /
-// d output [rows][4]): vector arithmetic, one column and half a stage per thread.  A rider's operands travel in the wide job's own
-// stages (16 more KiB + a [16][32]-float image per slot), so their bytes are spread over all of the job's workgroups instead of
-// being streamed by a few workgroups of their own at ~17 GB/s each.
-template <int kRider>
-__device__ static inline void f32w_wide_job(const float* __restrict__ jp, const float* __restrict__ jq, const float* __restrict__ rw,
-                                            const float* __restrict__ rt, int thin_f4, int64_t rows, int my, int nb, char* lds_c,
-                                            float* __restrict__ slab, const uint4* zero16) {
-    constexpr int H = kWideH, SR = kWdSRW;
-    constexpr int SLOT = kRider ? kWdSlotWR : kWdSlotW, D = kRider ? kWdDWR : kWdDW, P = D - 1, NG = kRider ? kWdNGW + 3 : kWdNGW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, kk = lane >> 5;
-    const int64_t n_st = (rows + SR - 1) / SR;
-    const int wm = wave >> 2, wn = wave & 3;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-    f32x16 racc;                                                     // rider 1: the first layer's tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-    float hacc[4] = {0.f, 0.f, 0.f, 0.f};                            // rider 2: the head's column
-    float bsum = 0.f, rbsum = 0.f;
-    const int bcol = tid & 255, brow0 = (tid >> 8) * (SR / 2);       // bias: column, first row of this thread's half stage
-    auto issue = [&](int64_t sg, int slot) {
-        char* sb = lds_c + slot * SLOT;
-        const int64_t r0 = sg * SR;
-        f32w_dma_rows<true, SR>(jp, r0, rows, sb, wave, lane, zero16);
-        f32w_dma_rows<false, SR>(jq, r0, rows, sb + SR * H * 4, wave, lane, zero16);
-        if constexpr (kRider != 0) {
-            // (rider 1: dZ_0 arrives as zeros past the end; rider 2: the activation is clamped, its g rows arrive as zeros)
-            if constexpr (kRider == 1) f32w_dma_rows<true, SR>(rw, r0, rows, sb + 2 * SR * H * 4, wave, lane, zero16);
-            else f32w_dma_rows<false, SR>(rw, r0, rows, sb + 2 * SR * H * 4, wave, lane, zero16);
-            // the narrow operand as a zero-padded [SR][32 floats] image: 8 lanes per row, 8 rows per piece, 2 pieces (waves 2..7 repeat)
-            const int piece = wave & 1;
-            const int64_t r = r0 + piece * 8 + (lane >> 3);
-            const int c4 = lane & 7;
-            const uint4* src = (c4 < thin_f4 && r < rows) ? reinterpret_cast<const uint4*>(rt + r * (4 * thin_f4)) + c4 : zero16;
-            __builtin_amdgcn_global_load_lds(src, (f32w_lds_void*)(sb + 3 * SR * H * 4 + piece * 1024), 16, 0, 0);
-        }
-    };
-    int64_t sg_issue = my;
-    int slot_issue = 0, slot = 0;
-#pragma unroll 1
-    for (int t = 0; t < P; ++t) {
-        issue(sg_issue, slot_issue);
-        sg_issue += nb;
-        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
-    }
-#pragma unroll 1
-    for (int64_t sg = my; sg < n_st; sg += nb) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue(sg_issue, slot_issue);
-        sg_issue += nb;
-        slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
-        const float* Pp = reinterpret_cast<const float*>(lds_c + slot * SLOT);
-        const float* Qp = Pp + SR * H;
-        const float* Rp = Qp + SR * H;                               // rider: its wide operand, then the image [SR][32]
-        const float* Tp = Rp + SR * H;
-        slot = slot + 1 == D ? 0 : slot + 1;
-        const float* pa = Pp + kk * H + 128 * wm + i;
-        const float* qa = Qp + kk * H + 64 * wn + i;
-        float av[4], bv[2], an[4], bn[2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = wide_lds_f(pa + 32 * x);
-#pragma unroll
-        for (int y = 0; y < 2; ++y) bv[y] = wide_lds_f(qa + 32 * y);
-        float bcur = wide_lds_f(Pp + brow0 * H + bcol), bnext = 0.f;     // (bias column: consumed one step after it is read, like the operands)
-        [[maybe_unused]] float ra = 0.f, rb = 0.f, rna = 0.f, rnb = 0.f, rbcur = 0.f, rbnext = 0.f;
-        if constexpr (kRider == 1) {
-            ra = wide_lds_f(Rp + kk * H + 32 * wave + i);
-            rb = wide_lds_f(Tp + kk * 32 + i);
-            rbcur = wide_lds_f(Rp + brow0 * H + bcol);
-        }
-#pragma unroll
-        for (int s = 0; s < SR / 2; ++s) {
-            if (s + 1 < SR / 2) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) an[x] = wide_lds_f(pa + (2 * s + 2) * H + 32 * x);
-#pragma unroll
-                for (int y = 0; y < 2; ++y) bn[y] = wide_lds_f(qa + (2 * s + 2) * H + 32 * y);
-                bnext = wide_lds_f(Pp + (brow0 + s + 1) * H + bcol);
-                if constexpr (kRider == 1) {
-                    rna = wide_lds_f(Rp + (2 * s + 2 + kk) * H + 32 * wave + i);
-                    rnb = wide_lds_f(Tp + (2 * s + 2 + kk) * 32 + i);
-                    rbnext = wide_lds_f(Rp + (brow0 + s + 1) * H + bcol);
-                }
-            }
-            bsum += bcur;                                             // (rows past the end are zeros)
-            bcur = bnext;
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
-            if constexpr (kRider == 1) {
-                racc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra, rb, racc, 0, 0, 0);
-                rbsum += rbcur;
-                ra = rna; rb = rnb; rbcur = rbnext;
-            }
-            if constexpr (kRider == 2) {
-                // one column and half a stage per thread, one row per step (its g row: zeros past the end)
-                const float4 g4 = wide_lds_f4(Tp + 32 * (brow0 + s));
-                const float qv = wide_lds_f(Rp + (brow0 + s) * H + bcol);
-                hacc[0] = fmaf(g4.x, qv, hacc[0]); hacc[1] = fmaf(g4.y, qv, hacc[1]);
-                hacc[2] = fmaf(g4.z, qv, hacc[2]); hacc[3] = fmaf(g4.w, qv, hacc[3]);
-                if (tid < 4) rbsum += wide_lds_f(Tp + 32 * (2 * s) + tid) + wide_lds_f(Tp + 32 * (2 * s + 1) + tid);
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) av[x] = an[x];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) bv[y] = bn[y];
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
-    // the two half stages' bias sums (and the riders' sums) meet in LDS and are added in a fixed order
-    float* red = reinterpret_cast<float*>(lds_c);
-    __syncthreads();
-    red[tid] = bsum;
-    if constexpr (kRider == 1) red[512 + tid] = rbsum;
-    if constexpr (kRider == 2) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) red[512 + k * 512 + tid] = hacc[k];
-    }
-    __syncthreads();
-    if (tid < H) slab[H * H + tid] = red[tid] + red[H + tid];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int m0 = 128 * wm + 32 * x, n0 = 64 * wn + 32 * y;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * H + n0 + i] = acc[x][y][r];
-        }
-    float* rslab = slab + H * H + H;                  // the rider's part: [256][32] then 256 bias sums / [4][256] then 4
-    if constexpr (kRider == 1) {
-        if (tid < H) rslab[H * 32 + tid] = red[512 + tid] + red[512 + H + tid];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rslab[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = racc[r];
-    }
-    if constexpr (kRider == 2) {
-        if (tid < H) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rslab[k * H + tid] = red[512 + k * 512 + tid] + red[512 + k * 512 + H + tid];
-        }
-        if (tid < 4) rslab[4 * H + tid] = rbsum;
     }
 }
 
@@ -589,26 +432,110 @@ __global__ __launch_bounds__(512, 2) void mlp_f32_wide_dw_kernel(F32DwArgs args,
     const float* jp = args.job[0].p; const float* jq = args.job[0].q;
     int jkind = args.job[0].kind, jn = args.job[0].n, jfirst = args.job[0].first_block, jnb = args.job[0].n_blocks, jslab = args.job[0].slab_len;
     int64_t joff = args.job[0].slab_off;
-    int jrec = args.job[0].recompute, jin_pad = args.job[0].in_pad;
-    const float* jdz0 = args.job[0].dz0; const float* jx = args.job[0].x; const float* jatop = args.job[0].a_top; const float* jg = args.job[0].g;
 #pragma unroll
     for (int t = 1; t < kF32DwMaxJobs; ++t)
         if (ji == t) {
             jp = args.job[t].p; jq = args.job[t].q; jkind = args.job[t].kind; jn = args.job[t].n; jfirst = args.job[t].first_block;
             jnb = args.job[t].n_blocks; jslab = args.job[t].slab_len; joff = args.job[t].slab_off;
-            jrec = args.job[t].recompute; jin_pad = args.job[t].in_pad;
-            jdz0 = args.job[t].dz0; jx = args.job[t].x; jatop = args.job[t].a_top; jg = args.job[t].g;
         }
     const int my = (int)blockIdx.x - jfirst, nb = jnb;
     const bool head = jkind == F32DW_HEAD, narrow = !head && jn <= 32;
     float* slab = ws + joff + (int64_t)my * jslab;
 
     if (!head && !narrow) {
-        // ================= wide job (with at most one rider) =================
-        const int rider = (jrec & 4) ? 1 : ((jrec & 8) ? 2 : 0);
-        if (rider == 0) f32w_wide_job<0>(jp, jq, nullptr, nullptr, 0, rows, my, nb, lds_c, slab, zero16);
-        else if (rider == 1) f32w_wide_job<1>(jp, jq, jdz0, jx, jin_pad / 4, rows, my, nb, lds_c, slab, zero16);
-        else f32w_wide_job<2>(jp, jq, jatop, jg, 1, rows, my, nb, lds_c, slab, zero16);
+        // ================= wide job =================
+        constexpr int SR = kWdSRW, D = kWdDW, P = D - 1, NG = kWdNGW;
+        const int64_t n_st = (rows + SR - 1) / SR;
+        const int wm = wave >> 2, wn = wave & 3;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+        float bsum = 0.f;
+        const int bcol = tid & 255, brow0 = (tid >> 8) * (SR / 2);       // bias: column, first row of this thread's half stage
+        auto issue = [&](int64_t sg, int slot) {
+            char* sb = lds_c + slot * kWdSlotW;
+            f32w_dma_rows<true, SR>(jp, sg * SR, rows, sb, wave, lane, zero16);
+            f32w_dma_rows<false, SR>(jq, sg * SR, rows, sb + SR * H * 4, wave, lane, zero16);
+        };
+        int64_t sg_issue = my;
+        int slot_issue = 0, slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < P; ++t) {
+            issue(sg_issue, slot_issue);
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+        }
+#pragma unroll 1
+        for (int64_t sg = my; sg < n_st; sg += nb) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NG) : "memory");
+#if !(TG_F32W_ABLATE & 8)                              /* probe builds (timing only): bit 3 = no stage barrier, bit 4 = no DMA inside the stage loop */
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+#if !(TG_F32W_ABLATE & 16)
+            issue(sg_issue, slot_issue);
+#endif
+            sg_issue += nb;
+            slot_issue = slot_issue + 1 == D ? 0 : slot_issue + 1;
+            const float* Pp = reinterpret_cast<const float*>(lds_c + slot * kWdSlotW);
+            const float* Qp = Pp + SR * H;
+            slot = slot + 1 == D ? 0 : slot + 1;
+            const float* pa = Pp + kk * H + 128 * wm + i;
+            const float* qa = Qp + kk * H + 64 * wn + i;
+            float av[4], bv[2], an[4], bn[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) av[x] = wide_lds_f(pa + 32 * x);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bv[y] = wide_lds_f(qa + 32 * y);
+            float bcur = wide_lds_f(Pp + brow0 * H + bcol), bnext = 0.f;     // (bias column: consumed one step after it is read, like the operands)
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s) {
+                if (s + 1 < SR / 2) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) an[x] = wide_lds_f(pa + (2 * s + 2) * H + 32 * x);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) bn[y] = wide_lds_f(qa + (2 * s + 2) * H + 32 * y);
+                    bnext = wide_lds_f(Pp + (brow0 + s + 1) * H + bcol);
+                }
+                bsum += bcur;                                             // (rows past the end are zeros)
+                bcur = bnext;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) av[x] = an[x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) bv[y] = bn[y];
+            }
+            // pin the order: a step's LDS reads (6 operands + 1 bias element, merged pairwise by hipcc: ~4 instructions) ahead of the
+            // previous step's 8 products
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < SR / 2; ++s) {
+                if (s + 1 < SR / 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+        // the two half stages' bias sums meet in LDS and are added in a fixed order
+        float* red = reinterpret_cast<float*>(lds_c);
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < H) slab[H * H + tid] = red[tid] + red[H + tid];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int m0 = 128 * wm + 32 * x, n0 = 64 * wn + 32 * y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(m0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * H + n0 + i] = acc[x][y][r];
+            }
     } else {
         // ================= light job: one wide operand, 32 rows per stage =================
         constexpr int SR = kWdSRL, D = kWdDL, P = D - 1, NG = kWdNGL;

@@ -573,14 +573,11 @@ class GemmMLP:
         # (kind, P, Q, columns of Q, weight window, bias window, rows x columns of the window, rebuild bits)
         specs = []
         fused = False
-        # H = 256 with >= 2 wide jobs: the first layer's and the head's gradients RIDE on the second layer's / the top layer's job
-        # (bits 4 / 8: nothing rebuilt, their operands travel in those jobs' stages) instead of being light jobs of their own
-        riders = f.wide and nh >= 3 and acts[0] is not None and dzs[nh - 1] is not None
         for i in range(nh - 1, 0, -1):
             rp, rq = dzs[i] is None, acts[i - 1] is None           # top layer's dZ / first activation rebuilt on chip
-            fused = fused or rp or rq or riders
-            bits = ((4 if i == 1 else 0) | (8 if i == nh - 1 else 0)) if riders else ((2 if rp else 0) | (1 if rq else 0))
-            specs.append((N.TG_F32DW_MM, dout if rp else dzs[i], xp if rq else acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H, bits))
+            fused = fused or rp or rq
+            specs.append((N.TG_F32DW_MM, dout if rp else dzs[i], xp if rq else acts[i - 1], H, lin[i].weight.grad, lin[i].bias.grad, H, H,
+                          (2 if rp else 0) | (1 if rq else 0)))
         if not fused:                                               # (the rebuilding jobs carry these two as riders)
             specs.append((N.TG_F32DW_MM, dzs[0], xp, f.in_pad, lin[0].weight.grad, lin[0].bias.grad, H, self.in_dim, 0))
             specs.append((N.TG_F32DW_HEAD, dout, acts[nh - 1], H, lin[nh].weight.grad, lin[nh].bias.grad, self.out_dim, H, 0))
@@ -599,16 +596,6 @@ class GemmMLP:
                 wh, bh = lin[nh].weight, lin[nh].bias
                 assert wh.is_contiguous() and wh.dtype == torch.float32 and wh.grad.stride(1) == 1 and bh.grad.is_contiguous()
                 slot.d_wh, slot.d_maskbits, slot.d_a_top = wh.data_ptr(), self._tmask.data_ptr(), acts[nh - 1].data_ptr()
-                slot.d_whgrad, slot.d_bhgrad, slot.whgrad_ld = wh.grad.data_ptr(), bh.grad.data_ptr(), wh.grad.stride(0)
-            if rebuild & 4:                                         # H = 256 rider: the first layer's gradient, operands read back
-                w0, b0 = lin[0].weight, lin[0].bias
-                assert w0.grad.stride(1) == 1 and b0.grad.is_contiguous()
-                slot.d_dz0, slot.d_x = dzs[0].data_ptr(), xp.data_ptr()
-                slot.d_w0grad, slot.d_b0grad, slot.w0grad_ld = w0.grad.data_ptr(), b0.grad.data_ptr(), w0.grad.stride(0)
-            if rebuild & 8:                                         # H = 256 rider: the head's gradient, operands read back
-                wh, bh = lin[nh].weight, lin[nh].bias
-                assert wh.grad.stride(1) == 1 and bh.grad.is_contiguous()
-                slot.d_a_top, slot.d_g = acts[nh - 1].data_ptr(), dout.data_ptr()
                 slot.d_whgrad, slot.d_bhgrad, slot.whgrad_ld = wh.grad.data_ptr(), bh.grad.data_ptr(), wh.grad.stride(0)
         ev = None
         if self.dw_events is not None:
