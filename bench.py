@@ -272,8 +272,17 @@ def _pmc_bytes_per_row(family):
         return None, None
 
 
-def _f32_pmc_bytes_per_row(family):
-    """HBM traffic per row of the fp32 chain learner's kernels (5-128-128-1, 2^20-row probe: profiles/r03_f32_chain_pmc.json)."""
+def _f32_pmc_bytes_per_row(family, wide=False):
+    """HBM traffic per row of the fp32 chain learner's kernels (5-128-128-1, 2^20-row probe: profiles/r03_f32_chain_pmc.json; wide: the
+    H = 256 learner at 20-256x5-4, profiles/r05_f32_wide_pmc.json)."""
+    if wide:
+        try:
+            with open(os.path.join(REPO, "profiles", "r05_f32_wide_pmc.json")) as f:
+                d = json.load(f)
+            k = d["kernels"]["void tg::mlp_f32_wide_kernel<true>" if family == "fwd" else "tg::mlp_f32_wide_dw_kernel"]
+            return k["bytes_per_row"], "r05_f32_wide_pmc.json"
+        except Exception:
+            return None, None
     try:
         with open(os.path.join(REPO, "profiles", "r03_f32_chain_pmc.json")) as f:
             d = json.load(f)
@@ -954,12 +963,12 @@ def run_config(args, ctx, secondary=False):
                 ach = nflop / dur / 1e12
                 # (HBM traffic of these matrix-bound kernels, for the record: PMC bytes per row of the 5-128-128-1 probe x rows per launch;
                 #  only quoted for that net shape)
-                pmc_row, pmc_file = _f32_pmc_bytes_per_row(fam) if (args.config == "c2" and hidden == (128, 128)) else (None, None)
+                pmc_row, pmc_file = (_f32_pmc_bytes_per_row(fam) if (args.config == "c2" and hidden == (128, 128)) else
+                                     (_f32_pmc_bytes_per_row(fam, wide=True) if "mlp_f32_wide" in ls[0][3] else (None, None)))
                 kernels[fam] = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
                                 "traffic": pmc_row * nrows / len(ls) if pmc_row else None,
                                 "traffic_source": (f"profiles/{pmc_file}: 2 x FETCH_SIZE + WRITE_SIZE per row of the 2^20-row probe, times this "
-                                                   "run's average rows per launch (1.001 x / 1.04 x the algorithmic bytes: the kernel is bound "
-                                                   "by the matrix pipe, not by these)") if pmc_row else None,
+                                                   "run's average rows per launch (the kernel is bound by the matrix pipe, not by these)") if pmc_row else None,
                                 "kernel": ls[0][3], "flops_per_row": nflop / nrows, "launches": len(ls),
                                 "avg_launch_ms": 1e3 * dur / len(ls), "avg_rows_per_launch": nrows / len(ls),
                                 "total_ms_per_step": 1e3 * dur / max(timed_steps, 1),

@@ -478,6 +478,24 @@ int  tg_mlp_f32w_forward(const float* d_x, int32_t in_pad, const float* d_stream
                          float* d_out, void* stream);
 int  tg_mlp_f32w_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers,
                                   int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream);
+/* The H = 128 net with at most ONE H x H layer (BASELINE configs[1], C2: 5-128-128-1, pipelines/cartpole_pipeline_grpo.py:54-76) on the
+ * same 16-row machine with its whole weight stream resident in LDS (csrc/mlp_f32_wide.hip, mlp_f32_res_kernel): 12 waves per CU, no
+ * barrier in the row loop, rows dealt 16 at a time wave-major across the CUs (C2's ~176,000 rows are 10.78 wave-rounds per SIMD: 11
+ * here, 6 x 32-row rounds = 12 in tg_mlp_f32_forward_backward).  Same outputs as tg_mlp_f32_forward[_backward] (incl. the top layer's
+ * mask bits): interchangeable in front of tg_mlp_f32_weight_grad.
+ *   d_stream f32 [tg_mlp_f32r_stream_floats]: forward blocks [8 mo][8 pieces t][64 lanes] x 16 B: W_1[16 mo + i][16 t + 4 g .. + 3], then
+ *            backward blocks [8 ko][8 t][64]: {W_1[16 t + 4 g + r][16 ko + i]}   (lane = (i = lane & 15, g = lane >> 4); empty with one hidden layer)
+ *   d_w0     f32 [tg_mlp_f32r_w0_floats]: [8 tiles mo][in_pad / 4 steps s][64 lanes]: W0[16 mo + i][4 s + g] (zero beyond the inputs)
+ *   d_table  f32 [tg_mlp_f32r_table_floats]: [2][128] hidden biases | [4][128] head weights | [4] head bias | 12 zeros */
+int  tg_mlp_f32r_supported(int32_t hidden, int32_t n_hidden_layers, int32_t in_pad);
+int64_t tg_mlp_f32r_stream_floats(int32_t hidden, int32_t n_hidden_layers);
+int64_t tg_mlp_f32r_w0_floats(int32_t hidden, int32_t in_pad);
+int64_t tg_mlp_f32r_table_floats(int32_t hidden);
+int  tg_mlp_f32r_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
+                         int32_t n_hidden_layers, int64_t rows, float* d_out, void* stream);
+int  tg_mlp_f32r_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
+                                  int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits,
+                                  const tg_chain_loss* loss, void* stream);
 enum { TG_F32DW_MM = 0, TG_F32DW_HEAD = 1 };
 typedef struct tg_f32_dw_job {
     const float* d_p;

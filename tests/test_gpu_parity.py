@@ -2243,6 +2243,7 @@ def test_f32_chain_forward_matches_fp64(tg, dev, dims, rows):
     net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
     m = M.GemmMLP(net, torch.float32)
     assert m._f32 is not None and m.in_pad == (S + 7) // 8 * 8
+    assert m._f32.res == (hidden in ((128,), (128, 128))) and m._f32.wide == (hidden[0] == 256)     # (which of the three kernels this is)
     X = torch.randn(rows, S, device=dev)
     xp = m.prepare_input(X)
     assert xp.shape == (rows, m.in_pad) and xp.dtype == torch.float32

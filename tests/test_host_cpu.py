@@ -107,6 +107,49 @@ def test_f32_chain_weight_stream_layout():
     assert M.f32_chain_supported(tg.NeuralNetwork(5, 1, (128,) * 5, "ReLU")) == 0
 
 
+def test_f32_resident_weight_stream_layout():
+    """mlp.F32ResStream (the operands of tg_mlp_f32r_forward[_backward], v_mfma_f32_16x16x4_f32: A lane (i, g) = A[i][g], B lane
+    (j, g) = B[g][j], accumulator register r of lane (j, g) of tile t = feature 16 t + 4 g + r of row j) against torch on the CPU."""
+    from trajopt_grpo_amd import mlp as M
+    for S, A, hidden in [(5, 1, (128, 128)), (20, 4, (128, 128)), (9, 2, (128,))]:
+        torch.manual_seed(S)
+        net = tg.NeuralNetwork(S, A, hidden, "ReLU")
+        assert M.f32_res_supported(net) == 128
+        fs = M.F32ResStream(net)
+        H, NT, K4, nh = 128, 8, fs.in_pad // 4, len(hidden)
+        st = fs.stream.double().numpy()
+        n_stream = 2 * (nh - 1) * NT * NT * 256
+        blocks = st[:n_stream].reshape(2 * (nh - 1), NT, NT, 64, 4)
+        w0 = fs.w0.double().numpy().reshape(NT, K4, 64)
+        tab = fs.table.double().numpy()
+        bias, wh, bh = tab[:2 * H].reshape(2, H), tab[2 * H:6 * H].reshape(4, H), tab[6 * H:6 * H + 4]
+        assert tab.size == 6 * H + 16 and np.all(tab[6 * H + 4:] == 0)
+        x = torch.randn(S)
+        xp = np.zeros(fs.in_pad)
+        xp[:S] = x.numpy()
+        contract = lambda blk, v: np.array([sum(blk[f // 16, t, (f % 16) + 16 * g, e] * v[16 * t + 4 * g + e] for t in range(NT) for g in range(4)
+                                                for e in range(4)) for f in range(H)])
+        a0 = np.array([bias[0, f] + sum(w0[f // 16, s_, (f % 16) + 16 * g] * xp[4 * s_ + g] for s_ in range(K4) for g in range(4)) for f in range(H)])
+        acts = [np.maximum(a0, 0)]
+        if nh == 2:
+            acts.append(np.maximum(bias[1] + contract(blocks[0], acts[0]), 0))
+        else:
+            assert np.all(bias[1] == 0)
+        out = wh @ acts[-1] + bh
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        h = x.double()
+        for l, a in zip(lin[:-1], acts):
+            h = torch.relu(l.weight.double() @ h + l.bias.double())
+            np.testing.assert_allclose(a, h.detach().numpy(), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out[:A], (lin[-1].weight.double() @ h + lin[-1].bias.double()).detach().numpy(), rtol=1e-12, atol=1e-12)
+        assert np.all(out[A:] == 0)
+        if nh == 2:
+            dz = np.arange(H, dtype=np.float64) / H - 0.3
+            np.testing.assert_allclose(contract(blocks[1], dz), (lin[1].weight.double().t() @ torch.from_numpy(dz)).detach().numpy(), rtol=1e-12, atol=1e-12)
+    for S, A, hidden in [(5, 1, (128,) * 3), (5, 1, (64, 64)), (40, 1, (128, 128)), (5, 5, (128, 128))]:
+        assert M.f32_res_supported(tg.NeuralNetwork(S, A, hidden, "ReLU")) == 0
+
+
 def test_avg_reward_keeps_the_reference_list_semantics(tmp_path):
     """`Rollout_Buffer.avg_reward` is a property since the device path reads its statistic lazily; for every other use it is the
     reference's plain list (rollout_buffer.py:70, :104-121): appended by store(), replaced by load(), assignable, len() = entries."""

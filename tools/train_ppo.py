@@ -2,7 +2,7 @@
 """End-to-end learning check: PPO with the reference factories' hyper-parameters but 4,096 parallel episodes per
 epoch instead of 50-80.
 
-    python3 tools/train_ppo.py [epochs] [CartPole|QuadPole2D|QuadPole] [bf16]
+    python3 tools/train_ppo.py [epochs] [CartPole|QuadPole2D|QuadPole] [bf16|fp32]
 
 CartPole / QuadPole2D (pipelines/cartpole_pipeline_ppo.py, quadpole2d_pipeline_ppo.py): 128x3 actor-critic, cov 0.5,
 eps 0.2, gamma 0.99, 24 full-batch updates, Adam 2e-4 (published curves: -37 -> ~800 and -70 -> ~1047).
@@ -24,6 +24,8 @@ def main():
     torch.manual_seed(0)
     if name == "QuadPole":
         S, A, hidden, cov, lr, upd, gamma, cdt = 20, 4, (256,) * 5, 0.3, 3e-4, 32, 0.999, torch.bfloat16
+        if len(sys.argv) > 3 and sys.argv[3] == "fp32":          # the reference's own precision: the H = 256 fp32 chain learner
+            cdt = None
     else:
         S, A = (5, 1) if name == "CartPole" else (10, 2)
         hidden, cov, lr, upd, gamma, cdt = (128, 128, 128), 0.5, 2e-4, 24, 0.99, None

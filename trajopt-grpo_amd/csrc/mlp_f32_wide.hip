@@ -116,17 +116,20 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
     constexpr int kWait = (P - 1) * (KS / WPW);
     constexpr int kWaitFull = kWait + (kTrain ? P : 0);
 
-#if TG_F32W_ABLATE
-#undef TG_RING_NEXT
-#define TG_RING_NEXT                                                                                       \
+    // A block's head: counted wait, barrier, the block's slot.  Its DMA (block + P into the slot just freed) is issued by dma_next()
+    // AFTER the block's first operand reads are on their way: the LDS round trip then passes under the DMA's address arithmetic
+    // instead of following it (the shared TG_RING_NEXT issues the DMA first).
+#define TG_WIDE_HEAD(WAITN)                                                                                \
+    TG_RING_WAIT(WAITN)                                                                                    \
     if (!(TG_F32W_ABLATE & 1)) __builtin_amdgcn_s_barrier();                                               \
     asm volatile("" ::: "memory");                                                                         \
-    if (!(TG_F32W_ABLATE & 2)) ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);    \
-    pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;                                                 \
-    pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;                                                     \
     const uint4* cur = ring + cur_slot * KS * 64;                                                          \
     cur_slot = (cur_slot + 1 == D) ? 0 : cur_slot + 1;
-#endif
+    auto dma_next = [&]() {
+        if (!(TG_F32W_ABLATE & 2)) ring_dma_block<KS, WPW>(wfrag + (int64_t)pre_pos * KS * 64, ring + pre_slot * KS * 64, wave, lane);
+        pre_pos = (pre_pos + 1 == n_blocks) ? 0 : pre_pos + 1;
+        pre_slot = (pre_slot + 1 == D) ? 0 : pre_slot + 1;
+    };
     auto relu_bits4 = [&](f32x4& v) {
         uint32_t m = 0;
 #pragma unroll
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
         const uint4* __restrict__ p = cur + lane;
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
         uint4 wa = wide_lds_u4(p), wb = wide_lds_u4(p + 64);
+        dma_next();
 #pragma unroll
         for (int t = 0; t < NT; t += 2) {
             uint4 na = wa, nb = wb;
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                TG_RING_ADVANCE(kWait)
+                TG_WIDE_HEAD(kWait)
+                dma_next();
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
                     const int mo = 8 * b + tt;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
 #pragma unroll
             for (int mo = 0; mo < NT; ++mo) {
                 if (mo >= 2) { TG_RING_WAIT(kWaitFull) } else { TG_RING_WAIT(kWait) }
-                TG_RING_NEXT
+                TG_WIDE_HEAD(0x3f)                               // (the counted wait was the line above: 0x3f never waits)
                 const float4 b4 = wide_lds_f4(bias_l + 16 * mo);
                 f32x4 acc = tile_products(cur, xin, f32x4{b4.x, b4.y, b4.z, b4.w});
                 const uint32_t m = relu_bits4(acc);
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
 #pragma unroll
                 for (int ko = 0; ko < NT; ++ko) {
                     // (the two blocks before any backward block stored: the top layer's last forward blocks, or this pass's own)
-                    TG_RING_ADVANCE(kWaitFull)
+                    TG_WIDE_HEAD(kWaitFull)
                     f32x4 acc = tile_products(cur, xin, f32x4{0.f, 0.f, 0.f, 0.f});
                     const uint32_t mw = (ko < 8 ? mk.x >> (4 * ko) : mk.y >> (4 * (ko - 8)));
                     acc[0] = (mw & 1u) ? acc[0] : 0.f;
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
     }
     // the ring's prefetches of a round that never came: let them land before the workgroup's LDS goes away
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef TG_WIDE_HEAD
     if constexpr (kTrain) {
         // loss sums: lanes -> wave (fixed shuffle tree) -> workgroup (waves in order): deterministic
         double v[4] = {s_surr, s_crit, s_kl, s_cnt};
@@ -368,6 +374,289 @@ static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const
     if (((uintptr_t)d_x | (uintptr_t)d_stream) & 15) return set_error(TG_ERR_ARG, "%s: input / stream not 16-B aligned", what);
     a.x = d_x; a.in_pad = in_pad; a.n_hh = n_hidden_layers - 1; a.rows = rows;
     a.stream = reinterpret_cast<const uint4*>(d_stream); a.table = d_table;
+    return TG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same 16-row machine with the whole weight stream RESIDENT in LDS: H = 128 with at most one H x H layer -- BASELINE configs[1]
+// (C2: CartPole GRPO, fp32 5-128-128-1, pipelines/cartpole_pipeline_grpo.py:54-76).  mlp_f32_chain.hip runs that shape with 32 rows
+// per wave on v_mfma_f32_32x32x2_f32: 128 registers of activations, two waves per SIMD, and a granularity of 32 rows per wave --
+// at C2's ~176,000 rows per update that is 5.39 wave-rounds per SIMD, i.e. 6 (10 % of the launch idle), with the matrix pipe 64 %
+// busy inside them.  Here a wave owns 16 rows (input + output = 64 registers): SIXTEEN waves per CU, four per SIMD, no barrier
+// anywhere in the row loop (a block is an offset into the resident stream), and the rows are dealt to the waves 16 at a time,
+// wave-major across the CUs, so that every SIMD gets 10 or 11 wave-rounds of C2's 10.78.
+//   stream  fwd blocks [n_hh][NT] then (training) bwd blocks [n_hh][NT], a block = NT pieces x 64 lanes x 16 B:
+//           fwd piece t of block mo: W_l[16 mo + i][16 t + 4 g .. + 3];  bwd piece t of block ko: {W_l[16 t + 4 g + r][16 ko + i]}
+//   w0      [NT tiles][K4 = in_pad / 4 steps][64 lanes] floats: lane (i, g) of step s holds W0[16 mo + i][4 s + g]
+//   table   [2][H] hidden biases | [4][H] head weights | [4] head bias (+ 12 pad)
+// Outputs as tg_mlp_f32_forward_backward's, including the top layer's mask bits in ITS format (the weight-gradient job of
+// mlp_f32_chain.hip rebuilds the top dZ from them): the two kernels are interchangeable in front of tg_mlp_f32_weight_grad.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kResWaves = 12;                  // (16 waves = 128 registers each spill 88 of them; 12 = 168)
+constexpr int kResMaxHidden = 2;
+
+struct F32ResArgs {
+    const float* x; int32_t in_pad; int32_t n_hh; int64_t rows;
+    const uint4* stream; const float* w0; const float* table;
+    float* acts[kResMaxHidden]; float* dz[kResMaxHidden];
+    float* out; uint32_t* top_mask;
+    F32Loss loss;
+};
+
+template <int H>
+static size_t f32_res_lds(int n_hh, int in_pad, bool train) {
+    constexpr int NT = H / 16;
+    return (size_t)n_hh * NT * (train ? 2 : 1) * NT * 1024 + (size_t)NT * (in_pad / 4) * 256 + (size_t)((kResMaxHidden + 4) * H + 16) * 4 +
+           kResWaves * 4 * 8;
+}
+
+TG_CLOCK_PROBE_VAR(g_probe_f32_res, attach_probe_f32_res)
+
+template <int H, int K4, bool kTrain>                                    // K4 = padded input width / 4: the first layer's products per tile
+__global__ __launch_bounds__(64 * kResWaves, 3) void mlp_f32_res_kernel(F32ResArgs a) {
+    constexpr int NT = H / 16, WPW = kResWaves, BLK = NT * 64;           // uint4 per block
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int n_hh = a.n_hh;
+    const int n_stream = n_hh * NT * (kTrain ? 2 : 1);
+    uint4* strm = lds;
+    float* w0_s = reinterpret_cast<float*>(strm + n_stream * BLK);      // [NT][K4][64]
+    float* table = w0_s + NT * K4 * 64;
+    float* wh_s = table + kResMaxHidden * H;
+    float* bh_s = wh_s + 4 * H;
+    double* red_s = reinterpret_cast<double*>(bh_s + 16);
+    const int64_t rows = a.rows;
+    const int64_t n_wr = (rows + 15) / 16;                               // wave-rounds of 16 rows
+    F32Loss L = a.loss;
+    if constexpr (kTrain) {
+        f32_loss_from_device(L);
+        TG_CLOCK_PROBE_BEGIN(g_probe_f32_res)
+    }
+    for (int q = tid; q < n_stream * BLK; q += 64 * WPW) strm[q] = a.stream[q];
+    for (int q = tid; q < NT * K4 * 64; q += 64 * WPW) w0_s[q] = a.w0[q];
+    for (int q = tid; q < (kResMaxHidden + 4) * H + 16; q += 64 * WPW) table[q] = a.table[q];
+    __syncthreads();
+
+    auto relu_bits4 = [&](f32x4& v) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m |= (v[r] > 0.0f ? 1u : 0u) << r;
+            v[r] = fmaxf(v[r], 0.0f);
+        }
+        return m;
+    };
+    // one 16-feature output tile against a whole H-wide operand (as mlp_f32_wide_kernel's): two accumulator chains, the A operands
+    // of the next two pieces requested before this pair's products
+    auto tile_products = [&](const uint4* __restrict__ cur, const f32x4 (&xin)[NT], f32x4 acc) {
+        const uint4* __restrict__ p = cur + lane;
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        uint4 wa = wide_lds_u4(p), wb = wide_lds_u4(p + 64);
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+            uint4 na = wa, nb = wb;
+            if (t + 2 < NT) { na = wide_lds_u4(p + (t + 2) * 64); nb = wide_lds_u4(p + (t + 3) * 64); }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), xin[t][0], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t + 1][0], acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), xin[t][1], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t + 1][1], acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), xin[t][2], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t + 1][2], acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), xin[t][3], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t + 1][3], acc1, 0, 0, 0);
+            wa = na; wb = nb;
+        }
+        // (pin the order -- and with it the number of pieces in registers at a time: hipcc otherwise hoists a whole block's reads)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < NT / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            if (i + 2 < NT / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        return acc + acc1;
+    };
+    auto store_tile = [&](float* gptr, int64_t row, int mo, const f32x4& v) {
+        *reinterpret_cast<float4*>(gptr + row * H + 16 * mo + 4 * g) = float4{v[0], v[1], v[2], v[3]};
+    };
+
+    double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
+    // wave-rounds dealt wave-major across the workgroups: q = k * (16 * grid) + wave * grid + block
+    for (int64_t q = (int64_t)wave * gridDim.x + blockIdx.x; q < n_wr; q += (int64_t)WPW * gridDim.x) {
+        const int64_t row = q * 16 + j;
+        const bool valid = row < rows;
+        const int64_t rowc = valid ? row : rows - 1;
+        f32x4 xin[NT], xout[NT];
+        uint32_t mb0 = 0, mb1 = 0;                       // ReLU mask bits of layer 0 / layer 1: tile t -> bits 4 t .. 4 t + 3
+        // ---- layer 0: step s contracts inputs 4 s + g (g = the lane group) ----
+        {
+            float xr[K4];
+#pragma unroll
+            for (int s = 0; s < K4; ++s) xr[s] = a.x[rowc * (4 * K4) + 4 * s + g];
+#pragma unroll
+            for (int mo = 0; mo < NT; ++mo) {
+                const float4 b4 = wide_lds_f4(table + 16 * mo + 4 * g);
+                f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int s = 0; s < K4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wide_lds_f(w0_s + (mo * K4 + s) * 64 + lane), xr[s], acc, 0, 0, 0);
+                mb0 |= relu_bits4(acc) << (4 * mo);
+                xin[mo] = acc;
+                if constexpr (kTrain) {
+                    if (a.acts[0] != nullptr) store_tile(a.acts[0], rowc, mo, acc);
+                }
+            }
+        }
+        if (n_hh == 1) {
+#pragma unroll
+            for (int mo = 0; mo < NT; ++mo) {
+                const float4 b4 = wide_lds_f4(table + H + 16 * mo + 4 * g);
+                f32x4 acc = tile_products(strm + mo * BLK, xin, f32x4{b4.x, b4.y, b4.z, b4.w});
+                mb1 |= relu_bits4(acc) << (4 * mo);
+                xout[mo] = acc;
+                if constexpr (kTrain) store_tile(a.acts[1], rowc, mo, acc);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xin[t] = xout[t];
+        }
+        const uint32_t mtop = n_hh == 1 ? mb1 : mb0;
+        // ---- head: <= 4 outputs as fp32 dot products over the lane's features, the four lane groups added in a fixed order ----
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const int A = kTrain ? L.A : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < A) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
+                    sacc = fmaf(xin[t][0], w.x, sacc);
+                    sacc = fmaf(xin[t][1], w.y, sacc);
+                    sacc = fmaf(xin[t][2], w.z, sacc);
+                    sacc = fmaf(xin[t][3], w.w, sacc);
+                }
+                const float p1 = __shfl_xor(sacc, 16, 64);
+                const float pair = (g & 1) ? p1 + sacc : sacc + p1;
+                const float p2 = __shfl_xor(pair, 32, 64);
+                o[k] = ((g & 2) ? p2 + pair : pair + p2) + wide_lds_f(bh_s + k);
+            }
+        if constexpr (!kTrain) {
+            if (valid && g == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
+        } else {
+            float gr[4], c_surr, c_crit, c_kl;
+            f32_loss_row<false>(L, o, row, rowc, valid, g == 0, gr, c_surr, c_crit, c_kl);
+            if (valid && g == 0) {
+                s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
+                *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{gr[0], gr[1], gr[2], gr[3]};
+            }
+            // the top layer's mask bits in tg_mlp_f32_forward_backward's row format: feature f = 32 mt + 8 q + 4 hh + low is bit
+            // low + 4 q + 16 (mt & 1) of word hh * (MT / 2) + (mt >> 1); this lane holds f = 16 t + 4 g + r, i.e. hh = g & 1,
+            // q = 2 (t & 1) + (g >> 1), mt = t >> 1: its nibble of tile t goes to bit 8 (t & 1) + 4 (g >> 1) + 16 ((t >> 1) & 1) of
+            // word hh * (MT / 2) + (t >> 2); the lane two groups on holds the other half of the same words
+            if (a.top_mask != nullptr) {
+                constexpr int NW = NT / 4;               // words per lane half (MT / 2)
+                uint32_t wds[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) v |= ((mtop >> (4 * (4 * w + tt))) & 15u) << (8 * (tt & 1) + 16 * (tt >> 1) + 4 * (g >> 1));
+                    wds[w] = v | (uint32_t)__shfl_xor((int)v, 32, 64);
+                }
+                if (g < 2) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) a.top_mask[rowc * (2 * NW) + g * NW + w] = wds[w];
+                }
+            }
+            // ---- backward: dZ_top = (g . W_head) * (a_top > 0), then dZ_0 = (W_1^T . dZ_1) * mask ----
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t mw = mtop >> (4 * t);
+                float4 sv = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < L.A) {
+                        const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
+                        sv.x = fmaf(gr[k], w.x, sv.x); sv.y = fmaf(gr[k], w.y, sv.y); sv.z = fmaf(gr[k], w.z, sv.z); sv.w = fmaf(gr[k], w.w, sv.w);
+                    }
+                f32x4 d;
+                d[0] = (mw & 1u) ? sv.x : 0.f;
+                d[1] = (mw & 2u) ? sv.y : 0.f;
+                d[2] = (mw & 4u) ? sv.z : 0.f;
+                d[3] = (mw & 8u) ? sv.w : 0.f;
+                xin[t] = d;
+                float* dz_top = n_hh == 1 ? a.dz[1] : a.dz[0];
+                if (dz_top != nullptr) store_tile(dz_top, rowc, t, d);
+            }
+            if (n_hh == 1) {
+#pragma unroll
+                for (int ko = 0; ko < NT; ++ko) {
+                    f32x4 acc = tile_products(strm + (NT + ko) * BLK, xin, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const uint32_t mw = mb0 >> (4 * ko);
+                    acc[0] = (mw & 1u) ? acc[0] : 0.f;
+                    acc[1] = (mw & 2u) ? acc[1] : 0.f;
+                    acc[2] = (mw & 4u) ? acc[2] : 0.f;
+                    acc[3] = (mw & 8u) ? acc[3] : 0.f;
+                    store_tile(a.dz[0], rowc, ko, acc);
+                }
+            }
+        }
+    }
+    if constexpr (kTrain) {
+        double v[4] = {s_surr, s_crit, s_kl, s_cnt};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red_s[wave * 4 + k] = v[k];
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double t = 0.0;
+            for (int w = 0; w < WPW; ++w) t += red_s[w * 4 + tid];
+            L.work[(int64_t)blockIdx.x * 4 + tid] = t;
+        }
+        TG_CLOCK_PROBE_END(g_probe_f32_res)
+    }
+}
+
+template <int K4, bool kTrain>
+static int launch_f32_res_k(const F32ResArgs& args, hipStream_t st) {
+    auto kern = mlp_f32_res_kernel<128, K4, kTrain>;
+    const size_t shmem = f32_res_lds<128>(args.n_hh, args.in_pad, kTrain);
+    static LdsOptIn opt_in;
+    if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32r_forward")) return rc;
+    const int64_t wgs = ceil_div(ceil_div(args.rows, (int64_t)16), (int64_t)kResWaves);
+    const int grid = (int)(wgs < device_cus() ? wgs : device_cus());
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kResWaves), shmem, st, args);
+    TG_LAUNCH_CHECK("tg_mlp_f32r_forward");
+    return TG_OK;
+}
+template <bool kTrain>
+static int launch_f32_res(const F32ResArgs& args, hipStream_t st) {
+    switch (args.in_pad) {
+        case 8: return launch_f32_res_k<2, kTrain>(args, st);
+        case 16: return launch_f32_res_k<4, kTrain>(args, st);
+        case 24: return launch_f32_res_k<6, kTrain>(args, st);
+        default: return launch_f32_res_k<8, kTrain>(args, st);
+    }
+}
+
+static int fill_f32_res(F32ResArgs& a, const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table,
+                        int32_t hidden, int32_t n_hidden_layers, int64_t rows, const char* what) {
+    if (hidden != 128) return set_error(TG_ERR_ARG, "%s: hidden width %d (128)", what, hidden);
+    if (!(n_hidden_layers >= 1 && n_hidden_layers <= kResMaxHidden))
+        return set_error(TG_ERR_ARG, "%s: %d hidden layers outside 1..%d (the whole stream must fit the LDS)", what, n_hidden_layers, kResMaxHidden);
+    if (!(in_pad >= 8 && in_pad <= 32 && in_pad % 8 == 0)) return set_error(TG_ERR_ARG, "%s: padded input width %d (a multiple of 8, <= 32)", what, in_pad);
+    if (!d_x || !d_w0 || !d_table || (n_hidden_layers > 1 && !d_stream)) return set_error(TG_ERR_ARG, "%s: null pointer", what);
+    if (rows < 0) return set_error(TG_ERR_ARG, "%s: negative row count", what);
+    if (((uintptr_t)d_stream) & 15) return set_error(TG_ERR_ARG, "%s: stream not 16-B aligned", what);
+    a.x = d_x; a.in_pad = in_pad; a.n_hh = n_hidden_layers - 1; a.rows = rows;
+    a.stream = reinterpret_cast<const uint4*>(d_stream); a.w0 = d_w0; a.table = d_table;
     return TG_OK;
 }
 
@@ -636,13 +925,60 @@ int launch_f32_wide_dw(const F32DwArgs& args, int64_t rows, float* d_workspace, 
     return TG_OK;
 }
 
-int attach_probe_f32w(int which, void* d_probe) { return which == 0 ? attach_probe_f32_wide(d_probe) : attach_probe_f32_wide_dw(d_probe); }
+int attach_probe_f32w(int which, void* d_probe) {
+    if (which != 0) return attach_probe_f32_wide_dw(d_probe);
+    const int rc = attach_probe_f32_wide(d_probe);
+    return rc ? rc : attach_probe_f32_res(d_probe);
+}
 
 }  // namespace tg
 
 using namespace tg;
 
 extern "C" {
+
+int tg_mlp_f32r_supported(int32_t hidden, int32_t n_hidden_layers, int32_t in_pad) {
+    return hidden == 128 && n_hidden_layers >= 1 && n_hidden_layers <= kResMaxHidden && in_pad >= 8 && in_pad <= 32 && in_pad % 8 == 0 &&
+           f32_res_lds<128>(n_hidden_layers - 1, in_pad, true) <= 160 * 1024;
+}
+int64_t tg_mlp_f32r_stream_floats(int32_t hidden, int32_t n_hidden_layers) { return (int64_t)2 * (n_hidden_layers - 1) * (hidden / 16) * (hidden / 16) * 256; }
+int64_t tg_mlp_f32r_w0_floats(int32_t hidden, int32_t in_pad) { return (int64_t)(hidden / 16) * (in_pad / 4) * 64; }
+int64_t tg_mlp_f32r_table_floats(int32_t hidden) { return (int64_t)(kResMaxHidden + 4) * hidden + 16; }
+
+int tg_mlp_f32r_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
+                        int32_t n_hidden_layers, int64_t rows, float* d_out, void* stream) {
+    F32ResArgs a{};
+    if (int rc = fill_f32_res(a, d_x, in_pad, d_stream, d_w0, d_table, hidden, n_hidden_layers, rows, "tg_mlp_f32r_forward")) return rc;
+    TG_REQUIRE(d_out, "tg_mlp_f32r_forward: null output");
+    if (rows == 0) return TG_OK;
+    a.out = d_out;
+    return launch_f32_res<false>(a, (hipStream_t)stream);
+}
+
+int tg_mlp_f32r_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
+                                 int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits,
+                                 const tg_chain_loss* loss, void* stream) {
+    F32ResArgs a{};
+    if (int rc = fill_f32_res(a, d_x, in_pad, d_stream, d_w0, d_table, hidden, n_hidden_layers, rows, "tg_mlp_f32r_forward_backward")) return rc;
+    TG_REQUIRE(loss && d_acts && d_dz, "tg_mlp_f32r_forward_backward: null pointer");
+    TG_REQUIRE(loss->d_dout8 && loss->d_work, "tg_mlp_f32r_forward_backward: loss outputs missing");
+    TG_REQUIRE(loss->act_dim >= 1 && loss->act_dim <= 4, "tg_mlp_f32r_forward_backward: %d outputs (1..4)", loss->act_dim);
+    TG_REQUIRE(loss->kind == 1 ? (loss->d_ret != nullptr && loss->act_dim == 1)
+                               : (loss->d_act && loss->d_adv && (loss->d_logp_old || loss->d_logp_old_out) && loss->act_row_stride == loss->act_dim &&
+                                  loss->act_col_stride == 1),
+               "tg_mlp_f32r_forward_backward: loss inputs missing (the actions must be contiguous [rows][A])");
+    if (rows == 0) return TG_OK;
+    for (int l = 0; l < n_hidden_layers; ++l) {
+        // as tg_mlp_f32_forward_backward: the first activation / the top layer's dZ may be left out (rebuilt by the weight-gradient job)
+        const bool a_opt = l == 0 && n_hidden_layers >= 2, z_opt = l == n_hidden_layers - 1 && n_hidden_layers >= 2 && d_top_maskbits;
+        TG_REQUIRE((d_acts[l] || a_opt) && (d_dz[l] || z_opt), "tg_mlp_f32r_forward_backward: buffer %d is null", l);
+        a.acts[l] = (float*)d_acts[l];
+        a.dz[l] = (float*)d_dz[l];
+    }
+    a.top_mask = (uint32_t*)d_top_maskbits;
+    fill_f32_loss(a.loss, loss);
+    return launch_f32_res<true>(a, (hipStream_t)stream);
+}
 
 int tg_mlp_f32w_blocks(void) { return 2 * device_cus(); }
 

@@ -166,7 +166,9 @@ class GemmMLP:
         # (parity tests: every hidden activation and dZ of the fp32 chain learner written to HBM, so that each can be compared with
         # fp64; the product rebuilds the first activation and the top dZ on chip instead)
         self.f32_store_all = False
-        if compute_dtype == torch.float32 and f32_chain_supported(net):
+        if compute_dtype == torch.float32 and f32_res_supported(net):
+            self._f32 = F32ResStream(net)                       # H = 128, <= 2 hidden layers: the resident 16-row kernel (C2's shape)
+        elif compute_dtype == torch.float32 and f32_chain_supported(net):
             self._f32 = F32ChainStream(net, f32_chain_supported(net))
         elif compute_dtype == torch.float32 and f32_wide_supported(net):
             self._f32 = F32WideStream(net)                      # H = 256: csrc/mlp_f32_wide.hip
@@ -344,7 +346,10 @@ class GemmMLP:
             f = self._f32
             assert xp.dtype == torch.float32 and xp.is_contiguous() and xp.shape[1] == f.in_pad
             out = torch.empty(xp.shape[0], 4, dtype=torch.float32, device=xp.device)
-            if f.wide:
+            if f.res:
+                N.check(N.load().tg_mlp_f32r_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.w0.data_ptr(), f.table.data_ptr(), f.H, f.n_hidden,
+                                                     xp.shape[0], out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32r_forward")
+            elif f.wide:
                 N.check(N.load().tg_mlp_f32w_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.table.data_ptr(), f.n_hidden, xp.shape[0],
                                                      out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32w_forward")
             else:
@@ -541,7 +546,10 @@ class GemmMLP:
         if self.fwd_events is not None:
             ev = N.event_pair()
             ev[0].record()
-        if f.wide:
+        if f.res:
+            N.check(lib.tg_mlp_f32r_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.w0.data_ptr(), f.table.data_ptr(), H, nh, rows,
+                                                     ptrs, zptrs, N.ptr(tmask), N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32r_forward_backward")
+        elif f.wide:
             N.check(lib.tg_mlp_f32w_forward_backward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.table.data_ptr(), nh, rows, ptrs, zptrs,
                                                      N.C.byref(a), N.stream_ptr(dev)), "tg_mlp_f32w_forward_backward")
         else:
@@ -552,8 +560,9 @@ class GemmMLP:
             # matrix-core flops per row: first layer + forward and backward products of the H x H layers (head: vector unit)
             # algorithmic flops per row (un-padded): forward first layer + H x H layers + head, backward head + H x H layers
             self.fwd_events.append((ev[0], ev[1], rows, 2 * H * self.in_dim + 4 * (nh - 1) * H * H + 4 * H * self.out_dim,
-                                    "tg::mlp_f32_wide_kernel<true>" if f.wide else f"tg::mlp_f32_chain_kernel<{H},true>"))
-        grid = min(nblk, -(-rows // (64 if f.wide else 256)))
+                                    "tg::mlp_f32_wide_kernel<true>" if f.wide else
+                                    (f"tg::mlp_f32_res_kernel<{H},{f.in_pad // 4},true>" if f.res else f"tg::mlp_f32_chain_kernel<{H},true>")))
+        grid = min(nblk, -(-rows // (64 if f.wide else (192 if f.res else 256))))      # (the launchers' own grids)
         self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
         assert getattr(self, "_loss_rider", None) is None, "forward_loss(sums_out=...) must be followed by backward_fused()"
         if sums_out is not None:
@@ -1073,6 +1082,89 @@ def f32_chain_supported(net) -> int:
     return H
 
 
+def f32_res_supported(net) -> int:
+    """128 if `net` is Linear(S<=32, 128) ReLU [Linear(128, 128) ReLU]{0..1} Linear(128, A<=4) -- BASELINE configs[1]'s policy
+    (5-128-128-1) and its like: the whole weight stream fits the LDS beside the tables -- else 0."""
+    if not supports(net):
+        return 0
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
+    if H != 128 or not (1 <= len(lin) - 1 <= 2) or lin[0].in_features > 32 or lin[-1].out_features > 4:
+        return 0
+    if any(l.out_features != H for l in lin[:-1]) or any(l.in_features != H for l in lin[1:]):
+        return 0
+    return H if N.load().tg_mlp_f32r_supported(H, len(lin) - 1, _round_up(lin[0].in_features, 8)) else 0
+
+
+class F32ResStream:
+    """Weight stream, first-layer table and bias / head table of the resident 16-row kernel (csrc/mlp_f32_wide.hip, mlp_f32_res_kernel),
+    ONE buffer refreshed with one gather: lane = (i = lane & 15, g = lane >> 4)
+      stream: forward blocks [8 mo][8 t][64 lanes][4]: W_1[16 mo + i][16 t + 4 g + e]; backward blocks [8 ko][8 t][64][4]:
+              W_1[16 t + 4 g + e][16 ko + i]            (nothing with one hidden layer)
+      w0:     [8 mo][in_pad / 4 steps s][64 lanes]: W0[16 mo + i][4 s + g]              (zero beyond the inputs)
+      table:  [2][128] hidden biases | [4][128] head weights (rows >= A zero) | [4] head bias | 12 zeros"""
+    wide, res = False, True
+
+    def __init__(self, net):
+        lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+        self.lin, self.H = lin, 128
+        H, NT = 128, 8
+        dev = lin[0].weight.device
+        nh = len(lin) - 1
+        self.n_hidden, self.in_dim, self.out_dim = nh, lin[0].in_features, lin[-1].out_features
+        self.in_pad = _round_up(self.in_dim, 8)
+        K4 = self.in_pad // 4
+        woff, off = [], 0
+        for l in lin:
+            woff.append(off)
+            off += l.weight.numel()
+        boff = []
+        for l in lin:
+            boff.append(off)
+            off += l.bias.numel()
+        zero_at = off
+        lane = torch.arange(64, device=dev).view(1, 64, 1)
+        i, g = lane & 15, lane >> 4
+        e = torch.arange(4, device=dev).view(1, 1, 4)
+        t = torch.arange(NT, device=dev).view(NT, 1, 1)
+        k = (16 * t + 4 * g + e).expand(NT, 64, 4)
+        idx = []
+        for l in range(1, nh):                                                       # forward: W_l[16 mo + i][k]
+            for mo in range(NT):
+                idx.append((woff[l] + (16 * mo + i) * H + k).reshape(-1))
+        for l in range(nh - 1, 0, -1):                                               # backward: W_l[k][16 ko + i]
+            for ko in range(NT):
+                idx.append((woff[l] + k * H + (16 * ko + i)).reshape(-1))
+        n_stream = sum(x.numel() for x in idx)
+        s4 = torch.arange(K4, device=dev).view(K4, 1)
+        ln = torch.arange(64, device=dev).view(1, 64)
+        col = (4 * s4 + (ln >> 4)).expand(K4, 64)
+        for mo in range(NT):
+            src = woff[0] + (16 * mo + (ln & 15)).expand(K4, 64) * self.in_dim + col
+            idx.append(torch.where(col < self.in_dim, src, torch.full_like(src, zero_at)).reshape(-1))
+        n_w0 = NT * K4 * 64
+        for l in range(2):
+            idx.append(boff[l] + torch.arange(H, device=dev) if l < nh else torch.full((H,), zero_at, device=dev))
+        for a in range(4):
+            idx.append(woff[nh] + a * H + torch.arange(H, device=dev) if a < self.out_dim else torch.full((H,), zero_at, device=dev))
+        idx.append(torch.tensor([boff[nh] + a if a < self.out_dim else zero_at for a in range(4)] + [zero_at] * 12, device=dev))
+        self._idx = torch.cat([x.reshape(-1) for x in idx])
+        lib = N.load()
+        assert n_stream == lib.tg_mlp_f32r_stream_floats(H, nh) and n_w0 == lib.tg_mlp_f32r_w0_floats(H, self.in_pad)
+        assert self._idx.numel() - n_stream - n_w0 == lib.tg_mlp_f32r_table_floats(H)
+        self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.stream = torch.empty(self._idx.numel(), dtype=torch.float32, device=dev)          # blocks, first-layer table, tables
+        self.w0 = self.stream[n_stream:n_stream + n_w0]
+        self.table = self.stream[n_stream + n_w0:]
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Two launches: concatenate the master tensors, gather."""
+        src = torch.cat([l.weight.reshape(-1) for l in self.lin] + [l.bias for l in self.lin] + [self._zero])
+        torch.index_select(src if src.dtype == torch.float32 else src.float(), 0, self._idx, out=self.stream)
+
+
 def f32_wide_supported(net) -> int:
     """256 if `net` is Linear(S<=32, 256) ReLU [Linear(256, 256) ReLU]{0..4} Linear(256, A<=4) -- the reference's QuadPole factory
     (pipelines/quadpole_pipeline_ppo.py:54-58: 20-256x5-{4,1}) -- else 0."""
@@ -1095,7 +1187,7 @@ class F32WideStream:
       forward, layer l = 1 .. nh - 1, block mo, piece t:  W_l[16 mo + i][16 t + 4 g + e]
       backward, layer l = nh - 1 .. 1, block ko, piece t: W_l[16 t + 4 g + e][16 ko + i]
     then the tables: [5][256] hidden biases | [4][256] head weights (rows >= A zero) | [4] head bias | 12 zeros."""
-    wide = True
+    wide, res = True, False
 
     def __init__(self, net):
         lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
@@ -1154,7 +1246,7 @@ class F32WideStream:
 
 
 class F32ChainStream:
-    wide = False
+    wide, res = False, False
 
     """The fp32 weight stream of the chain learner, refreshed from the master weights with ONE gather:
       [first layer, MFMA fragment order: H/32 tiles x k2/4 groups x 64 lanes x 4]  lane (i, kk), step s = 4 g + e of tile mo holds
