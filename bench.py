@@ -273,7 +273,7 @@ def _pmc_bytes_per_row(family):
 
 
 def _f32_pmc_bytes_per_row(family, wide=False):
-    """HBM traffic per row of the fp32 chain learner's kernels (5-128-128-1, 2^20-row probe: profiles/r03_f32_chain_pmc.json; wide: the
+    """HBM traffic per row of the fp32 chain learner's kernels (5-128-128-1, 2^20-row probe: profiles/r05_f32_chain_pmc.json; wide: the
     H = 256 learner at 20-256x5-4, profiles/r05_f32_wide_pmc.json)."""
     if wide:
         try:
@@ -283,13 +283,15 @@ def _f32_pmc_bytes_per_row(family, wide=False):
             return k["bytes_per_row"], "r05_f32_wide_pmc.json"
         except Exception:
             return None, None
-    try:
-        with open(os.path.join(REPO, "profiles", "r03_f32_chain_pmc.json")) as f:
-            d = json.load(f)
-        k = d["kernels"]["forward_backward" if family == "fwd" else "weight_grad"]
-        return k["traffic_bytes_per_launch"] / d["rows"], "r03_f32_chain_pmc.json"
-    except Exception:
-        return None, None
+    for name in ("r05_f32_chain_pmc.json", "r03_f32_chain_pmc.json"):          # (round 5: the resident 16-row kernel; round 3: the 32-row chain kernel)
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                d = json.load(f)
+            k = d["kernels"]["forward_backward" if family == "fwd" else "weight_grad"]
+            return k["traffic_bytes_per_launch"] / d["rows"], name
+        except Exception:
+            continue
+    return None, None
 
 
 class PowerSampler:

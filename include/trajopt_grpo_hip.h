@@ -479,7 +479,7 @@ int  tg_mlp_f32w_forward(const float* d_x, int32_t in_pad, const float* d_stream
 int  tg_mlp_f32w_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_table, int32_t n_hidden_layers,
                                   int64_t rows, void* const* d_acts, void* const* d_dz, const tg_chain_loss* loss, void* stream);
 /* The H = 128 net with at most ONE H x H layer (BASELINE configs[1], C2: 5-128-128-1, pipelines/cartpole_pipeline_grpo.py:54-76) on the
- * same 16-row machine with its whole weight stream resident in LDS (csrc/mlp_f32_wide.hip, mlp_f32_res_kernel): 12 waves per CU, no
+ * same 16-row machine with its whole weight stream resident in LDS (csrc/mlp_f32_wide.hip, mlp_f32_res_kernel): 12 waves per CU (16 without gradients), no
  * barrier in the row loop, rows dealt 16 at a time wave-major across the CUs (C2's ~176,000 rows are 10.78 wave-rounds per SIMD: 11
  * here, 6 x 32-row rounds = 12 in tg_mlp_f32_forward_backward).  Same outputs as tg_mlp_f32_forward[_backward] (incl. the top layer's
  * mask bits): interchangeable in front of tg_mlp_f32_weight_grad.
@@ -491,8 +491,9 @@ int  tg_mlp_f32r_supported(int32_t hidden, int32_t n_hidden_layers, int32_t in_p
 int64_t tg_mlp_f32r_stream_floats(int32_t hidden, int32_t n_hidden_layers);
 int64_t tg_mlp_f32r_w0_floats(int32_t hidden, int32_t in_pad);
 int64_t tg_mlp_f32r_table_floats(int32_t hidden);
+int  tg_mlp_f32r_grid(int64_t rows);          /* workgroups of a training launch over `rows` rows = rows of f64 [4] partial sums it leaves in d_work */
 int  tg_mlp_f32r_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
-                         int32_t n_hidden_layers, int64_t rows, float* d_out, void* stream);
+                         int32_t n_hidden_layers, int32_t out_dim, int64_t rows, float* d_out /* [rows][4], columns >= out_dim zero */, void* stream);
 int  tg_mlp_f32r_forward_backward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
                                   int32_t n_hidden_layers, int64_t rows, void* const* d_acts, void* const* d_dz, void* d_top_maskbits,
                                   const tg_chain_loss* loss, void* stream);

@@ -18,7 +18,10 @@ ap.add_argument("--rows", type=int, nargs="+", default=[176584, 1 << 20])
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--no-gemm", action="store_true")
 ap.add_argument("--shapes", default="5:1:128x2,5:1:128x4,20:4:128x3,5:1:64x2")
+ap.add_argument("--no-res", action="store_true", help="H = 128 nets with <= 2 hidden layers through the 32-row chain kernel (rounds 2-4) instead of the resident 16-row kernel")
 a = ap.parse_args()
+if a.no_res:
+    M.f32_res_supported = lambda net: 0
 dev = torch.device("cuda", 0)
 
 

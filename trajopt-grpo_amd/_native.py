@@ -173,7 +173,8 @@ SIGNATURES = {
     "tg_mlp_f32r_stream_floats": (C.c_int64, [_I32, _I32]),
     "tg_mlp_f32r_w0_floats": (C.c_int64, [_I32, _I32]),
     "tg_mlp_f32r_table_floats": (C.c_int64, [_I32]),
-    "tg_mlp_f32r_forward": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _I64, _VP, _VP]),
+    "tg_mlp_f32r_grid": (C.c_int, [_I64]),
+    "tg_mlp_f32r_forward": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _VP, _VP]),
     "tg_mlp_f32r_forward_backward": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP,
                                                C.POINTER(ChainLoss), _VP]),
     "tg_mlp_f32_weight_grad_workspace": (C.c_int64, [_I32]),

@@ -42,20 +42,42 @@ __device__ static inline void f32_loss_from_device(F32Loss& L) {
     }
 }
 
-// One row: head outputs o[4] -> d loss / d output g[4] and the row's contributions to the loss sums.  `rowc` = the row clamped into
-// range (loads), `row` / `valid` / `writer` decide what is written (one lane per row writes).  kZeroInvalid: a lane past the last row
-// gets g = 0 (mlp_f32_chain.hip); false: it keeps the clamped row's own g -- the H = 256 kernel lets such lanes recompute and
-// re-store the last row's values (identical bytes), so that every store instruction is issued whatever the row count.
+// The per-row inputs of the loss head, loadable ahead of the row's products (f32_loss_load) ...
+struct F32LossIn { float act[4]; float lpo, adv; };
+
+// (every load unconditional within its uniform branch: columns >= A re-read the last action column)
+// row = base + r: `base` wave-uniform (it goes into the scalar part of the address), `r` the lane's part
+template <typename R>
+__device__ static inline F32LossIn f32_loss_load(const F32Loss& L, int64_t base, R r) {
+    F32LossIn in;
+    in.act[1] = in.act[2] = in.act[3] = 0.f; in.lpo = 0.f; in.adv = 0.f;
+    if (L.kind == 0) {
+        const float* act = L.act + base * L.A;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in.act[k] = act[r * L.A + (k < L.A ? k : L.A - 1)];
+        if (L.logp_old_out == nullptr) in.lpo = (L.logp_old + base)[r];
+        in.adv = (L.adv + base)[r];
+    } else {
+        in.act[0] = (L.act + base)[r];
+    }
+    return in;
+}
+__device__ static inline F32LossIn f32_loss_load(const F32Loss& L, int64_t rowc) { return f32_loss_load(L, (int64_t)0, rowc); }
+
+// ... and the arithmetic: head outputs o[4] -> d loss / d output g[4] and the row's contributions to the loss sums.  `row` / `valid` /
+// `writer` decide what is written (one lane per row writes).  kZeroInvalid: a lane past the last row gets g = 0 (mlp_f32_chain.hip);
+// false: it keeps the clamped row's own g -- the 16-row kernels let such lanes recompute and re-store the last row's values
+// (identical bytes), so that every store instruction is issued whatever the row count.
 template <bool kZeroInvalid = true>
-__device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4], int64_t row, int64_t rowc, bool valid, bool writer,
-                                           float (&g)[4], float& c_surr, float& c_crit, float& c_kl) {
+__device__ static inline void f32_loss_compute(const F32Loss& L, const F32LossIn& in, const float (&o)[4], int64_t row, bool valid, bool writer,
+                                               float (&g)[4], float& c_surr, float& c_crit, float& c_kl) {
     g[0] = g[1] = g[2] = g[3] = 0.f;
     c_surr = c_crit = c_kl = 0.f;
     if (L.kind == 0) {
         float quad = 0.f, dmu[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float d = (k < L.A ? L.act[rowc * L.A + k] : 0.f) - o[k];
+            const float d = (k < L.A ? in.act[k] : 0.f) - o[k];
             dmu[k] = d;
             quad += d * d * L.inv_var[k];
         }
@@ -65,9 +87,9 @@ __device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4]
             lpo = lp;
             if (valid && writer) L.logp_old_out[row] = lp;
         } else {
-            lpo = L.logp_old[rowc];
+            lpo = in.lpo;
         }
-        const float adv = (L.adv[rowc] - L.n_m) * L.n_i;
+        const float adv = (in.adv - L.n_m) * L.n_i;
         const float rho = expf(lp - lpo);
         const float lo = 1.0f - L.epsilon, hi = 1.0f + L.epsilon;
         const float surr1 = rho * adv, surr2 = fminf(fmaxf(rho, lo), hi) * adv;
@@ -83,13 +105,21 @@ __device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4]
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = dlp * dmu[k] * L.inv_var[k];
     } else {
-        const float d = o[0] - (L.act[rowc] - L.n_m) * L.n_i;
+        const float d = o[0] - (in.act[0] - L.n_m) * L.n_i;
         c_crit = d * d;
         g[0] = L.critic_coef * 2.0f * d;
     }
     if constexpr (kZeroInvalid) {
         if (!valid) { g[0] = g[1] = g[2] = g[3] = 0.f; }
     }
+}
+
+// One row, inputs loaded on the spot (`rowc` = the row clamped into range).
+template <bool kZeroInvalid = true>
+__device__ static inline void f32_loss_row(const F32Loss& L, const float (&o)[4], int64_t row, int64_t rowc, bool valid, bool writer,
+                                           float (&g)[4], float& c_surr, float& c_crit, float& c_kl) {
+    const F32LossIn in = f32_loss_load(L, rowc);
+    f32_loss_compute<kZeroInvalid>(L, in, o, row, valid, writer, g, c_surr, c_crit, c_kl);
 }
 
 }  // namespace tg

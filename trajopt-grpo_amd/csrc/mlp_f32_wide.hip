@@ -18,6 +18,7 @@
 // (16 KiB = 16 pieces of 1 KiB) at a time through a ring of 3 slots, LDS-DMA, counted vmcnt + one raw s_barrier per block
 // (mfma_ring.hpp's discipline).  Biases and the head stay in LDS; the ReLU mask bits of a wave's rows live in LDS between the passes.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "tg_common.hpp"
 #include "mfma_ring.hpp"
@@ -28,6 +29,13 @@
 #define TG_F32W_ABLATE 0           /* timing-only probe builds of the chain kernel (results meaningless): bit 0 = no block barrier, bit 1 = no
                                       weight DMA inside the rounds, bit 2 = no activation / dZ stores (tools/f32_wide_ablation.sh); of the wide
                                       weight-gradient job: bit 3 = no stage barrier, bit 4 = no DMA inside the stage loop */
+#endif
+#ifndef TG_F32R_TRAIN_WAVES
+#define TG_F32R_TRAIN_WAVES 12     /* waves per CU of the resident kernel's training launches (probe builds: 16) */
+#endif
+#ifndef TG_F32R_ABLATE
+#define TG_F32R_ABLATE 0           /* ... of the resident H = 128 kernel: bit 0 = no activation / dZ / mask stores, bit 1 = no matrix products in
+                                      the H x H tiles, bit 2 = no LDS reads of their weights, bit 3 = no head / loss arithmetic (tools/f32_res_ablation.sh) */
 #endif
 
 namespace tg {
@@ -382,7 +390,7 @@ static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const
 // (C2: CartPole GRPO, fp32 5-128-128-1, pipelines/cartpole_pipeline_grpo.py:54-76).  mlp_f32_chain.hip runs that shape with 32 rows
 // per wave on v_mfma_f32_32x32x2_f32: 128 registers of activations, two waves per SIMD, and a granularity of 32 rows per wave --
 // at C2's ~176,000 rows per update that is 5.39 wave-rounds per SIMD, i.e. 6 (10 % of the launch idle), with the matrix pipe 64 %
-// busy inside them.  Here a wave owns 16 rows (input + output = 64 registers): SIXTEEN waves per CU, four per SIMD, no barrier
+// busy inside them.  Here a wave owns 16 rows (input + output = 64 registers): TWELVE waves per CU (sixteen in no-grad launches), no barrier
 // anywhere in the row loop (a block is an offset into the resident stream), and the rows are dealt to the waves 16 at a time,
 // wave-major across the CUs, so that every SIMD gets 10 or 11 wave-rounds of C2's 10.78.
 //   stream  fwd blocks [n_hh][NT] then (training) bwd blocks [n_hh][NT], a block = NT pieces x 64 lanes x 16 B:
@@ -392,7 +400,9 @@ static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const
 // Outputs as tg_mlp_f32_forward_backward's, including the top layer's mask bits in ITS format (the weight-gradient job of
 // mlp_f32_chain.hip rebuilds the top dZ from them): the two kernels are interchangeable in front of tg_mlp_f32_weight_grad.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int kResWaves = 12;                  // (16 waves = 128 registers each spill 88 of them; 12 = 168)
+constexpr int kResWaves = 16;                  // no-grad launches: 4 waves per SIMD (~95 registers)
+constexpr int kResWavesTrain = TG_F32R_TRAIN_WAVES;            // training launches: 3 per SIMD (155 registers; at 128 some 35 of them spill)
+constexpr int res_waves(bool train) { return train ? kResWavesTrain : kResWaves; }
 constexpr int kResMaxHidden = 2;
 
 struct F32ResArgs {
@@ -400,6 +410,7 @@ struct F32ResArgs {
     const uint4* stream; const float* w0; const float* table;
     float* acts[kResMaxHidden]; float* dz[kResMaxHidden];
     float* out; uint32_t* top_mask;
+    int32_t out_dim;            // (no-grad launches: head outputs to compute, the others are written as 0)
     F32Loss loss;
 };
 
@@ -413,8 +424,8 @@ static size_t f32_res_lds(int n_hh, int in_pad, bool train) {
 TG_CLOCK_PROBE_VAR(g_probe_f32_res, attach_probe_f32_res)
 
 template <int H, int K4, bool kTrain>                                    // K4 = padded input width / 4: the first layer's products per tile
-__global__ __launch_bounds__(64 * kResWaves, 3) void mlp_f32_res_kernel(F32ResArgs a) {
-    constexpr int NT = H / 16, WPW = kResWaves, BLK = NT * 64;           // uint4 per block
+__global__ __launch_bounds__(64 * res_waves(kTrain)) void mlp_f32_res_kernel(F32ResArgs a) {
+    constexpr int NT = H / 16, WPW = res_waves(kTrain), BLK = NT * 64;           // uint4 per block
     extern __shared__ uint4 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -438,116 +449,191 @@ __global__ __launch_bounds__(64 * kResWaves, 3) void mlp_f32_res_kernel(F32ResAr
     for (int q = tid; q < (kResMaxHidden + 4) * H + 16; q += 64 * WPW) table[q] = a.table[q];
     __syncthreads();
 
-    auto relu_bits4 = [&](f32x4& v) {
-        uint32_t m = 0;
+    // ReLU in place + the four mask bits of the tile (bit r: register r stayed positive).  Three instructions per element, two of them
+    // written out: every vector instruction of this kernel is time the matrix pipe does not get (profiles/r05_f32_res_kernel.md), and
+    // hipcc makes five of `fmaxf` + a comparison (a canonicalising max in front of the max; class test + select + or for the bit)
+    auto relu_bits4 = [&](f32x4& v, uint32_t& m, int sh) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            m |= (v[r] > 0.0f ? 1u : 0u) << r;
-            v[r] = fmaxf(v[r], 0.0f);
+            float p; uint32_t b;
+            asm("v_max_f32 %0, 0, %1" : "=v"(p) : "v"(v[r]));                       // (as fmaxf(x, 0))
+            asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(p));                          // +0 -> 0, any positive float -> 1
+            m |= b << (sh + r);
+            v[r] = p;
         }
-        return m;
     };
-    // one 16-feature output tile against a whole H-wide operand (as mlp_f32_wide_kernel's): two accumulator chains, the A operands
-    // of the next two pieces requested before this pair's products
-    auto tile_products = [&](const uint4* __restrict__ cur, const f32x4 (&xin)[NT], f32x4 acc) {
-        const uint4* __restrict__ p = cur + lane;
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-        uint4 wa = wide_lds_u4(p), wb = wide_lds_u4(p + 64);
+    // v[r] kept where bit sh + r of m is set, else +0: sign-extended one-bit field, and
+    auto mask4 = [&](f32x4& v, uint32_t m, int sh) {
 #pragma unroll
-        for (int t = 0; t < NT; t += 2) {
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)m, sh + r, 1);
+            v[r] = __uint_as_float(__float_as_uint(v[r]) & keep);
+        }
+    };
+    // TWO 16-feature output tiles against a whole H-wide operand: one accumulator chain each, alternating (a dependent product
+    // issues every other slot), the A operands of the next step requested before this step's eight products
+    auto tile_pair = [&](const uint4* __restrict__ blk_a, const uint4* __restrict__ blk_b, const f32x4 (&xin)[NT], f32x4& acc_a, f32x4& acc_b) {
+        const uint4* __restrict__ pa = blk_a + lane;
+        const uint4* __restrict__ pb = blk_b + lane;
+#if TG_F32R_ABLATE & 4
+        uint4 wa = uint4{(unsigned)lane, 1u, 2u, 3u}, wb = wa;
+        asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wa.z), "+v"(wa.w));
+        asm volatile("" : "+v"(wb.x), "+v"(wb.y), "+v"(wb.z), "+v"(wb.w));
+#else
+        uint4 wa = wide_lds_u4(pa), wb = wide_lds_u4(pb);
+#endif
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
             uint4 na = wa, nb = wb;
-            if (t + 2 < NT) { na = wide_lds_u4(p + (t + 2) * 64); nb = wide_lds_u4(p + (t + 3) * 64); }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), xin[t][0], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t + 1][0], acc1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), xin[t][1], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t + 1][1], acc1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), xin[t][2], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t + 1][2], acc1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), xin[t][3], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t + 1][3], acc1, 0, 0, 0);
+#if !(TG_F32R_ABLATE & 4)
+            if (t + 1 < NT) { na = wide_lds_u4(pa + (t + 1) * 64); nb = wide_lds_u4(pb + (t + 1) * 64); }
+#endif
+#if TG_F32R_ABLATE & 2
+            asm volatile("" ::"v"(wa.x), "v"(wa.y), "v"(wa.z), "v"(wa.w), "v"(wb.x), "v"(wb.y), "v"(wb.z), "v"(wb.w));
+            acc_a[t & 3] += xin[t][0]; acc_b[t & 3] += xin[t][1];
+#else
+            acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), xin[t][0], acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.x), xin[t][0], acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), xin[t][1], acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.y), xin[t][1], acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), xin[t][2], acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.z), xin[t][2], acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), xin[t][3], acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wb.w), xin[t][3], acc_b, 0, 0, 0);
+#endif
             wa = na; wb = nb;
         }
+#if !(TG_F32R_ABLATE & 6)
         // (pin the order -- and with it the number of pieces in registers at a time: hipcc otherwise hoists a whole block's reads)
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-        for (int i = 0; i < NT / 2; ++i) {
+        for (int i = 0; i < NT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            if (i + 2 < NT / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (i + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
-        return acc + acc1;
+#endif
     };
-    auto store_tile = [&](float* gptr, int64_t row, int mo, const f32x4& v) {
-        *reinterpret_cast<float4*>(gptr + row * H + 16 * mo + 4 * g) = float4{v[0], v[1], v[2], v[3]};
+    // Addresses: a round's 16 rows start at a wave-uniform base (scalar registers), the lane adds a small offset -- `jr` = the lane's
+    // row within the round, clamped into range (a lane past the last row re-does the last row: identical bytes).
+    auto store_tile = [&](float* round_base, int jr, int mo, const f32x4& v) {
+#if TG_F32R_ABLATE & 1
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
+        *reinterpret_cast<float4*>(round_base + (jr * H + 4 * g) + 16 * mo) = float4{v[0], v[1], v[2], v[3]};
+#endif
     };
+    auto lane_row = [&](int64_t q) { const int64_t last = rows - 1 - q * 16; return last < j ? (int)last : j; };
 
     double s_surr = 0.0, s_crit = 0.0, s_kl = 0.0, s_cnt = 0.0;
-    // wave-rounds dealt wave-major across the workgroups: q = k * (16 * grid) + wave * grid + block
-    for (int64_t q = (int64_t)wave * gridDim.x + blockIdx.x; q < n_wr; q += (int64_t)WPW * gridDim.x) {
+    // wave-rounds dealt wave-major across the workgroups: q = k * (WPW * grid) + wave * grid + block
+    const int64_t q_step = (int64_t)WPW * gridDim.x;
+    int64_t q = (int64_t)wave * gridDim.x + blockIdx.x;
+    float xr[K4];                                        // the round's input row: step s contracts inputs 4 s + g (g = the lane group)
+    if (q < n_wr) {
+        const float* xq = a.x + q * (16 * 4 * K4);
+        const int jr = lane_row(q);
+#pragma unroll
+        for (int s = 0; s < K4; ++s) xr[s] = xq[jr * (4 * K4) + g + 4 * s];
+    }
+    for (; q < n_wr; q += q_step) {
         const int64_t row = q * 16 + j;
         const bool valid = row < rows;
-        const int64_t rowc = valid ? row : rows - 1;
-        f32x4 xin[NT], xout[NT];
+        const int jr = lane_row(q);
+        F32LossIn lin;
+        if constexpr (kTrain) lin = f32_loss_load(L, q * 16, jr);        // (used after both layers: in flight behind them)
+        f32x4 xin[NT];
         uint32_t mb0 = 0, mb1 = 0;                       // ReLU mask bits of layer 0 / layer 1: tile t -> bits 4 t .. 4 t + 3
-        // ---- layer 0: step s contracts inputs 4 s + g (g = the lane group) ----
-        {
-            float xr[K4];
+        // ---- layer 0 ----
 #pragma unroll
-            for (int s = 0; s < K4; ++s) xr[s] = a.x[rowc * (4 * K4) + 4 * s + g];
+        for (int mo = 0; mo < NT; ++mo) {
+            const float4 b4 = wide_lds_f4(table + 16 * mo + 4 * g);
+            f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int mo = 0; mo < NT; ++mo) {
-                const float4 b4 = wide_lds_f4(table + 16 * mo + 4 * g);
-                f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int s = 0; s < K4; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wide_lds_f(w0_s + (mo * K4 + s) * 64 + lane), xr[s], acc, 0, 0, 0);
-                mb0 |= relu_bits4(acc) << (4 * mo);
-                xin[mo] = acc;
-                if constexpr (kTrain) {
-                    if (a.acts[0] != nullptr) store_tile(a.acts[0], rowc, mo, acc);
-                }
+            for (int s = 0; s < K4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wide_lds_f(w0_s + (mo * K4 + s) * 64 + lane), xr[s], acc, 0, 0, 0);
+            relu_bits4(acc, mb0, 4 * mo);
+            xin[mo] = acc;
+            if constexpr (kTrain) {
+                if (a.acts[0] != nullptr) store_tile(a.acts[0] + q * (16 * H), jr, mo, acc);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                   // (phase boundary: nothing hoisted across, registers stay bounded)
+        {   // the next round's input row, into the registers the products above have just read (the last round re-reads its own)
+            const int64_t qn = q + q_step < n_wr ? q + q_step : q;
+            const float* xq = a.x + qn * (16 * 4 * K4);
+            const int jn = lane_row(qn);
+#pragma unroll
+            for (int s = 0; s < K4; ++s) xr[s] = xq[jn * (4 * K4) + g + 4 * s];
+        }
+        // ---- head: <= 4 outputs as fp32 dot products over the lane's features (tiles in order, registers in order), accumulated tile
+        // by tile as the top layer's tiles come out of the matrix pipe: the top activation is never whole in registers ----
+        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int A = kTrain ? L.A : a.out_dim;
+        auto head_tile = [&](int k, const f32x4& v, int t) {
+#if !(TG_F32R_ABLATE & 8)
+            const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
+            sacc[k] = fmaf(v[0], w.x, sacc[k]);
+            sacc[k] = fmaf(v[1], w.y, sacc[k]);
+            sacc[k] = fmaf(v[2], w.z, sacc[k]);
+            sacc[k] = fmaf(v[3], w.w, sacc[k]);
+#endif
+        };
         if (n_hh == 1) {
+            // (one copy of the layer per output count: a run-time `k < A` inside would cut the schedule of every tile pair)
+            auto layer1 = [&](auto a_tag) {
+                constexpr int AA = decltype(a_tag)::value;
 #pragma unroll
-            for (int mo = 0; mo < NT; ++mo) {
-                const float4 b4 = wide_lds_f4(table + H + 16 * mo + 4 * g);
-                f32x4 acc = tile_products(strm + mo * BLK, xin, f32x4{b4.x, b4.y, b4.z, b4.w});
-                mb1 |= relu_bits4(acc) << (4 * mo);
-                xout[mo] = acc;
-                if constexpr (kTrain) store_tile(a.acts[1], rowc, mo, acc);
+                for (int mo = 0; mo < NT; mo += 2) {
+                    const float4 ba = wide_lds_f4(table + H + 16 * mo + 4 * g), bb = wide_lds_f4(table + H + 16 * (mo + 1) + 4 * g);
+                    f32x4 acc_a = {ba.x, ba.y, ba.z, ba.w}, acc_b = {bb.x, bb.y, bb.z, bb.w};
+                    tile_pair(strm + mo * BLK, strm + (mo + 1) * BLK, xin, acc_a, acc_b);
+                    relu_bits4(acc_a, mb1, 4 * mo);
+                    relu_bits4(acc_b, mb1, 4 * (mo + 1));
+                    if constexpr (kTrain) { store_tile(a.acts[1] + q * (16 * H), jr, mo, acc_a); store_tile(a.acts[1] + q * (16 * H), jr, mo + 1, acc_b); }
+#pragma unroll
+                    for (int k = 0; k < AA; ++k) head_tile(k, acc_a, mo);
+#pragma unroll
+                    for (int k = 0; k < AA; ++k) head_tile(k, acc_b, mo + 1);
+                    __builtin_amdgcn_sched_barrier(0);       // (the next pair's reads stay behind this pair's epilogue: registers)
+                }
+            };
+            switch (A) {
+                case 1: layer1(std::integral_constant<int, 1>{}); break;
+                case 2: layer1(std::integral_constant<int, 2>{}); break;
+                case 3: layer1(std::integral_constant<int, 3>{}); break;
+                default: layer1(std::integral_constant<int, 4>{}); break;
             }
+        } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) xin[t] = xout[t];
+            for (int k = 0; k < 4; ++k)
+                if (k < A) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) head_tile(k, xin[t], t);
+                }
         }
+        __builtin_amdgcn_sched_barrier(0);                   // (phase boundary: nothing hoisted across, registers stay bounded)
         const uint32_t mtop = n_hh == 1 ? mb1 : mb0;
-        // ---- head: <= 4 outputs as fp32 dot products over the lane's features, the four lane groups added in a fixed order ----
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const int A = kTrain ? L.A : 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};                   // the four lane groups added in a fixed order
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < A) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
-                    sacc = fmaf(xin[t][0], w.x, sacc);
-                    sacc = fmaf(xin[t][1], w.y, sacc);
-                    sacc = fmaf(xin[t][2], w.z, sacc);
-                    sacc = fmaf(xin[t][3], w.w, sacc);
-                }
-                const float p1 = __shfl_xor(sacc, 16, 64);
-                const float pair = (g & 1) ? p1 + sacc : sacc + p1;
+                const float p1 = __shfl_xor(sacc[k], 16, 64);
+                const float pair = (g & 1) ? p1 + sacc[k] : sacc[k] + p1;
                 const float p2 = __shfl_xor(pair, 32, 64);
                 o[k] = ((g & 2) ? p2 + pair : pair + p2) + wide_lds_f(bh_s + k);
             }
         if constexpr (!kTrain) {
-            if (valid && g == 0) *reinterpret_cast<float4*>(a.out + row * 4) = float4{o[0], o[1], o[2], o[3]};
+            if (valid && g == 0) *reinterpret_cast<float4*>(a.out + q * 64 + jr * 4) = float4{o[0], o[1], o[2], o[3]};
         } else {
             float gr[4], c_surr, c_crit, c_kl;
-            f32_loss_row<false>(L, o, row, rowc, valid, g == 0, gr, c_surr, c_crit, c_kl);
+#if TG_F32R_ABLATE & 8
+            gr[0] = o[0] + lin.adv; gr[1] = gr[2] = gr[3] = 0.f; c_surr = c_crit = c_kl = o[0];
+#else
+            f32_loss_compute<false>(L, lin, o, row, valid, g == 0, gr, c_surr, c_crit, c_kl);
+#endif
             if (valid && g == 0) {
                 s_surr += (double)c_surr; s_crit += (double)c_crit; s_kl += (double)c_kl; s_cnt += 1.0;
-                *reinterpret_cast<float4*>(L.dout4 + row * 4) = float4{gr[0], gr[1], gr[2], gr[3]};
+                *reinterpret_cast<float4*>(L.dout4 + q * 64 + jr * 4) = float4{gr[0], gr[1], gr[2], gr[3]};
             }
             // the top layer's mask bits in tg_mlp_f32_forward_backward's row format: feature f = 32 mt + 8 q + 4 hh + low is bit
             // low + 4 q + 16 (mt & 1) of word hh * (MT / 2) + (mt >> 1); this lane holds f = 16 t + 4 g + r, i.e. hh = g & 1,
@@ -558,46 +644,49 @@ __global__ __launch_bounds__(64 * kResWaves, 3) void mlp_f32_res_kernel(F32ResAr
                 uint32_t wds[NW];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) v |= ((mtop >> (4 * (4 * w + tt))) & 15u) << (8 * (tt & 1) + 16 * (tt >> 1) + 4 * (g >> 1));
+                    // nibbles 4 w .. 4 w + 3 of mtop -> bytes: (n0 | n1 << 8 | n2 << 16 | n3 << 24), then up by 4 in the upper groups
+                    const uint32_t h = (mtop >> (16 * w)) & 0xffffu;
+                    uint32_t v = (h | (h << 8)) & 0x00ff00ffu;                        // bytes 0 / 2 hold the nibble pairs (n1 n0) / (n3 n2)
+                    v = (v | (v << 4)) & 0x0f0f0f0fu;                                  // one nibble per byte
+                    v <<= 4 * (g >> 1);
                     wds[w] = v | (uint32_t)__shfl_xor((int)v, 32, 64);
                 }
+#if TG_F32R_ABLATE & 1
+                asm volatile("" ::"v"(wds[0]), "v"(wds[1]));
+#else
                 if (g < 2) {
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) a.top_mask[rowc * (2 * NW) + g * NW + w] = wds[w];
+                    for (int w = 0; w < NW; ++w) (a.top_mask + q * (16 * 2 * NW))[jr * (2 * NW) + g * NW + w] = wds[w];
                 }
+#endif
             }
+            __builtin_amdgcn_sched_barrier(0);                   // (phase boundary: nothing hoisted across, registers stay bounded)
             // ---- backward: dZ_top = (g . W_head) * (a_top > 0), then dZ_0 = (W_1^T . dZ_1) * mask ----
+            float* dz_top = n_hh == 1 ? a.dz[1] : a.dz[0];
+            float* dz_top_q = dz_top + q * (16 * H);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const uint32_t mw = mtop >> (4 * t);
-                float4 sv = float4{0.f, 0.f, 0.f, 0.f};
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < L.A) {
                         const float4 w = wide_lds_f4(wh_s + k * H + 16 * t + 4 * g);
-                        sv.x = fmaf(gr[k], w.x, sv.x); sv.y = fmaf(gr[k], w.y, sv.y); sv.z = fmaf(gr[k], w.z, sv.z); sv.w = fmaf(gr[k], w.w, sv.w);
+                        d[0] = fmaf(gr[k], w.x, d[0]); d[1] = fmaf(gr[k], w.y, d[1]); d[2] = fmaf(gr[k], w.z, d[2]); d[3] = fmaf(gr[k], w.w, d[3]);
                     }
-                f32x4 d;
-                d[0] = (mw & 1u) ? sv.x : 0.f;
-                d[1] = (mw & 2u) ? sv.y : 0.f;
-                d[2] = (mw & 4u) ? sv.z : 0.f;
-                d[3] = (mw & 8u) ? sv.w : 0.f;
+                mask4(d, mtop, 4 * t);
                 xin[t] = d;
-                float* dz_top = n_hh == 1 ? a.dz[1] : a.dz[0];
-                if (dz_top != nullptr) store_tile(dz_top, rowc, t, d);
+                if (dz_top != nullptr) store_tile(dz_top_q, jr, t, d);
             }
             if (n_hh == 1) {
 #pragma unroll
-                for (int ko = 0; ko < NT; ++ko) {
-                    f32x4 acc = tile_products(strm + (NT + ko) * BLK, xin, f32x4{0.f, 0.f, 0.f, 0.f});
-                    const uint32_t mw = mb0 >> (4 * ko);
-                    acc[0] = (mw & 1u) ? acc[0] : 0.f;
-                    acc[1] = (mw & 2u) ? acc[1] : 0.f;
-                    acc[2] = (mw & 4u) ? acc[2] : 0.f;
-                    acc[3] = (mw & 8u) ? acc[3] : 0.f;
-                    store_tile(a.dz[0], rowc, ko, acc);
+                for (int ko = 0; ko < NT; ko += 2) {
+                    f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+                    tile_pair(strm + (NT + ko) * BLK, strm + (NT + ko + 1) * BLK, xin, acc_a, acc_b);
+                    mask4(acc_a, mb0, 4 * ko);
+                    mask4(acc_b, mb0, 4 * (ko + 1));
+                    store_tile(a.dz[0] + q * (16 * H), jr, ko, acc_a);
+                    store_tile(a.dz[0] + q * (16 * H), jr, ko + 1, acc_b);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -630,9 +719,9 @@ static int launch_f32_res_k(const F32ResArgs& args, hipStream_t st) {
     const size_t shmem = f32_res_lds<128>(args.n_hh, args.in_pad, kTrain);
     static LdsOptIn opt_in;
     if (int rc = reserve_dynamic_lds((const void*)kern, shmem, opt_in, "tg_mlp_f32r_forward")) return rc;
-    const int64_t wgs = ceil_div(ceil_div(args.rows, (int64_t)16), (int64_t)kResWaves);
+    const int64_t wgs = ceil_div(ceil_div(args.rows, (int64_t)16), (int64_t)res_waves(kTrain));
     const int grid = (int)(wgs < device_cus() ? wgs : device_cus());
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kResWaves), shmem, st, args);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * res_waves(kTrain)), shmem, st, args);
     TG_LAUNCH_CHECK("tg_mlp_f32r_forward");
     return TG_OK;
 }
@@ -943,15 +1032,20 @@ int tg_mlp_f32r_supported(int32_t hidden, int32_t n_hidden_layers, int32_t in_pa
 }
 int64_t tg_mlp_f32r_stream_floats(int32_t hidden, int32_t n_hidden_layers) { return (int64_t)2 * (n_hidden_layers - 1) * (hidden / 16) * (hidden / 16) * 256; }
 int64_t tg_mlp_f32r_w0_floats(int32_t hidden, int32_t in_pad) { return (int64_t)(hidden / 16) * (in_pad / 4) * 64; }
+int tg_mlp_f32r_grid(int64_t rows) {          // workgroups of a training launch = rows of partial loss sums it writes to tg_chain_loss.d_work
+    const int64_t wgs = ceil_div(ceil_div(rows, (int64_t)16), (int64_t)kResWavesTrain);
+    return (int)(wgs < device_cus() ? wgs : device_cus());
+}
 int64_t tg_mlp_f32r_table_floats(int32_t hidden) { return (int64_t)(kResMaxHidden + 4) * hidden + 16; }
 
 int tg_mlp_f32r_forward(const float* d_x, int32_t in_pad, const float* d_stream, const float* d_w0, const float* d_table, int32_t hidden,
-                        int32_t n_hidden_layers, int64_t rows, float* d_out, void* stream) {
+                        int32_t n_hidden_layers, int32_t out_dim, int64_t rows, float* d_out, void* stream) {
     F32ResArgs a{};
     if (int rc = fill_f32_res(a, d_x, in_pad, d_stream, d_w0, d_table, hidden, n_hidden_layers, rows, "tg_mlp_f32r_forward")) return rc;
     TG_REQUIRE(d_out, "tg_mlp_f32r_forward: null output");
+    TG_REQUIRE(out_dim >= 1 && out_dim <= 4, "tg_mlp_f32r_forward: %d outputs (1..4)", out_dim);
     if (rows == 0) return TG_OK;
-    a.out = d_out;
+    a.out = d_out; a.out_dim = out_dim;
     return launch_f32_res<false>(a, (hipStream_t)stream);
 }
 

@@ -348,7 +348,7 @@ class GemmMLP:
             out = torch.empty(xp.shape[0], 4, dtype=torch.float32, device=xp.device)
             if f.res:
                 N.check(N.load().tg_mlp_f32r_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.w0.data_ptr(), f.table.data_ptr(), f.H, f.n_hidden,
-                                                     xp.shape[0], out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32r_forward")
+                                                     f.out_dim, xp.shape[0], out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32r_forward")
             elif f.wide:
                 N.check(N.load().tg_mlp_f32w_forward(xp.data_ptr(), f.in_pad, f.stream.data_ptr(), f.table.data_ptr(), f.n_hidden, xp.shape[0],
                                                      out.data_ptr(), N.stream_ptr(xp.device)), "tg_mlp_f32w_forward")
@@ -562,7 +562,7 @@ class GemmMLP:
             self.fwd_events.append((ev[0], ev[1], rows, 2 * H * self.in_dim + 4 * (nh - 1) * H * H + 4 * H * self.out_dim,
                                     "tg::mlp_f32_wide_kernel<true>" if f.wide else
                                     (f"tg::mlp_f32_res_kernel<{H},{f.in_pad // 4},true>" if f.res else f"tg::mlp_f32_chain_kernel<{H},true>")))
-        grid = min(nblk, -(-rows // (64 if f.wide else (192 if f.res else 256))))      # (the launchers' own grids)
+        grid = lib.tg_mlp_f32r_grid(rows) if f.res else min(nblk, -(-rows // (64 if f.wide else 256)))      # (the launchers' own grids)
         self._acts, self._bits, self._dz_head, self._tmask = [xp] + acts, dzs, dout, tmask
         assert getattr(self, "_loss_rider", None) is None, "forward_loss(sums_out=...) must be followed by backward_fused()"
         if sums_out is not None:
