@@ -33,6 +33,12 @@
 #ifndef TG_F32R_TRAIN_WAVES
 #define TG_F32R_TRAIN_WAVES 12     /* waves per CU of the resident kernel's training launches (probe builds: 16) */
 #endif
+#ifndef TG_F32W_NT_STORE
+#define TG_F32W_NT_STORE 0         /* 1: the same for the H = 256 chain kernel */
+#endif
+#ifndef TG_F32R_NT_STORE
+#define TG_F32R_NT_STORE 1         /* the resident kernel's activation / dZ tiles leave as non-temporal stores (A/B: profiles/r05_f32_res_kernel.md; 0 = plain) */
+#endif
 #ifndef TG_F32R_ABLATE
 #define TG_F32R_ABLATE 0           /* ... of the resident H = 128 kernel: bit 0 = no activation / dZ / mask stores, bit 1 = no matrix products in
                                       the H x H tiles, bit 2 = no LDS reads of their weights, bit 3 = no head / loss arithmetic (tools/f32_res_ablation.sh) */
@@ -187,7 +193,11 @@ __global__ __launch_bounds__(256, 2) void mlp_f32_wide_kernel(F32WideArgs a) {
 #if TG_F32W_ABLATE & 4
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 #else
+#if TG_F32W_NT_STORE
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gptr + row * H + 16 * mo + 4 * g));
+#else
         *reinterpret_cast<float4*>(gptr + row * H + 16 * mo + 4 * g) = float4{v[0], v[1], v[2], v[3]};
+#endif
 #endif
     };
 
@@ -399,9 +409,13 @@ static int fill_f32_wide(F32WideArgs& a, const float* d_x, int32_t in_pad, const
 //   table   [2][H] hidden biases | [4][H] head weights | [4] head bias (+ 12 pad)
 // Outputs as tg_mlp_f32_forward_backward's, including the top layer's mask bits in ITS format (the weight-gradient job of
 // mlp_f32_chain.hip rebuilds the top dZ from them): the two kernels are interchangeable in front of tg_mlp_f32_weight_grad.
+// The matrix pipe is 80 % busy (no-grad launches 89 %); what is left is vector instructions, which on this chip take the pipe's time
+// whichever wave issues them (profiles/r05_f32_res_kernel.md) -- hence: tile PAIRS on one accumulator chain each, ReLU + mask bit
+// in three instructions per element, the head accumulated tile by tile (the top activation is never whole in registers), the next
+// round's input row and this round's loss inputs loaded ahead, a round's addresses as scalar base + small lane offset.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kResWaves = 16;                  // no-grad launches: 4 waves per SIMD (~95 registers)
-constexpr int kResWavesTrain = TG_F32R_TRAIN_WAVES;            // training launches: 3 per SIMD (155 registers; at 128 some 35 of them spill)
+constexpr int kResWavesTrain = TG_F32R_TRAIN_WAVES;            // training launches: 3 per SIMD (143 registers; 16 waves = 128 registers, 22 spilled: measured, no faster)
 constexpr int res_waves(bool train) { return train ? kResWavesTrain : kResWaves; }
 constexpr int kResMaxHidden = 2;
 
@@ -519,7 +533,11 @@ __global__ __launch_bounds__(64 * res_waves(kTrain)) void mlp_f32_res_kernel(F32
 #if TG_F32R_ABLATE & 1
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 #else
+#if TG_F32R_NT_STORE
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(round_base + (jr * H + 4 * g) + 16 * mo));
+#else
         *reinterpret_cast<float4*>(round_base + (jr * H + 4 * g) + 16 * mo) = float4{v[0], v[1], v[2], v[3]};
+#endif
 #endif
     };
     auto lane_row = [&](int64_t q) { const int64_t last = rows - 1 - q * 16; return last < j ? (int)last : j; };
