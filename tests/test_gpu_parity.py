@@ -2256,6 +2256,69 @@ def test_f32_chain_forward_matches_fp64(tg, dev, dims, rows):
     assert pad.shape == (rows, 4) and torch.equal(pad[:, :A].contiguous(), out) and torch.all(pad[:, A:] == 0)
 
 
+@pytest.mark.parametrize("dims", [(5, 1, (128, 128)), (20, 4, (128, 128)), (9, 2, (128,))])
+@pytest.mark.parametrize("rows", [1, 17, 193, 50001])
+def test_f32_resident_kernel_is_interchangeable_with_the_chain_kernel(tg, dev, dims, rows, monkeypatch):
+    """tg_mlp_f32r_forward_backward (16 rows per wave, weights resident in LDS) and tg_mlp_f32_forward_backward (32 rows per wave)
+    on the same net and rows: loss sums, d loss / d output, stored activation / dZ to 1e-5 of their scale (the two sum a row's
+    products in different orders), the top layer's mask words bit for bit wherever the pre-activation is not within rounding of 0
+    (< 1e-4 of the bits may differ), and the gradients tg_mlp_f32_weight_grad forms from either to 2e-5.  Then the new entry
+    points' argument checks (host side, nothing launched)."""
+    from trajopt_grpo_amd import mlp as M
+    Nn = tg._native
+    S, A, hidden = dims
+    torch.manual_seed(rows + S)
+    net = tg.NeuralNetwork(S, A, hidden, "ReLU").to(dev)
+    X = torch.randn(rows, S, device=dev)
+    act = torch.randn(rows, A, device=dev)
+    lpo = (-0.5 * torch.rand(rows, device=dev) - 1.0).contiguous()
+    adv = torch.randn(rows, device=dev)
+    var = torch.full((A,), 0.3)
+
+    def run(resident):
+        with monkeypatch.context() as mp:
+            if not resident:
+                mp.setattr(M, "f32_res_supported", lambda net_: 0)
+            m = M.GemmMLP(net, torch.float32)
+        assert m._f32.res == resident
+        for p_ in net.parameters():
+            p_.grad = torch.zeros_like(p_)
+        xp = m.prepare_input(X)
+        out = m.forward(xp, keep=False, padded=True).clone()
+        sums = m.forward_loss(xp, 0, act=act, logp_old=lpo, adv=adv, norm=[0.1, 1.3, 0.0, 1.0], var=var, epsilon=0.2, surr_coef=-1.0 / rows,
+                              kl_coef=0.5 / rows).clone()
+        keep = {"out": out, "sums": sums, "dout": m._dz_head.clone(), "tmask": None if m._tmask is None else m._tmask.clone(),
+                "acts": [None if t is None else t.clone() for t in m._acts[1:]], "dz": [None if t is None else t.clone() for t in m._bits]}
+        m.backward_fused()
+        keep["grads"] = [p_.grad.clone() for p_ in net.parameters()]
+        return keep
+
+    r, c = run(True), run(False)
+    close = lambda x, y, tol: float((x.double() - y.double()).abs().max()) <= tol * (float(y.double().abs().max()) + 1e-12)
+    assert close(r["out"], c["out"], 1e-5) and close(r["sums"], c["sums"], 1e-6) and close(r["dout"], c["dout"], 1e-5)
+    for x, y in zip(r["acts"] + r["dz"], c["acts"] + c["dz"]):
+        assert (x is None) == (y is None)
+        assert x is None or close(x, y, 1e-5)
+    if r["tmask"] is not None:
+        diff = (r["tmask"] ^ c["tmask"]).view(torch.uint8)
+        flipped = sum(int(((diff >> b) & 1).sum()) for b in range(8))
+        assert flipped <= max(1, int(1e-4 * rows * 128)), flipped
+    for x, y in zip(r["grads"], c["grads"]):
+        assert close(x, y, 2e-5 * max(1.0, (rows / 1000) ** 0.5))
+    # ---- argument checks of the resident entry points ----
+    lib, f = Nn.load(), M.GemmMLP(net, torch.float32)._f32
+    xp = torch.zeros(16, f.in_pad, device=dev)
+    o = torch.zeros(16, 4, device=dev)
+    args = lambda H=128, nh=f.n_hidden, A_=A, pad=f.in_pad: (xp.data_ptr(), pad, f.stream.data_ptr(), f.w0.data_ptr(), f.table.data_ptr(), H, nh, A_, 16,
+                                                              o.data_ptr(), Nn.stream_ptr(dev))
+    assert lib.tg_mlp_f32r_forward(*args()) == 0
+    for bad, what in ((args(H=64), b"hidden width"), (args(nh=3), b"hidden layers"), (args(A_=5), b"outputs"), (args(pad=12), b"padded input width")):
+        assert lib.tg_mlp_f32r_forward(*bad) != 0 and what in lib.tg_last_error(), what
+    assert lib.tg_mlp_f32r_supported(128, 2, 8) == 1 and lib.tg_mlp_f32r_supported(128, 3, 8) == 0 and lib.tg_mlp_f32r_supported(256, 2, 8) == 0
+    assert lib.tg_mlp_f32r_grid(1) == 1 and lib.tg_mlp_f32r_grid(16 * 12 + 1) == 2 and lib.tg_mlp_f32r_grid(1 << 24) == lib.tg_mlp_f32_blocks()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dims", F32_SHAPES)
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("rows", [1, 255, 4000, 70001])
