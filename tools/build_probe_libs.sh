@@ -15,3 +15,4 @@ for v in 3 4 5 6; do build p8abl$v "-DTG_F32DW_ABLATE=$v"; done                 
 for v in 1 2; do build headrelay$v "-DTG_ABLATE_HEAD_RELAY=$v"; done                       # forward chain's head hand-off: removed / without its barriers (tools/head_relay_ab.sh)
 for v in 1 2 4 7 8 16 24; do build f32wabl$v "-DTG_F32W_ABLATE=$v"; done                          # fp32 H = 256 chain kernel: no barrier / no DMA / no stores / none of the three (tools/f32_wide_ablation.sh)
 for v in 1 2 4 6 8 9 15; do build f32rabl$v "-DTG_F32R_ABLATE=$v"; done                        # fp32 resident H = 128 kernel: no stores / no products / no weight reads / neither / no head + loss (tools/f32_res_ablation.sh)
+for v in 1 2 3; do build chainvalu$v "-DTG_ABLATE_CHAIN_VALU=$v"; done                               # bf16 chain kernels with part of their vector instructions removed (sensitivity probe)

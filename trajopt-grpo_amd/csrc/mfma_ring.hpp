@@ -59,6 +59,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef TG_ABLATE_HEAD_RELAY
 #define TG_ABLATE_HEAD_RELAY 0
 #endif
+// Probe builds only (`chainvalu1..3`): how much of the bf16 chain kernels' time their vector instructions are -- bit 0: the forward
+// chain's ReLU mask bits not formed (7 instructions per 8 activations), bit 1: ReLU's clamp of the packed pair left out (1 per pair).
+// Results meaningless.  (profiles/r05_chain_valu_sensitivity.md)
+#ifndef TG_ABLATE_CHAIN_VALU
+#define TG_ABLATE_CHAIN_VALU 0
+#endif
 __device__ static inline int64_t mem_row(int64_t r) {
 #if TG_PROBE_ROW_WINDOW
     return r & (int64_t)(TG_PROBE_ROW_WINDOW - 1);
@@ -83,6 +89,9 @@ __device__ static inline uint32_t relu_pack_bf16x2(float a, float b) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const bf16x2 p = __builtin_convertvector(f32x2{a, b}, bf16x2);          // ONE v_cvt_pk_bf16_f32
+#if TG_ABLATE_CHAIN_VALU & 2
+    return __builtin_bit_cast(uint32_t, p);                                 // (probe build: no clamp)
+#endif
     const i16x2 zero = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, p), zero));
 }
