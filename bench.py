@@ -924,7 +924,8 @@ def run_config(args, ctx, secondary=False):
                                      "traffic": 1706642656 if envs_local == 65536 and agents == 1 else None,
                                      "traffic_source": "profiles/r01_fused_rollout_pmc.json (all-alive launch: 2 x FETCH_SIZE + "
                                                        "WRITE_SIZE = the 101 B/env-step trajectory record; weights stay in L2)",
-                                     "kernel": f"tg::fused_rollout_f32_kernel<{env_name}Env<float>,{hidden[0]},{len(hidden)}>" if f32 else
+                                     "kernel": (f"tg::fused_rollout_f32{'x16' if mgr.engine._f32_block_envs == 16 else ''}_kernel"
+                                                f"<{env_name}Env<float>,{hidden[0]},{len(hidden) - 1}>") if f32 else
                                                "tg::fused_rollout_kernel<QuadPoleEnv<float>,256,1,8>",
                                      "flops_per_env_step": 2 * n_par, "launches": len(launches),
                                      "avg_launch_ms": 1e3 * dur / len(launches),

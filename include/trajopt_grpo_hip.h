@@ -169,13 +169,20 @@ int  tg_fused_rollout(const tg_env_params* p, const tg_traj* tr, const void* d_w
  * whole rollout -- built for latency at the reference's net sizes and a few thousand envs.  The means differ from the
  * GEMM path only by fp32 summation order.  Actor: Linear(S,H) ReLU [Linear(H,H) ReLU]^(n_hidden_layers-1) Linear(H,A),
  * H in {64, 128}, 1..4 hidden layers, S <= 32, A <= 4 (tg_fused_rollout_f32_supported()).
- *   d_wstream: f32 [H/32 waves][K1/2 + (n_hidden_layers-1)*H/2 registers][64 lanes], K1 = S rounded up to 8: register
- *              4q + j of lane (m, kh) of wave w is W[32w + m][8q + 4kh + j] (zero beyond the matrix), first layer
- *              then the H x H layers (trajopt-grpo_amd/mlp.py `RegisterStreamF32`);
+ *   block_envs: 32, or 16 -- the same rollout with sixteen envs per workgroup on v_mfma_f32_16x16x4_f32, for env counts that leave
+ *              CUs without a workgroup at 32 (BASELINE configs[1]: 4,096 envs = 128 workgroups on 256 CUs): a time step is a chain
+ *              of dependent products on the workgroup's one CU, so half the envs are half the step's latency.
+ *              tg_fused_rollout_f32_block_envs(n, agents) says which one the launch should use; it decides the layout of d_wstream.
+ *   d_wstream: f32 [H/32 waves][K1/2 + (n_hidden_layers-1)*H/2 registers][64 lanes], K1 = S rounded up to 8, first layer then
+ *              the H x H layers (zero beyond the matrix; trajopt-grpo_amd/mlp.py `RegisterStreamF32`):
+ *              block_envs 32: register 4q + j of lane (m, kh) of wave w is W[32w + m][8q + 4kh + j];
+ *              block_envs 16: register tt * (k / 4) + s of lane (i, g) of wave w is W[32w + 16 tt + i][first layer: 4 s + g;
+ *                             H x H: 16 (s >> 2) + 4 g + (s & 3)]   (k = the layer's padded input width, tt = 0, 1);
  *   d_tab:     f32 [(n_hidden_layers)*H hidden biases][4*H head weights, rows >= A zero][4 head biases]. */
 int  tg_fused_rollout_f32_supported(int32_t hidden, int32_t n_hidden_layers);
+int  tg_fused_rollout_f32_block_envs(int64_t n, int32_t agents);
 int  tg_fused_rollout_f32(const tg_env_params* p, const tg_traj* tr, const float* d_wstream, const float* d_tab,
-                          int32_t hidden, int32_t n_hidden_layers, const float* sigma, const uint64_t* d_rng,
+                          int32_t hidden, int32_t n_hidden_layers, int32_t block_envs, const float* sigma, const uint64_t* d_rng,
                           int64_t env_offset, int32_t t_begin, int32_t t_end, void* stream);
 
 /* d_rng[1] += 1 (enqueued; one thread) */

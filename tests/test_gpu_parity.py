@@ -1082,19 +1082,23 @@ def test_fused_rollout_matches_unfused_path(tg, dev, name, hidden):
 
 @pytest.mark.parametrize("name,hidden", [("CartPole", (128, 128)), ("CartPole", (128, 128, 128, 128)), ("QuadPole2D", (128, 128, 128)),
                                          ("QuadPole", (64, 64)), ("QuadPole", (128,)), ("Pendulum", (64, 64, 64))])
-def test_fused_f32_rollout_matches_unfused_path(tg, dev, name, hidden):
-    """tg_fused_rollout_f32 (fp32 products on the matrix cores, register-resident weights) against the per-step path:
-    same reset and Philox draws, means equal to fp32 summation order; its recorded trajectory replays bit-exactly
-    through the teacher-forced step kernel; a rollout split into two launches equals the unsplit one."""
+@pytest.mark.parametrize("block_envs", [16, 32])
+def test_fused_f32_rollout_matches_unfused_path(tg, dev, name, hidden, block_envs):
+    """tg_fused_rollout_f32 (fp32 products on the matrix cores, register-resident weights; both forms: 32 envs per workgroup on
+    v_mfma_f32_32x32x2_f32 and 16 on v_mfma_f32_16x16x4_f32) against the per-step path: same reset and Philox draws, means equal
+    to fp32 summation order; its recorded trajectory replays bit-exactly through the teacher-forced step kernel; a rollout split
+    into two launches equals the unsplit one."""
     S, A = DIMS[name]
-    T, G, Eps = 40, 3, 43                       # 129 envs: 4 full workgroups + one with a single env
+    T, G, Eps = 40, 3, 43                       # 129 envs: full workgroups + one with a single env
     torch.manual_seed(8)
     pol = tg.GaussianActor_NeuralNetwork(S, A, hidden, cov=0.3, device=dev)
     mk = lambda: tg.environments.ENV_CLASSES[name](max_steps=T)
     fused = tg.DeviceRollout(mk(), pol, G, Eps, seed=22)
+    fused.f32_block_envs = block_envs
     plain = tg.DeviceRollout(mk(), pol, G, Eps, seed=22, fused=False)
     assert fused.fused and fused._fused_f32 and not plain.fused
     tf = fused.run()
+    assert fused._frag.block_envs == block_envs
     fo, fa, fr, fm, fl = (x.clone() for x in (tf.obs, tf.act, tf.rew, tf.mask, tf.len))
     tp = plain.run()
     assert torch.equal(tp.obs[:, 0, :], fo[:, 0, :])                           # same reset draw
@@ -1117,6 +1121,7 @@ def test_fused_f32_rollout_matches_unfused_path(tg, dev, name, hidden):
     assert torch.all(fr[~m] == 0) and torch.all(fa[:, ~m] == 0) and torch.all(fo[:, :T][:, ~m] == 0)
     # split launch: [0, 13) then [13, T) gives the same bits as one launch
     split = tg.DeviceRollout(mk(), pol, G, Eps, seed=22)
+    split.f32_block_envs = block_envs
     split._seed_host, split._stream_host = 22, 0
     with torch.cuda.device(dev):
         split._enqueue_prepare(None)
@@ -1148,18 +1153,25 @@ def test_fused_rollout_auto_selection_and_manager(tg, dev):
 # --------------------------------------------------------------------------------------------
 # swarm (BASELINE config 5; build-defined semantics, no reference oracle beyond n_agents = 1)
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fused,cdt", [(False, torch.bfloat16), (True, torch.bfloat16), (True, None)])
-def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused, cdt):
-    """cdt None + fused: the fp32 fused rollout kernel (tg_fused_rollout_f32); bf16 + fused: tg_fused_rollout."""
+@pytest.mark.parametrize("fused,cdt,block_envs", [(False, torch.bfloat16, None), (True, torch.bfloat16, None), (True, None, 16), (True, None, 32)])
+def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused, cdt, block_envs):
+    """cdt None + fused: the fp32 fused rollout kernel (tg_fused_rollout_f32, 16 / 32 envs per workgroup); bf16 + fused: tg_fused_rollout."""
     T, G, Eps, K = 48, 2, 16, 8
     torch.manual_seed(8)
     pol = tg.GaussianActor_NeuralNetwork(20, 4, (128, 128), cov=0.3, device=dev)
     kw = dict(seed=5, compute_dtype=cdt, fused=fused)
-    swarm = tg.DeviceRollout(tg.QuadPoleSwarm(n_agents=K, max_steps=T), pol, G, Eps, **kw).run()
+
+    class _Roll:                                               # DeviceRollout with the fp32 kernel's block size fixed before run()
+        def __call__(self, *args, **kwargs):
+            eng = tg.DeviceRollout(*args, **kwargs)
+            eng.f32_block_envs = block_envs
+            return eng
+    roll = _Roll()
+    swarm = roll(tg.QuadPoleSwarm(n_agents=K, max_steps=T), pol, G, Eps, **kw).run()
     s_len, s_act, s_obs = swarm.len.clone(), swarm.act.clone(), swarm.obs.clone()
     assert swarm.n == G * Eps * K and swarm.E == Eps * K
     # the same env slots stepped as independent QuadPole bodies: same Philox keys, same initial states
-    indep = tg.DeviceRollout(tg.QuadPole(max_steps=T), pol, G, Eps * K, **kw).run()
+    indep = roll(tg.QuadPole(max_steps=T), pol, G, Eps * K, **kw).run()
     assert torch.equal(indep.obs[:, 0, :], s_obs[:, 0, :])
     # every body of an env stops with the env, at the first step any of its bodies would have stopped alone
     per_env = s_len.view(-1, K)
@@ -1170,7 +1182,7 @@ def test_swarm_termination_couples_the_bodies_of_an_env(tg, dev, fused, cdt):
     assert torch.equal(s_act[:, t_keep], indep.act[:, t_keep])
     assert (per_env[:, 0] < T).any() and (per_env[:, 0] > 1).all()
     # n_agents = 1 is the plain env, bit for bit
-    one = tg.DeviceRollout(tg.QuadPoleSwarm(n_agents=1, max_steps=T), pol, G, Eps * K, **kw).run()
+    one = roll(tg.QuadPoleSwarm(n_agents=1, max_steps=T), pol, G, Eps * K, **kw).run()
     for a, b in ((one.obs, indep.obs), (one.act, indep.act), (one.rew, indep.rew), (one.len, indep.len)):
         assert torch.equal(a, b)
 

@@ -285,6 +285,51 @@ def test_register_stream_f32_layout_follows_the_lds_exchange_order():
     assert rs.stream.view(4, R, 64)[1, K1 // 2 + 64 + 5, 7].item() == 2.0 * old
 
 
+def test_register_stream_f32_sixteen_env_layout_reproduces_the_net():
+    """The 16-envs-per-workgroup form of tg_fused_rollout_f32 (v_mfma_f32_16x16x4_f32: A lane (i, g) = A[i][g], B lane (j, g) = B[g][j],
+    accumulator register r of lane (j, g) = row 4 g + r), restated on the host from mlp.RegisterStreamF32(block_envs=16): wave w owns
+    two 16-feature tiles; the first layer's step s contracts inputs 4 s + g; an H x H layer's step 4 q + e contracts the features
+    16 q + 4 g + e a lane reads back from LDS group 4 q + g.  One env through the whole net in fp64 against torch."""
+    torch.manual_seed(4)
+    S, A, H = 10, 2, 128
+    net = tg.NeuralNetwork(S, A, (H, H, H), "ReLU")
+    rs = tg.mlp.RegisterStreamF32(net, H, 16)
+    lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
+    K1 = 16
+    R = K1 // 2 + 2 * (H // 2)
+    st = rs.stream.double().view(H // 32, R, 64).numpy()
+    tab = rs.table.double().numpy()
+    x = np.zeros(K1)
+    x[:S] = torch.randn(S).numpy()
+    a = np.zeros(H)
+    for w in range(H // 32):
+        for tt in range(2):
+            for i in range(16):
+                f = 32 * w + 16 * tt + i
+                a[f] = tab[f] + sum(st[w, tt * (K1 // 4) + s_, i + 16 * g] * x[4 * s_ + g] for s_ in range(K1 // 4) for g in range(4))
+    a = np.maximum(a, 0)
+    h = torch.relu(lin[0].weight.double() @ torch.from_numpy(x[:S]) + lin[0].bias.double())
+    np.testing.assert_allclose(a, h.detach().numpy(), rtol=1e-12, atol=1e-12)
+    for l in (1, 2):
+        nxt = np.zeros(H)
+        base = K1 // 2 + (l - 1) * (H // 2)
+        for w in range(H // 32):
+            for tt in range(2):
+                for i in range(16):
+                    f = 32 * w + 16 * tt + i
+                    nxt[f] = tab[l * H + f] + sum(st[w, base + tt * (H // 4) + 4 * q + e, i + 16 * g] * a[16 * q + 4 * g + e]
+                                                  for q in range(H // 16) for e in range(4) for g in range(4))
+        a = np.maximum(nxt, 0)
+        h = torch.relu(lin[l].weight.double() @ h + lin[l].bias.double())
+        np.testing.assert_allclose(a, h.detach().numpy(), rtol=1e-12, atol=1e-12)
+    # the same tables as the 32-env form; a different permutation of the same weights
+    rs32 = tg.mlp.RegisterStreamF32(net, H)
+    assert torch.equal(rs.table, rs32.table) and rs.stream.numel() == rs32.stream.numel() and not torch.equal(rs.stream, rs32.stream)
+    assert torch.equal(torch.sort(rs.stream)[0], torch.sort(rs32.stream)[0])
+    lib = tg._native.load()
+    assert lib.tg_fused_rollout_f32_block_envs(1 << 20, 1) == 32 and lib.tg_fused_rollout_f32_block_envs(64, 32) == 32
+
+
 def test_every_public_member_of_the_reference_classes_exists_on_the_drop_in():
     """tests/golden/reference_public_members.json (oracle/tools/gen_members.py: the member NAMES of the reference's classes, read off the
     imported reference) against the drop-in: each name is there (`QuadPole2D.out_of_bounds`, `Env._dynamics`,

@@ -126,7 +126,8 @@ SIGNATURES = {
     "tg_rollout_finish_stats": (C.c_int, [_P(Traj), _VP, _VP, _VP, _VP]),
     "tg_fused_rollout": (C.c_int, [_P(EnvParams), _P(Traj), _VP, _VP, _I32, _I32, _P(_F), _VP, _I64, _I32, _I32, _VP]),
     "tg_fused_rollout_f32_supported": (C.c_int, [_I32, _I32]),
-    "tg_fused_rollout_f32": (C.c_int, [_P(EnvParams), _P(Traj), _VP, _VP, _I32, _I32, _P(_F), _VP, _I64, _I32, _I32, _VP]),
+    "tg_fused_rollout_f32_block_envs": (C.c_int, [_I64, _I32]),
+    "tg_fused_rollout_f32": (C.c_int, [_P(EnvParams), _P(Traj), _VP, _VP, _I32, _I32, _I32, _P(_F), _VP, _I64, _I32, _I32, _VP]),
     "tg_rng_advance": (C.c_int, [_VP, _VP]),
     "tg_colsum_finish": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "tg_head_prep_blocks": (C.c_int, []),

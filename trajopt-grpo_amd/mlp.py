@@ -978,11 +978,14 @@ def fused_rollout_f32_supported(net, obs_dim: int, act_dim: int) -> int:
 
 class RegisterStreamF32:
     """fp32 weights in the order tg_fused_rollout_f32 loads them into registers, refreshed from the master weights
-    with one gather: [H/32 waves][K1/2 + n_hh*H/2 registers][64 lanes]; register 4q + j of lane (m, kh) of wave w holds
-    W[32w + m][8q + 4kh + j] (first layer: K1 = in_features rounded up to 8, zero beyond).  `table` =
-    [n_hidden*H hidden biases][4*H head weights][4 head biases]."""
+    with one gather: [H/32 waves][K1/2 + n_hh*H/2 registers][64 lanes] (first layer: K1 = in_features rounded up to 8, zero beyond).
+    block_envs 32: register 4q + j of lane (m, kh) of wave w holds W[32w + m][8q + 4kh + j];
+    block_envs 16: register tt * (k / 4) + s of lane (i, g) holds W[32w + 16 tt + i][first layer: 4 s + g; H x H: 16 (s >> 2) + 4 g + (s & 3)].
+    `table` = [n_hidden*H hidden biases][4*H head weights][4 head biases]."""
 
-    def __init__(self, net, H: int):
+    def __init__(self, net, H: int, block_envs: int = 32):
+        assert block_envs in (16, 32)
+        self.block_envs = block_envs
         lin = [m for m in net.network if isinstance(m, torch.nn.Linear)]
         self.lin, self.H = lin, H
         dev = lin[0].weight.device
@@ -992,10 +995,15 @@ class RegisterStreamF32:
         lane = torch.arange(64, device=dev).view(1, 1, -1)
         wave = torch.arange(H // 32, device=dev).view(-1, 1, 1)
         idx, off = [], 0
-        for k in self._k:
+        for li, k in enumerate(self._k):
             r = torch.arange(k // 2, device=dev).view(1, -1, 1)
-            row = 32 * wave + (lane & 31)
-            colk = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)
+            if block_envs == 32:
+                row = 32 * wave + (lane & 31)
+                colk = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)
+            else:
+                tt, s_ = r // (k // 4), r % (k // 4)
+                row = 32 * wave + 16 * tt + (lane & 15)
+                colk = 4 * s_ + (lane >> 4) if li == 0 else 16 * (s_ >> 2) + 4 * (lane >> 4) + (s_ & 3)
             idx.append(off + row * k + colk)                   # [waves][k/2][64]
             off += H * k
         self._idx = torch.cat(idx, dim=1).reshape(-1)

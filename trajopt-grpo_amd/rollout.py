@@ -157,6 +157,10 @@ class DeviceRollout:
         # True: a teacher-forced replay runs as T launches of the golden-pinned tg_rollout_step instead of one tg_rollout_forced
         # launch (the parity tests replay both ways and compare bits)
         self.forced_per_step = False
+        # 16 / 32: envs per workgroup of the fp32 fused rollout, fixed before the first run() (tests hold both kernels to the same
+        # bar); None: tg_fused_rollout_f32_block_envs decides
+        self.f32_block_envs = None
+        self._f32_block_envs = 32
 
     # ---- policy mean for time step t -------------------------------------------------
     def _refresh_weights(self, entry: bool = False):
@@ -243,7 +247,12 @@ class DeviceRollout:
         """All steps [t_begin, t_end) in one persistent launch (tg_fused_rollout)."""
         lib, tr, st = self.lib, self.traj.native(), N.stream_ptr(self.device)
         if self._frag is None:
-            self._frag = (M.RegisterStreamF32 if self._fused_f32 else M.FragmentStream)(self.policy.actor, self._fused_H)
+            if self._fused_f32:
+                # 16 envs per workgroup while every workgroup still gets a CU of its own (C2's 4,096 envs), else 32
+                self._f32_block_envs = self.f32_block_envs or lib.tg_fused_rollout_f32_block_envs(self.n, int(self.params.agents))
+                self._frag = M.RegisterStreamF32(self.policy.actor, self._fused_H, self._f32_block_envs)
+            else:
+                self._frag = M.FragmentStream(self.policy.actor, self._fused_H)
         elif N.TRUST_KEYS and getattr(self._frag, "is_fresh", lambda: False)():
             pass                                                  # (the learner's last launch rebuilt this stream, and the keys are trusted)
         else:
@@ -259,7 +268,7 @@ class DeviceRollout:
             ev[0].record()
         if self._fused_f32:
             N.check(lib.tg_fused_rollout_f32(C.byref(self.params), C.byref(tr), self._frag.stream.data_ptr(),
-                                             self._frag.table.data_ptr(), self._fused_H, n_hidden, self._sigma,
+                                             self._frag.table.data_ptr(), self._fused_H, n_hidden, self._f32_block_envs, self._sigma,
                                              self.rng.data_ptr(), self.group_offset * self.E, t_begin, t_end, st),
                     "tg_fused_rollout_f32")
         else:
