@@ -40,6 +40,8 @@ __device__ static inline f32x16 bias_rows_f32(const float* __restrict__ b) {
     return acc;
 }
 
+__device__ static inline float4 f32r_lds_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+
 __device__ static inline void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // not __syncthreads(): that would also wait for the trajectory stores
     __builtin_amdgcn_s_barrier();
@@ -257,6 +259,21 @@ __global__ __launch_bounds__(64 * (H / 32)) void fused_rollout_f32x16_kernel(
 
     for (int32_t t = t0; t < t1; ++t) {
         if (__ballot(alive) == 0ull) break;                  // the same 16 envs in every wave: a uniform exit
+        // ---- the step's noise first: it depends on (env, t) only, and its ~100 vector instructions fill the products' latencies ----
+        float eps[4];
+        {
+            uint32_t rnd[4];
+            Philox::draw(rng[0], (uint64_t)(env_offset + ic), (uint32_t)t, (uint32_t)rng[1], rnd);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (2 * hh < A) {
+                    const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(Philox::u01(rnd[2 * hh])));
+                    const float rev = Philox::u01(rnd[2 * hh + 1]);
+                    eps[2 * hh] = rad * __builtin_amdgcn_cosf(rev);
+                    eps[2 * hh + 1] = rad * __builtin_amdgcn_sinf(rev);
+                }
+            }
+        }
         // ---- layer 1: B operands straight from the state registers (feature 4 s + g at step s) ----
         f32x4r acc[2];
 #pragma unroll
@@ -284,18 +301,23 @@ __global__ __launch_bounds__(64 * (H / 32)) void fused_rollout_f32x16_kernel(
             lds_barrier();
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) acc[tt] = bias4(tab_s + (l + 1) * H + 32 * wave + 16 * tt + 4 * g);
+            // (the next group's operands are requested before this group's eight products: hipcc otherwise reads each group into the
+            //  same registers right in front of its products -- eight exposed LDS latencies per layer and step)
+            float4 x = f32r_lds_f4(buf + (g * E + col) * 4);
 #pragma unroll
             for (int q = 0; q < H / 16; ++q) {
-                const float4 x = *reinterpret_cast<const float4*>(buf + ((4 * q + g) * E + col) * 4);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][0][4 * q], x.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][1][4 * q], x.x, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][0][4 * q + 1], x.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][1][4 * q + 1], x.y, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][0][4 * q + 2], x.z, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][1][4 * q + 2], x.z, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][0][4 * q + 3], x.w, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][1][4 * q + 3], x.w, acc[1], 0, 0, 0);
+                float4 xn = x;
+                if (q + 1 < H / 16) xn = f32r_lds_f4(buf + ((4 * (q + 1) + g) * E + col) * 4);
+                const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __builtin_amdgcn_sched_barrier(0);               // (the two chains stay interleaved, the read stays in front of the group)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][0][4 * q + e], xe[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[l][1][4 * q + e], xe[e], acc[1], 0, 0, 0);
+                }
+                x = xn;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -332,22 +354,8 @@ __global__ __launch_bounds__(64 * (H / 32)) void fused_rollout_f32x16_kernel(
         }
         // ---- sample, step, record (same arithmetic and RNG keys as rollout_step_kernel) ----
         float a[A];
-        {
-            uint32_t rnd[4];
-            Philox::draw(rng[0], (uint64_t)(env_offset + ic), (uint32_t)t, (uint32_t)rng[1], rnd);
-            float eps[4];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (2 * hh < A) {
-                    const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(Philox::u01(rnd[2 * hh])));
-                    const float rev = Philox::u01(rnd[2 * hh + 1]);
-                    eps[2 * hh] = rad * __builtin_amdgcn_cosf(rev);
-                    eps[2 * hh + 1] = rad * __builtin_amdgcn_sinf(rev);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < A; ++k) a[k] = rn_add(mu[k], rn_mul(sigma.v[k], eps[k]));
-        }
+        for (int k = 0; k < A; ++k) a[k] = rn_add(mu[k], rn_mul(sigma.v[k], eps[k]));
         float o[S], r;
         const StepOut out = Env::step(s, a, c, t + 1, o, r);
         bool ended = out.truncated;
